@@ -1,0 +1,143 @@
+"""The oracle (oracle/prmf_oracle.py) against golden vectors produced by the
+reference itself (oracle/gen_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from oracle import prmf_oracle as orc
+
+TOL = 1e-11   # float64 restatement vs float64 reference: summation-order noise only
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def oracle_pathways(case):
+    n = case["X"].shape[1]
+    return [orc.pathway_from_edges(n, e, nodes, w) for (e, w, nodes) in case["pathways"]]
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("g1_inner1.npz", {"seed": 2}),
+    ("g2_inner25.npz", {}),
+    ("g3_zero_row.npz", {"zero_row": True}),
+    ("g9_bf16x.npz", {"bf16_x": True}),
+])
+def test_inner_loop_matches_reference(golden_dir, name, kw):
+    g = load(golden_dir, name)
+    case = synth.small_case(**({"seed": 1} | kw))
+    assert synth.sha16(case["X"]) == str(g["x_sha"])
+    pws = oracle_pathways(case)
+    active = [pws[k] for k in range(case["k"])]
+    U, V = case["U0"], case["V0"]
+    snaps = list(g["snap_steps"])
+    for step in range(1, int(snaps[-1]) + 1):
+        tr = []
+        U, V, od = orc.nmf_manifold_vec_update(case["X"], U, V, active, n_steps=1,
+                                               gamma=case["gamma"], delta=case["delta"], trace=tr)
+        row = g["obj"][step - 1]
+        for j, key in enumerate(["recon", "manifold", "ignore", "fro", "gamma", "delta", "obj"]):
+            assert abs(od[key] - row[j]) <= TOL * max(1.0, abs(row[j])), (step, key)
+        if step in snaps:
+            i = snaps.index(step)
+            assert rel(U, g["U"][i]) < TOL and rel(V, g["V"][i]) < TOL
+    if "zero_row" in kw:
+        assert np.all(U[3] == 0.0)           # absorbing zeros in U (never clamped)
+    assert V.min() >= orc.EPSILON
+
+
+def test_lean_objective_equals_faithful(golden_dir):
+    g = load(golden_dir, "g2_inner25.npz")
+    case = synth.small_case(seed=1)
+    pws = oracle_pathways(case)
+    U, V = g["U"][-1], g["V"][-1]
+    od = orc.nmf_manifold_vec_obj(case["X"], U, V, pws[:case["k"]], case["gamma"], case["delta"], lean=True)
+    assert abs(od["recon"] - g["obj"][-1][0]) < 1e-9 * g["obj"][-1][0]
+    assert abs(od["obj"] - g["obj"][-1][6]) < 1e-10 * g["obj"][-1][6]
+
+
+def test_tradeoff_matches_reference(golden_dir):
+    g = load(golden_dir, "g4_tradeoff15.npz")
+    case = synth.small_case(seed=1)
+    pws = oracle_pathways(case)
+    tr = []
+    U, V, od, gam, dlt = orc.nmf_manifold_vec_update_tradeoff(
+        case["X"], case["U0"], case["V0"], pws[:case["k"]], n_steps=15,
+        tradeoff=float(g["tradeoff"]), gamma=case["gamma"], delta=case["delta"], trace=tr)
+    got = np.array([[o[k] for k in ["recon", "manifold", "ignore", "fro", "gamma", "delta", "obj"]] for o in tr])
+    assert np.allclose(got, g["obj"], rtol=1e-10, atol=0)
+    assert rel(U, g["U"][-1]) < 1e-10 and rel(V, g["V"][-1]) < 1e-10
+    assert np.allclose([gam, dlt], g["final_gamma_delta"], rtol=1e-10)
+
+
+def test_restrict_scores_and_kept_sets(golden_dir):
+    g = load(golden_dir, "g5_restrict.npz")
+    case = synth.small_case(seed=3, P=12)
+    pws = oracle_pathways(case)
+    V = g["V"]
+    S = orc.score_matrix(V, pws)
+    assert np.allclose(S, g["scores"], rtol=1e-11, atol=1e-13)
+    l2p = {k: [(p, 1) for p in range(len(pws))] for k in range(V.shape[1])}
+    kept = orc.restrict(V, pws, l2p)
+    mask = np.zeros_like(g["kept"])
+    for k, lst in kept.items():
+        for p, _ in lst:
+            mask[k, p] = 1
+    assert np.array_equal(mask, g["kept"])
+
+
+def _graphs_to_pathways(c):
+    import networkx as nx
+    pws = []
+    for fp in c["manifolds"]:
+        G = nx.read_graphml(fp).to_undirected()
+        G = nx.relabel_nodes(G, {x: G.nodes[x]["name"] for x in G.nodes()})
+        pws.append(orc.pathway_from_graph(G, c["nodelist_ids"]))
+    return pws
+
+
+@pytest.mark.parametrize("name,tradeoff", [("g6_api.npz", None), ("g6_api_tradeoff.npz", 0.5)])
+def test_outer_solver_trace_matches_reference(golden_dir, tmp_path, name, tradeoff):
+    g = load(golden_dir, name)
+    c = synth.cli_case(str(tmp_path), variant=1)
+    assert synth.sha16(c["X"]) == str(g["x_sha"])
+    pws = _graphs_to_pathways(c)
+    trace, rounds = [], []
+    np.random.seed(1)
+    U, V, od = orc.nmf_pathway(c["X"], pws, gamma=1.0, tradeoff=tradeoff, k_latent=6,
+                               trace=trace, round_log=rounds)
+    assert np.array_equal(np.array(rounds), g["rounds"])
+    assert np.allclose([t["obj"] for t in trace], g["trace"], rtol=1e-9)
+    l2p = od["latent_to_pathway_data"]
+    assert [int(l2p[k][0][0]) for k in sorted(l2p)] == list(g["final_map"])
+    assert rel(U, g["U"]) < 1e-9 and rel(V, g["V"]) < 1e-9
+
+
+def test_reference_stale_golden_gamma_delta(golden_dir):
+    """The only golden file the reference ships
+    (test_inferred_nodelist_1_expected_obj.txt) is stale except for its
+    gamma/delta lines: gamma = 8337.63767, delta = 0.00020.
+    Both are functions of ||X|| only, so they pin the data generator and the
+    gamma/delta scaling of prmf_runner.py:644-645."""
+    vals = json.loads(str(load(golden_dir, "g6_nonorm.npz")["obj_txt"]))
+    assert "{:0.5f}".format(vals["gamma"]) == "8337.63767"
+    assert "{:0.5f}".format(vals["delta"]) == "0.00020"
+
+
+def test_embed_and_cv_helpers():
+    rs = np.random.RandomState(0)
+    arr = rs.rand(4, 3)
+    out = orc.embed_arr(["a", "b", "c", "d", "e"], ["d", "a", "c"], arr)
+    assert np.array_equal(out[:, 3], arr[:, 0]) and np.array_equal(out[:, 0], arr[:, 1])
+    assert np.all(out[:, [1, 4]] == 0)
+    V = rs.rand(30, 3)
+    Xt = rs.rand(5, 3) @ V.T
+    assert np.all(orc.measure_cv_performance(V, Xt) < 1e-6)
