@@ -1,0 +1,204 @@
+/*
+ * prmf_hip.h -- C-ABI of libprmf_hip.so: the MI355X (gfx950) implementation of
+ * PRMF's alternating multiplicative-update inner loop.
+ *
+ * The reference (gitter-lab/prmf) has no FFI; its boundary for this path is the
+ * Python function
+ *     nmf_manifold_vec_update(X, U, V, k_to_W, k_to_D, k_to_L, k_to_feat_inds,
+ *                             n_steps, gamma, delta, i, verbose, norm_X)
+ *                                             script/prmf_runner.py:374-451
+ * (+ its _tradeoff twin :497-554 and the objective :336-372), called once per
+ * round of `modulus` iterations by nmf_pathway (:740/:742).  The entry points
+ * below are what a ctypes binding for that call needs; INTEGRATION.md shows the
+ * stub.  Conventions: plain pointers and sizes, no torch types; every function
+ * returns 0 or a negative prmf_status and never throws; no hidden global state
+ * (one ctx per device/rank, a ctx is not thread-safe); all device work is
+ * enqueued on the caller's HIP stream (`stream` = hipStream_t as void*, NULL =
+ * default stream); only the calls documented as synchronising wait for it.
+ *
+ * Device buffers passed in (U, V, comm buffers) are owned by the caller (the
+ * Python host allocates them as torch tensors); everything else is owned by ctx.
+ */
+#ifndef PRMF_HIP_H
+#define PRMF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRMF_ABI_VERSION 1
+
+typedef struct prmf_ctx prmf_ctx;
+
+enum prmf_status {
+  PRMF_OK = 0,
+  PRMF_ERR_ARG = -1,         /* bad argument / shape / alignment */
+  PRMF_ERR_HIP = -2,         /* a HIP runtime call failed (see prmf_last_error) */
+  PRMF_ERR_STATE = -3,       /* call order violated (e.g. step before set_x) */
+  PRMF_ERR_NUMERIC = -4,     /* NaN/Inf in the objective: the reference would raise
+                                FloatingPointError (np.seterr(divide='raise'), prmf_runner.py:22) */
+  PRMF_ERR_UNSUPPORTED = -5
+};
+
+enum prmf_x_dtype {
+  PRMF_X_F32 = 0,            /* X float32, fp32 MFMA (exact fp32 products)            */
+  PRMF_X_BF16 = 1            /* X bfloat16, bf16 MFMA with hi+lo split factors, fp32 acc */
+};
+
+/* objective record written per iteration: the keys of the reference's obj_data
+ * dict (prmf_runner.py:363-371) in this order, + recon^2 for diagnostics */
+#define PRMF_OBJ_STRIDE 8
+enum { PRMF_OBJ_RECON = 0, PRMF_OBJ_MANIFOLD, PRMF_OBJ_IGNORE, PRMF_OBJ_FRO,
+       PRMF_OBJ_GAMMA, PRMF_OBJ_DELTA, PRMF_OBJ_OBJ, PRMF_OBJ_RECON_SQ };
+
+int prmf_abi_version(void);
+
+/* Human-readable text of the last failure on ctx (ctx == NULL: last failure of
+ * prmf_create in this thread).  Valid until the next call on the same ctx. */
+const char* prmf_last_error(const prmf_ctx* ctx);
+
+/*
+ * One context per GPU / rank.  X is row-sharded over `nranks` ranks: this rank
+ * holds `m_local` of the samples; n (genes) and k (latent) are global.  The k
+ * latent columns (and their active pathway Laplacians) are sharded for the
+ * V-update: rank r owns columns [r*kc, min(k,(r+1)*kc)), kc = ceil(k/nranks).
+ * Replaces: the shapes implied by X/U/V at prmf_runner.py:417-418.
+ */
+int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k,
+                int x_dtype, int nranks, int rank, unsigned flags);
+int prmf_destroy(prmf_ctx* ctx);
+
+/*
+ * Upload the data matrix.  dX: device pointer, m_local x n row-major with row
+ * stride `ld` elements, dtype as given to prmf_create.  The library keeps its
+ * own zero-padded copy of X and of X^T in HBM (both sweeps then stream a
+ * row-major operand), so the caller may free dX after the stream has passed
+ * this call.  norm_x_sq = ||X||_F^2 of the GLOBAL matrix (all ranks), needed by
+ * the Gram-identity form of the reconstruction error.
+ * Replaces: the `X` argument of nmf_manifold_vec_update (prmf_runner.py:374).
+ */
+int prmf_set_x(prmf_ctx* ctx, const void* dX, int64_t ld, double norm_x_sq, void* stream);
+
+/*
+ * Upload the whole pathway library once (host pointers; copied to the device).
+ * Pathway p has support nodes sup_idx[sup_ptr[p] .. sup_ptr[p+1]) (gene indices,
+ * in G.nodes() order -- prmf_runner.py:689-690).  For the s-th support node
+ * overall: sup_deg[s] = column sum of W (diagonal of D, :680-682), sup_ldiag[s]
+ * = L[i,i] = deg - W[i,i] (normalize_laplacian reads it, :60), and its
+ * adjacency row is entries row_ptr[s] .. row_ptr[s+1) of (col_local, w), where
+ * col_local indexes the SAME pathway's support list.
+ * Replaces: the Ws/Ds/Ls/lapl_to_feat_inds lists built at prmf_runner.py:673-690
+ * and the NORMALIZED_LAPLACIANS global (:693-696).
+ */
+int prmf_set_pathway_library(prmf_ctx* ctx, int P,
+                             const int64_t* sup_ptr, const int32_t* sup_idx,
+                             const double* sup_deg, const double* sup_ldiag,
+                             const int64_t* row_ptr, const int32_t* col_local,
+                             const double* w, void* stream);
+
+/*
+ * Choose the active pathway of every latent column for the next steps
+ * (k host ints, indices into the library).
+ * Replaces: map_k_to_lapls (prmf_runner.py:260-270, called at :730).
+ */
+int prmf_set_active(prmf_ctx* ctx, const int32_t* k_to_lapl, void* stream);
+
+/*
+ * Tell the library that the caller changed U or V (or their pointers) outside
+ * prmf_step, so cached derived state (packed V, V^T V) is rebuilt on the next step.
+ */
+int prmf_invalidate_factors(prmf_ctx* ctx);
+
+/*
+ * n_steps iterations of U-update, V-update and objective, single rank
+ * (nranks == 1).  dU (m x k) and dV (n x k): float32 row-major device buffers,
+ * updated in place.  gamma/delta are the already-scaled values the reference
+ * passes (prmf_runner.py:644-645).  tradeoff < 0: fixed gamma/delta (:374-451);
+ * tradeoff in [0,1]: after each step gamma = delta = (1-t)*recon/(t*manifold)
+ * (:542-548).  obj_out (host, n_steps x PRMF_OBJ_STRIDE doubles) receives one
+ * record per iteration; gamma_delta_out (host, 2 doubles, may be NULL) the
+ * values to use for the next call.  Synchronises `stream` before returning.
+ * Returns PRMF_ERR_NUMERIC if any record is not finite.
+ * Replaces: nmf_manifold_vec_update / _tradeoff (prmf_runner.py:374-451, 497-554).
+ */
+int prmf_step(prmf_ctx* ctx, float* dU, float* dV, int n_steps,
+              double gamma, double delta, double tradeoff,
+              double* obj_out, double* gamma_delta_out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Multi-rank form of one iteration: four device phases with a collective
+ * between them, driven by the host over torch.distributed (RCCL):
+ *
+ *   prmf_phase_u    P = X_g V ; U_g update ; partial U_g^T U_g      -> gram buffer
+ *        all_reduce(gram, SUM)                       k*k doubles
+ *   prmf_phase_q    Q_g = X_g^T U_g, laid out by owner column block -> q_send
+ *        reduce_scatter(q_send -> q_recv, SUM)       n*kc floats per rank
+ *   prmf_phase_v    graph terms + divide + clamps for the OWN columns,
+ *                   own-column objective pieces                     -> v_send
+ *        all_gather(v_send -> v_recv)                n*kc+8 floats per rank
+ *   prmf_phase_post rebuild replicated V, V^T V, objective record
+ *
+ * prmf_step is exactly this sequence with the collectives elided.
+ * ---------------------------------------------------------------------- */
+
+/* element counts of the caller-allocated communication buffers */
+typedef struct prmf_comm_sizes {
+  int64_t gram_doubles;     /* all_reduce buffer (float64)                    */
+  int64_t q_send_floats;    /* nranks * q_recv_floats                         */
+  int64_t q_recv_floats;    /* n * kc                                         */
+  int64_t v_send_floats;    /* n * kc + 8 (objective partials in the tail)    */
+  int64_t v_recv_floats;    /* nranks * v_send_floats                         */
+  int32_t kc;               /* latent columns owned per rank                  */
+  int32_t reserved;
+} prmf_comm_sizes;
+
+int prmf_get_comm_sizes(const prmf_ctx* ctx, prmf_comm_sizes* out);
+
+/* Device buffers for the collectives (float64 gram, float32 others).  With
+ * nranks == 1 this call is optional (ctx allocates them; q_recv aliases q_send
+ * and v_recv aliases v_send). */
+int prmf_set_comm_buffers(prmf_ctx* ctx, double* gram, float* q_send, float* q_recv,
+                          float* v_send, float* v_recv);
+
+/* Bind the factor buffers and hyper-parameters for a sequence of phase calls
+ * (same meaning as in prmf_step); resets the objective-record cursor. */
+int prmf_begin(prmf_ctx* ctx, float* dU, float* dV, double gamma, double delta,
+               double tradeoff, void* stream);
+int prmf_phase_u(prmf_ctx* ctx, void* stream);
+int prmf_phase_q(prmf_ctx* ctx, void* stream);
+int prmf_phase_v(prmf_ctx* ctx, void* stream);
+int prmf_phase_post(prmf_ctx* ctx, void* stream);
+/* Copy the records of the iterations run since prmf_begin to the host
+ * (synchronises `stream`). */
+int prmf_end(prmf_ctx* ctx, int n_steps, double* obj_out, double* gamma_delta_out, void* stream);
+
+/*
+ * Candidate scoring for `restrict` (prmf_runner.py:129-194 / :115-127):
+ * scores_out[kk*P + p] = ||vhat_kk[S_p]||_2 + 1 - vhat_kk^T Lhat_p vhat_kk for
+ * every latent column kk and every library pathway p (host buffer, k*P doubles).
+ * dV: n x k float32 device buffer.  Synchronises `stream`.
+ */
+int prmf_score_candidates(prmf_ctx* ctx, const float* dV, double* scores_out, void* stream);
+
+/* Introspection used by bench.py for the roofline block: launch geometry and
+ * per-launch algorithmic bytes of the dominant kernel (the X / X^T sweep). */
+typedef struct prmf_sweep_info {
+  int64_t bytes_x_sweep;    /* bytes of X streamed by the X*V sweep  (padded copy)  */
+  int64_t bytes_xt_sweep;   /* bytes of X^T streamed by the X^T*U sweep             */
+  int32_t splits_xv, splits_xtu;
+  int32_t grid_xv, grid_xtu;
+} prmf_sweep_info;
+int prmf_get_sweep_info(const prmf_ctx* ctx, prmf_sweep_info* out);
+
+/* Time (ms, HIP events on `stream`) of the last `prmf_step`'s two sweeps and of
+ * everything else, averaged per iteration; valid only if the ctx was created
+ * with PRMF_FLAG_TIMING. */
+#define PRMF_FLAG_TIMING 0x1u
+int prmf_get_timing(const prmf_ctx* ctx, double* ms_xv, double* ms_xtu, double* ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRMF_HIP_H */

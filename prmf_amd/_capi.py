@@ -1,0 +1,102 @@
+"""ctypes binding of libprmf_hip.so (include/prmf_hip.h).
+
+The product path has no CPU fallback: if the library is missing or does not
+load, `load()` raises -- callers must not catch that to substitute other
+arithmetic.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libprmf_hip.so")
+
+PRMF_ABI_VERSION = 1
+PRMF_X_F32, PRMF_X_BF16 = 0, 1
+PRMF_OBJ_STRIDE = 8
+PRMF_FLAG_TIMING = 0x1
+OBJ_KEYS = ("recon", "manifold", "ignore", "fro", "gamma", "delta", "obj")
+
+PRMF_OK = 0
+PRMF_ERR_ARG, PRMF_ERR_HIP, PRMF_ERR_STATE, PRMF_ERR_NUMERIC, PRMF_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+
+
+class CommSizes(C.Structure):
+    _fields_ = [("gram_doubles", C.c_int64), ("q_send_floats", C.c_int64), ("q_recv_floats", C.c_int64),
+                ("v_send_floats", C.c_int64), ("v_recv_floats", C.c_int64), ("kc", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class SweepInfo(C.Structure):
+    _fields_ = [("bytes_x_sweep", C.c_int64), ("bytes_xt_sweep", C.c_int64),
+                ("splits_xv", C.c_int32), ("splits_xtu", C.c_int32),
+                ("grid_xv", C.c_int32), ("grid_xtu", C.c_int32)]
+
+
+# every symbol include/prmf_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _i64, _d, _u = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_uint
+SIGNATURES = {
+    "prmf_abi_version": (_i, []),
+    "prmf_last_error": (C.c_char_p, [_vp]),
+    "prmf_create": (_i, [C.POINTER(_vp), _i, _i64, _i64, _i, _i, _i, _i, _u]),
+    "prmf_destroy": (_i, [_vp]),
+    "prmf_set_x": (_i, [_vp, _vp, _i64, _d, _vp]),
+    "prmf_set_pathway_library": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "prmf_set_active": (_i, [_vp, _vp, _vp]),
+    "prmf_invalidate_factors": (_i, [_vp]),
+    "prmf_step": (_i, [_vp, _vp, _vp, _i, _d, _d, _d, _vp, _vp, _vp]),
+    "prmf_get_comm_sizes": (_i, [_vp, C.POINTER(CommSizes)]),
+    "prmf_set_comm_buffers": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "prmf_begin": (_i, [_vp, _vp, _vp, _d, _d, _d, _vp]),
+    "prmf_phase_u": (_i, [_vp, _vp]),
+    "prmf_phase_q": (_i, [_vp, _vp]),
+    "prmf_phase_v": (_i, [_vp, _vp]),
+    "prmf_phase_post": (_i, [_vp, _vp]),
+    "prmf_end": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "prmf_score_candidates": (_i, [_vp, _vp, _vp, _vp]),
+    "prmf_get_sweep_info": (_i, [_vp, C.POINTER(SweepInfo)]),
+    "prmf_get_timing": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)]),
+}
+
+_lib = None
+
+
+class PrmfLibraryError(RuntimeError):
+    pass
+
+
+class PrmfError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "libprmf_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+def load(path=None):
+    """Load libprmf_hip.so and declare every entry point; raises if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise PrmfLibraryError(
+            "%s not found: build it with `python -m prmf_amd._build` (hipcc, gfx950). "
+            "There is no CPU fallback for the PRMF hot path." % p)
+    try:
+        lib = C.CDLL(p)
+    except OSError as e:
+        raise PrmfLibraryError("cannot load %s: %s" % (p, e))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.prmf_abi_version() != PRMF_ABI_VERSION:
+        raise PrmfLibraryError("ABI version mismatch: library %d, binding %d" %
+                               (lib.prmf_abi_version(), PRMF_ABI_VERSION))
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(lib, ctx, rc):
+    if rc != PRMF_OK:
+        msg = lib.prmf_last_error(ctx)
+        raise PrmfError(rc, msg.decode("utf-8", "replace") if msg else "")

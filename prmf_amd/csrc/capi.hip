@@ -1,0 +1,633 @@
+// C-ABI of libprmf_hip.so (include/prmf_hip.h): context, HBM workspace and the
+// sequencing of one PRMF iteration into four device phases.
+#include "../../include/prmf_hip.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace prmf;
+
+namespace {
+thread_local char g_create_error[512] = "";
+constexpr int MAX_RECORDS = 256;   // objective records kept on the device between begin/end
+}
+
+struct prmf_ctx {
+  int device = 0;
+  int64_t m = 0, n = 0;
+  int k = 0, KP = 0, NT = 0;
+  int x_dtype = 0;
+  int nranks = 1, rank = 0;
+  int kc = 0, col0 = 0, ncols = 0;
+  unsigned flags = 0;
+  char err[512] = "";
+
+  // X (m x n) and X^T (n x m), zero padded, resident
+  void* X = nullptr;
+  void* XT = nullptr;
+  int64_t ldx = 0, ldxt = 0;          // elements
+  int64_t Kpad_x = 0, Kpad_xt = 0;    // reduction lengths (n resp. m, padded to 64)
+  double norm_x_sq = 0.0;
+  bool have_x = false;
+
+  // packed factors + sweep slabs
+  void* Vp = nullptr;
+  void* Up = nullptr;
+  GemmPlan plan_xv{}, plan_xtu{};
+  float* slabs = nullptr;             // shared by both sweeps
+  int64_t slab_stride_p = 0, slab_stride_q = 0;
+
+  // Gram
+  double* gram_partial = nullptr;
+  double* Gv = nullptr;               // k*k
+  double* gram_buf = nullptr;         // all-reduce buffer (U^T U), caller's or own
+  bool own_comm = false;
+
+  // comm buffers
+  float *q_send = nullptr, *q_recv = nullptr, *v_send = nullptr, *v_recv = nullptr;
+  int64_t extras_off = 0, v_send_floats = 0;
+
+  // pathway library
+  PathwayLibDev lib{};
+  std::vector<void*> lib_allocs;
+  bool have_lib = false, have_active = false;
+  int32_t* active_dev = nullptr;
+  int32_t* active_host_pinned = nullptr;
+  int32_t* pos = nullptr;
+  float *gnum = nullptr, *gden = nullptr;
+  double* obj_scratch = nullptr;      // [kc][max_support]
+  double* colres = nullptr;           // [kc][2]
+  double* vpartial = nullptr;         // [v_update_blocks][kc+1]
+  int vblocks = 0;
+
+  // hyper-parameters + records
+  double* hyper = nullptr;            // device: gamma, delta, tradeoff
+  double* hyper_host = nullptr;       // pinned
+  double* records = nullptr;          // device [MAX_RECORDS][8]
+  double* records_host = nullptr;     // pinned
+  int cursor = 0;
+
+  // bound factors
+  float* U = nullptr;
+  float* V = nullptr;
+  bool prepared = false;
+
+  // timing
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  double ms_xv = 0, ms_xtu = 0, ms_total = 0;
+  int timed_iters = 0;
+
+  // scoring scratch
+  double* colnorm = nullptr;
+  double* scores_dev = nullptr;
+  int64_t scores_cap = 0;
+};
+
+namespace {
+
+int fail(prmf_ctx* c, int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(c ? c->err : g_create_error, 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                       \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) return fail(ctx, PRMF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+template <typename T>
+int dev_alloc(prmf_ctx* c, T** p, size_t count, bool zero = true) {
+  size_t bytes = (count ? count : 1) * sizeof(T);
+  hipError_t e = hipMalloc((void**)p, bytes);
+  if (e != hipSuccess) return fail(c, PRMF_ERR_HIP, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+  if (zero) {
+    e = hipMemset(*p, 0, bytes);
+    if (e != hipSuccess) return fail(c, PRMF_ERR_HIP, "hipMemset: %s", hipGetErrorString(e));
+  }
+  return PRMF_OK;
+}
+
+void dev_free(void* p) {
+  if (p) (void)hipFree(p);
+}
+
+int64_t packed_bytes(const prmf_ctx* c, int64_t Kpad) {
+  return Kpad / chunk_elems(c->x_dtype) * packed_chunk_bytes(c->x_dtype, c->NT);
+}
+
+int set_device(prmf_ctx* c) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  return PRMF_OK;
+}
+
+// pack V and build V^T V from the bound V (first step, or after the caller changed V)
+int prepare(prmf_ctx* c, hipStream_t s) {
+  FactorView fv{c->V, (int)c->n, c->k, c->k, 0};
+  HIP_TRY(c, launch_pack_factor(fv, c->x_dtype, c->NT, c->Kpad_x, c->Vp, s));
+  HIP_TRY(c, launch_gram(fv, c->gram_partial, c->Gv, s));
+  c->prepared = true;
+  return PRMF_OK;
+}
+
+int check_ready(prmf_ctx* c) {
+  if (!c) return PRMF_ERR_ARG;
+  if (!c->have_x) return fail(c, PRMF_ERR_STATE, "prmf_set_x has not been called");
+  if (!c->have_lib) return fail(c, PRMF_ERR_STATE, "prmf_set_pathway_library has not been called");
+  if (!c->have_active) return fail(c, PRMF_ERR_STATE, "prmf_set_active has not been called");
+  if (!c->U || !c->V) return fail(c, PRMF_ERR_STATE, "factors are not bound (prmf_begin / prmf_step)");
+  if (!c->gram_buf || !c->q_send || !c->q_recv || !c->v_send || !c->v_recv)
+    return fail(c, PRMF_ERR_STATE, "communication buffers are not set (prmf_set_comm_buffers)");
+  return PRMF_OK;
+}
+
+int ensure_own_comm(prmf_ctx* c) {
+  if (c->gram_buf) return PRMF_OK;
+  if (c->nranks != 1) return fail(c, PRMF_ERR_STATE, "nranks > 1 needs caller-allocated communication buffers");
+  int rc;
+  if ((rc = dev_alloc(c, &c->gram_buf, (size_t)c->k * c->k))) return rc;
+  if ((rc = dev_alloc(c, &c->q_send, (size_t)c->n * c->kc))) return rc;
+  if ((rc = dev_alloc(c, &c->v_send, (size_t)c->v_send_floats))) return rc;
+  c->q_recv = c->q_send;
+  c->v_recv = c->v_send;
+  c->own_comm = true;
+  return PRMF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int prmf_abi_version(void) { return PRMF_ABI_VERSION; }
+
+const char* prmf_last_error(const prmf_ctx* ctx) { return ctx ? ctx->err : g_create_error; }
+
+int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, int x_dtype, int nranks, int rank,
+                unsigned flags) {
+  if (!out) return fail(nullptr, PRMF_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (m_local < 0 || n <= 0 || k <= 0) return fail(nullptr, PRMF_ERR_ARG, "bad shape m=%lld n=%lld k=%d", (long long)m_local, (long long)n, k);
+  if (k > MAX_KP) return fail(nullptr, PRMF_ERR_UNSUPPORTED, "k=%d > %d latent columns", k, MAX_KP);
+  if (x_dtype != PRMF_X_F32 && x_dtype != PRMF_X_BF16) return fail(nullptr, PRMF_ERR_ARG, "bad x_dtype %d", x_dtype);
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(nullptr, PRMF_ERR_ARG, "bad rank %d of %d", rank, nranks);
+  if (m_local * (int64_t)k > 0x7fffffff00LL || n * (int64_t)k > 0x7fffffff00LL) return fail(nullptr, PRMF_ERR_UNSUPPORTED, "factor too large");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || device < 0 || device >= ndev)
+    return fail(nullptr, PRMF_ERR_HIP, "no HIP device %d (count %d): %s", device, ndev, hipGetErrorString(e));
+  prmf_ctx* c = new (std::nothrow) prmf_ctx();
+  if (!c) return fail(nullptr, PRMF_ERR_HIP, "out of host memory");
+  c->device = device;
+  c->m = m_local;
+  c->n = n;
+  c->k = k;
+  c->KP = (int)round_up(k, 32);
+  c->NT = c->KP / 32;
+  c->x_dtype = x_dtype;
+  c->nranks = nranks;
+  c->rank = rank;
+  c->flags = flags;
+  c->kc = (k + nranks - 1) / nranks;
+  c->col0 = rank * c->kc;
+  c->ncols = c->col0 >= k ? 0 : (c->col0 + c->kc <= k ? c->kc : k - c->col0);
+  c->extras_off = round_up(n * c->kc, 2);
+  c->v_send_floats = c->extras_off + 8;
+  int rc = PRMF_OK;
+  auto bail = [&](int code) {
+    std::snprintf(g_create_error, sizeof g_create_error, "%s", c->err);
+    prmf_destroy(c);
+    return code;
+  };
+  if ((rc = set_device(c))) return bail(rc);
+
+  c->Kpad_x = round_up(n, K_PAD);
+  c->Kpad_xt = round_up(m_local > 0 ? m_local : 1, K_PAD);
+  c->plan_xv = plan_gemm(x_dtype, m_local > 0 ? m_local : 1, c->Kpad_x, c->NT, 0);
+  c->plan_xtu = plan_gemm(x_dtype, n, c->Kpad_xt, c->NT, 0);
+  c->slab_stride_p = (m_local > 0 ? m_local : 1) * (int64_t)c->KP;
+  c->slab_stride_q = n * (int64_t)c->KP;
+  int64_t slab_floats = c->slab_stride_p * c->plan_xv.splits;
+  if (c->slab_stride_q * c->plan_xtu.splits > slab_floats) slab_floats = c->slab_stride_q * c->plan_xtu.splits;
+
+  if ((rc = dev_alloc(c, (char**)&c->Vp, (size_t)packed_bytes(c, c->Kpad_x)))) return bail(rc);
+  if ((rc = dev_alloc(c, (char**)&c->Up, (size_t)packed_bytes(c, c->Kpad_xt)))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->slabs, (size_t)slab_floats, false))) return bail(rc);
+  int gb = gram_blocks(m_local > n ? m_local : n);
+  if ((rc = dev_alloc(c, (float**)&c->gram_partial, (size_t)gb * k * k))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->Gv, (size_t)k * k))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->active_dev, (size_t)k))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->pos, (size_t)n * c->kc, false))) return bail(rc);
+  c->vblocks = v_update_blocks(n);
+  if ((rc = dev_alloc(c, &c->vpartial, (size_t)c->vblocks * (c->kc + 1)))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->colres, (size_t)c->kc * 2))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->hyper, 4))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->records, (size_t)MAX_RECORDS * PRMF_OBJ_STRIDE))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->colnorm, (size_t)k))) return bail(rc);
+  if (hipHostMalloc((void**)&c->hyper_host, 4 * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&c->records_host, (size_t)MAX_RECORDS * PRMF_OBJ_STRIDE * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&c->active_host_pinned, (size_t)k * sizeof(int32_t)) != hipSuccess) {
+    fail(c, PRMF_ERR_HIP, "hipHostMalloc failed");
+    return bail(PRMF_ERR_HIP);
+  }
+  if (flags & PRMF_FLAG_TIMING)
+    for (auto& ev : c->ev)
+      if (hipEventCreate(&ev) != hipSuccess) {
+        fail(c, PRMF_ERR_HIP, "hipEventCreate failed");
+        return bail(PRMF_ERR_HIP);
+      }
+  *out = c;
+  return PRMF_OK;
+}
+
+int prmf_destroy(prmf_ctx* c) {
+  if (!c) return PRMF_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  dev_free(c->X);
+  dev_free(c->XT);
+  dev_free(c->Vp);
+  dev_free(c->Up);
+  dev_free(c->slabs);
+  dev_free(c->gram_partial);
+  dev_free(c->Gv);
+  if (c->own_comm) {
+    dev_free(c->gram_buf);
+    dev_free(c->q_send);
+    dev_free(c->v_send);
+  }
+  for (void* p : c->lib_allocs) dev_free(p);
+  dev_free(c->active_dev);
+  dev_free(c->pos);
+  dev_free(c->gnum);
+  dev_free(c->gden);
+  dev_free(c->obj_scratch);
+  dev_free(c->colres);
+  dev_free(c->vpartial);
+  dev_free(c->hyper);
+  dev_free(c->records);
+  dev_free(c->colnorm);
+  dev_free(c->scores_dev);
+  if (c->hyper_host) (void)hipHostFree(c->hyper_host);
+  if (c->records_host) (void)hipHostFree(c->records_host);
+  if (c->active_host_pinned) (void)hipHostFree(c->active_host_pinned);
+  for (auto& ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  delete c;
+  return PRMF_OK;
+}
+
+int prmf_set_x(prmf_ctx* c, const void* dX, int64_t ld, double norm_x_sq, void* stream) {
+  if (!c) return PRMF_ERR_ARG;
+  if (c->m > 0 && !dX) return fail(c, PRMF_ERR_ARG, "dX is NULL");
+  if (ld < c->n) return fail(c, PRMF_ERR_ARG, "ld=%lld < n=%lld", (long long)ld, (long long)c->n);
+  if (!(norm_x_sq >= 0.0) || !std::isfinite(norm_x_sq)) return fail(c, PRMF_ERR_ARG, "norm_x_sq must be finite and >= 0");
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int eb = elem_bytes(c->x_dtype);
+  const int64_t rows_x = round_up(c->m > 0 ? c->m : 1, M_PAD), rows_xt = round_up(c->n, M_PAD);
+  c->ldx = c->Kpad_x;
+  c->ldxt = c->Kpad_xt;
+  if (!c->X) {
+    if ((rc = dev_alloc(c, (char**)&c->X, (size_t)(rows_x * c->ldx * eb)))) return rc;
+    if ((rc = dev_alloc(c, (char**)&c->XT, (size_t)(rows_xt * c->ldxt * eb)))) return rc;
+  }
+  HIP_TRY(c, launch_copy_pad(c->x_dtype, dX, ld, c->m, c->n, c->X, c->ldx, s));
+  HIP_TRY(c, launch_transpose_pad(c->x_dtype, dX, ld, c->m, c->n, c->XT, c->ldxt, s));
+  c->norm_x_sq = norm_x_sq;
+  c->have_x = true;
+  return PRMF_OK;
+}
+
+int prmf_set_pathway_library(prmf_ctx* c, int P, const int64_t* sup_ptr, const int32_t* sup_idx, const double* sup_deg,
+                             const double* sup_ldiag, const int64_t* row_ptr, const int32_t* col_local,
+                             const double* w, void* stream) {
+  if (!c) return PRMF_ERR_ARG;
+  if (P <= 0 || !sup_ptr || !sup_idx || !sup_deg || !sup_ldiag || !row_ptr) return fail(c, PRMF_ERR_ARG, "NULL library array or P <= 0");
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t ts = sup_ptr[P], nnz = row_ptr[ts];
+  if (sup_ptr[0] != 0 || row_ptr[0] != 0 || ts < 0 || nnz < 0) return fail(c, PRMF_ERR_ARG, "malformed pointer arrays");
+  if (nnz > 0 && (!col_local || !w)) return fail(c, PRMF_ERR_ARG, "NULL adjacency arrays");
+  int max_sup = 1;
+  for (int p = 0; p < P; ++p) {
+    int64_t ns = sup_ptr[p + 1] - sup_ptr[p];
+    if (ns < 0) return fail(c, PRMF_ERR_ARG, "sup_ptr not monotone at pathway %d", p);
+    if (ns > max_sup) max_sup = (int)ns;
+    for (int64_t i = sup_ptr[p]; i < sup_ptr[p + 1]; ++i) {
+      if (sup_idx[i] < 0 || sup_idx[i] >= c->n) return fail(c, PRMF_ERR_ARG, "support index %d out of range in pathway %d", sup_idx[i], p);
+      if (row_ptr[i + 1] < row_ptr[i]) return fail(c, PRMF_ERR_ARG, "row_ptr not monotone");
+      for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e)
+        if (col_local[e] < 0 || col_local[e] >= ns) return fail(c, PRMF_ERR_ARG, "col_local out of range in pathway %d", p);
+    }
+  }
+  // (re)allocate
+  HIP_TRY(c, hipStreamSynchronize(s));
+  for (void* p : c->lib_allocs) dev_free(p);
+  c->lib_allocs.clear();
+  dev_free(c->gnum); c->gnum = nullptr;
+  dev_free(c->gden); c->gden = nullptr;
+  dev_free(c->obj_scratch); c->obj_scratch = nullptr;
+  c->have_lib = false;
+  c->have_active = false;
+
+  std::vector<double> dis((size_t)(ts ? ts : 1));
+  for (int64_t i = 0; i < ts; ++i) dis[i] = sup_ldiag[i] != 0.0 ? std::pow(sup_ldiag[i], -0.5) : 0.0;
+
+  auto up = [&](const void* host, size_t bytes, void** dev) -> int {
+    char* d = nullptr;
+    int r = dev_alloc(c, &d, bytes ? bytes : 1, false);
+    if (r) return r;
+    c->lib_allocs.push_back(d);
+    if (bytes) {
+      hipError_t e = hipMemcpy(d, host, bytes, hipMemcpyHostToDevice);
+      if (e != hipSuccess) return fail(c, PRMF_ERR_HIP, "hipMemcpy(library): %s", hipGetErrorString(e));
+    }
+    *dev = d;
+    return PRMF_OK;
+  };
+  PathwayLibDev L{};
+  L.P = P;
+  L.max_support = max_sup;
+  L.total_support = ts;
+  L.total_nnz = nnz;
+  if ((rc = up(sup_ptr, (size_t)(P + 1) * 8, (void**)&L.sup_ptr))) return rc;
+  if ((rc = up(sup_idx, (size_t)ts * 4, (void**)&L.sup_idx))) return rc;
+  if ((rc = up(sup_deg, (size_t)ts * 8, (void**)&L.sup_deg))) return rc;
+  if ((rc = up(dis.data(), (size_t)ts * 8, (void**)&L.sup_dis))) return rc;
+  if ((rc = up(row_ptr, (size_t)(ts + 1) * 8, (void**)&L.row_ptr))) return rc;
+  if ((rc = up(col_local, (size_t)nnz * 4, (void**)&L.col_local))) return rc;
+  if ((rc = up(w, (size_t)nnz * 8, (void**)&L.w))) return rc;
+  c->lib = L;
+  if ((rc = dev_alloc(c, &c->gnum, (size_t)c->kc * max_sup))) return rc;
+  if ((rc = dev_alloc(c, &c->gden, (size_t)c->kc * max_sup))) return rc;
+  if ((rc = dev_alloc(c, &c->obj_scratch, (size_t)c->kc * max_sup))) return rc;
+  c->have_lib = true;
+  return PRMF_OK;
+}
+
+int prmf_set_active(prmf_ctx* c, const int32_t* k_to_lapl, void* stream) {
+  if (!c || !k_to_lapl) return PRMF_ERR_ARG;
+  if (!c->have_lib) return fail(c, PRMF_ERR_STATE, "prmf_set_pathway_library has not been called");
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < c->k; ++i)
+    if (k_to_lapl[i] < 0 || k_to_lapl[i] >= c->lib.P) return fail(c, PRMF_ERR_ARG, "latent %d: pathway %d out of range", i, k_to_lapl[i]);
+  HIP_TRY(c, hipStreamSynchronize(s));   // the pinned staging buffer may still be in use
+  std::memcpy(c->active_host_pinned, k_to_lapl, (size_t)c->k * sizeof(int32_t));
+  HIP_TRY(c, hipMemcpyAsync(c->active_dev, c->active_host_pinned, (size_t)c->k * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIP_TRY(c, launch_build_pos(c->lib, c->active_dev, c->col0, c->ncols, c->kc, c->n, c->pos, s));
+  c->have_active = true;
+  return PRMF_OK;
+}
+
+int prmf_invalidate_factors(prmf_ctx* c) {
+  if (!c) return PRMF_ERR_ARG;
+  c->prepared = false;
+  return PRMF_OK;
+}
+
+int prmf_get_comm_sizes(const prmf_ctx* c, prmf_comm_sizes* out) {
+  if (!c || !out) return PRMF_ERR_ARG;
+  out->gram_doubles = (int64_t)c->k * c->k;
+  out->q_recv_floats = c->n * c->kc;
+  out->q_send_floats = out->q_recv_floats * c->nranks;
+  out->v_send_floats = c->v_send_floats;
+  out->v_recv_floats = c->v_send_floats * c->nranks;
+  out->kc = c->kc;
+  out->reserved = 0;
+  return PRMF_OK;
+}
+
+int prmf_set_comm_buffers(prmf_ctx* c, double* gram, float* q_send, float* q_recv, float* v_send, float* v_recv) {
+  if (!c) return PRMF_ERR_ARG;
+  if (!gram || !q_send || !q_recv || !v_send || !v_recv) return fail(c, PRMF_ERR_ARG, "NULL communication buffer");
+  if (c->own_comm) {
+    dev_free(c->gram_buf);
+    dev_free(c->q_send);
+    dev_free(c->v_send);
+    c->own_comm = false;
+  }
+  c->gram_buf = gram;
+  c->q_send = q_send;
+  c->q_recv = q_recv;
+  c->v_send = v_send;
+  c->v_recv = v_recv;
+  return PRMF_OK;
+}
+
+int prmf_begin(prmf_ctx* c, float* dU, float* dV, double gamma, double delta, double tradeoff, void* stream) {
+  if (!c) return PRMF_ERR_ARG;
+  if ((c->m > 0 && !dU) || !dV) return fail(c, PRMF_ERR_ARG, "NULL factor pointer");
+  if (tradeoff > 1.0) return fail(c, PRMF_ERR_ARG, "tradeoff must be < 0 (off) or in [0,1]");
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  if ((rc = ensure_own_comm(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (c->U != dU || c->V != dV) c->prepared = false;
+  c->U = dU;
+  c->V = dV;
+  if ((rc = check_ready(c))) return rc;
+  HIP_TRY(c, hipStreamSynchronize(s));   // pinned staging reuse
+  c->hyper_host[0] = gamma;
+  c->hyper_host[1] = delta;
+  c->hyper_host[2] = tradeoff;
+  c->hyper_host[3] = 0.0;
+  HIP_TRY(c, hipMemcpyAsync(c->hyper, c->hyper_host, 4 * sizeof(double), hipMemcpyHostToDevice, s));
+  c->cursor = 0;
+  if (!c->prepared && (rc = prepare(c, s))) return rc;
+  return PRMF_OK;
+}
+
+int prmf_phase_u(prmf_ctx* c, void* stream) {
+  int rc;
+  if ((rc = check_ready(c))) return rc;
+  if (!c->prepared) return fail(c, PRMF_ERR_STATE, "prmf_begin has not been called");
+  if ((rc = set_device(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (c->m > 0) {
+    const bool timing = (c->flags & PRMF_FLAG_TIMING) != 0;
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    // P = X V                                             (prmf_runner.py:420)
+    HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xv, c->X, c->ldx, c->m, c->Vp, c->NT, c->slabs, c->slab_stride_p, s));
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    // U <- U * P / (U Gv + U)                              (:421-422)
+    HIP_TRY(c, launch_u_update(c->U, c->m, c->k, c->slabs, c->plan_xv.splits, c->slab_stride_p, c->KP, c->Gv, s));
+    FactorView fu{c->U, (int)c->m, c->k, c->k, 0};
+    HIP_TRY(c, launch_pack_factor(fu, c->x_dtype, c->NT, c->Kpad_xt, c->Up, s));
+    HIP_TRY(c, launch_gram(fu, c->gram_partial, c->gram_buf, s));
+  } else {
+    HIP_TRY(c, hipMemsetAsync(c->gram_buf, 0, (size_t)c->k * c->k * sizeof(double), s));
+  }
+  return PRMF_OK;
+}
+
+int prmf_phase_q(prmf_ctx* c, void* stream) {
+  int rc;
+  if ((rc = check_ready(c))) return rc;
+  if ((rc = set_device(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const bool timing = (c->flags & PRMF_FLAG_TIMING) != 0;
+  if (c->m > 0) {
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    // Q = X^T U_new                                       (:424)
+    HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xtu, c->XT, c->ldxt, c->n, c->Up, c->NT, c->slabs, c->slab_stride_q, s));
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[3], s));
+    HIP_TRY(c, launch_slab_sum_blocks(c->slabs, c->plan_xtu.splits, c->slab_stride_q, c->KP, c->n, c->k, c->kc,
+                                      c->nranks, c->q_send, s));
+  } else {
+    HIP_TRY(c, hipMemsetAsync(c->q_send, 0, (size_t)c->n * c->kc * c->nranks * sizeof(float), s));
+  }
+  return PRMF_OK;
+}
+
+int prmf_phase_v(prmf_ctx* c, void* stream) {
+  int rc;
+  if ((rc = check_ready(c))) return rc;
+  if ((rc = set_device(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  // sparse pathway terms on the OLD V                    (:431-438)
+  HIP_TRY(c, launch_graph_terms(c->lib, c->active_dev, c->col0, c->ncols, c->V, c->k, c->hyper, c->gnum, c->gden, s));
+  // V_own <- V * (Q + gnum) / max(V Gu + gden, eps)      (:425, :440-444)
+  HIP_TRY(c, launch_v_update(c->V, c->n, c->k, c->col0, c->ncols, c->kc, c->q_recv, c->gram_buf, c->pos, c->gnum, c->gden,
+                             c->lib.max_support, c->v_send, c->vpartial, s));
+  double* extras = reinterpret_cast<double*>(c->v_send + c->extras_off);
+  HIP_TRY(c, launch_objective_terms(c->lib, c->active_dev, c->col0, c->ncols, c->kc, c->n, c->v_send, c->vpartial,
+                                    c->vblocks, c->colres, c->obj_scratch, extras, s));
+  return PRMF_OK;
+}
+
+int prmf_phase_post(prmf_ctx* c, void* stream) {
+  int rc;
+  if ((rc = check_ready(c))) return rc;
+  if ((rc = set_device(c))) return rc;
+  if (c->cursor >= MAX_RECORDS) return fail(c, PRMF_ERR_STATE, "more than %d iterations between prmf_begin and prmf_end", MAX_RECORDS);
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(c, launch_assemble_v(c->v_recv, c->nranks, c->v_send_floats, c->kc, c->n, c->k, c->V, s));
+  FactorView fv{c->V, (int)c->n, c->k, c->k, 0};
+  HIP_TRY(c, launch_pack_factor(fv, c->x_dtype, c->NT, c->Kpad_x, c->Vp, s));
+  HIP_TRY(c, launch_gram(fv, c->gram_partial, c->Gv, s));
+  HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->nranks, c->v_send_floats, c->extras_off,
+                             c->norm_x_sq, c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, s));
+  c->cursor++;
+  return PRMF_OK;
+}
+
+int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out, void* stream) {
+  if (!c) return PRMF_ERR_ARG;
+  if (n_steps < 0 || n_steps > c->cursor) return fail(c, PRMF_ERR_ARG, "n_steps=%d but %d iterations were run", n_steps, c->cursor);
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (n_steps > 0)
+    HIP_TRY(c, hipMemcpyAsync(c->records_host, c->records + (size_t)(c->cursor - n_steps) * PRMF_OBJ_STRIDE,
+                              (size_t)n_steps * PRMF_OBJ_STRIDE * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(c->hyper_host, c->hyper, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (obj_out && n_steps > 0) std::memcpy(obj_out, c->records_host, (size_t)n_steps * PRMF_OBJ_STRIDE * sizeof(double));
+  if (gamma_delta_out) {
+    gamma_delta_out[0] = c->hyper_host[0];
+    gamma_delta_out[1] = c->hyper_host[1];
+  }
+  for (int i = 0; i < n_steps; ++i)
+    for (int j = 0; j < 7; ++j)
+      if (!std::isfinite(c->records_host[i * PRMF_OBJ_STRIDE + j]))
+        return fail(c, PRMF_ERR_NUMERIC, "non-finite objective component %d at iteration %d of this call", j, i);
+  return PRMF_OK;
+}
+
+int prmf_step(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma, double delta, double tradeoff,
+              double* obj_out, double* gamma_delta_out, void* stream) {
+  if (!c) return PRMF_ERR_ARG;
+  if (c->nranks != 1) return fail(c, PRMF_ERR_STATE, "prmf_step is the single-rank form; use the phase calls with nranks > 1");
+  if (n_steps < 0) return fail(c, PRMF_ERR_ARG, "n_steps < 0");
+  const bool timing = (c->flags & PRMF_FLAG_TIMING) != 0;
+  if (timing) { c->ms_xv = c->ms_xtu = c->ms_total = 0; c->timed_iters = 0; }
+  int done = 0;
+  int rc;
+  while (done < n_steps || (n_steps == 0 && done == 0)) {
+    int batch = n_steps - done < MAX_RECORDS ? n_steps - done : MAX_RECORDS;
+    if ((rc = prmf_begin(c, dU, dV, gamma, delta, tradeoff, stream))) return rc;
+    for (int i = 0; i < batch; ++i) {
+      if ((rc = prmf_phase_u(c, stream))) return rc;
+      if ((rc = prmf_phase_q(c, stream))) return rc;
+      if ((rc = prmf_phase_v(c, stream))) return rc;
+      if ((rc = prmf_phase_post(c, stream))) return rc;
+      if (timing && i == batch - 1) {
+        // events of the last iteration of the batch
+        hipStream_t s = (hipStream_t)stream;
+        HIP_TRY(c, hipStreamSynchronize(s));
+        float a = 0, b = 0;
+        HIP_TRY(c, hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+        HIP_TRY(c, hipEventElapsedTime(&b, c->ev[2], c->ev[3]));
+        c->ms_xv += a;
+        c->ms_xtu += b;
+        c->timed_iters++;
+      }
+    }
+    double gd[2] = {gamma, delta};
+    if ((rc = prmf_end(c, batch, obj_out ? obj_out + (size_t)done * PRMF_OBJ_STRIDE : nullptr, gd, stream))) return rc;
+    gamma = gd[0];
+    delta = gd[1];
+    done += batch;
+    if (n_steps == 0) break;
+  }
+  if (gamma_delta_out) {
+    gamma_delta_out[0] = gamma;
+    gamma_delta_out[1] = delta;
+  }
+  return PRMF_OK;
+}
+
+int prmf_score_candidates(prmf_ctx* c, const float* dV, double* scores_out, void* stream) {
+  if (!c || !dV || !scores_out) return PRMF_ERR_ARG;
+  if (!c->have_lib) return fail(c, PRMF_ERR_STATE, "prmf_set_pathway_library has not been called");
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t need = (int64_t)c->k * c->lib.P;
+  if (need > c->scores_cap) {
+    HIP_TRY(c, hipStreamSynchronize(s));
+    dev_free(c->scores_dev);
+    c->scores_dev = nullptr;
+    if ((rc = dev_alloc(c, &c->scores_dev, (size_t)need))) return rc;
+    c->scores_cap = need;
+  }
+  HIP_TRY(c, launch_score_candidates(c->lib, dV, c->n, c->k, c->colnorm, c->scores_dev, s));
+  HIP_TRY(c, hipMemcpyAsync(scores_out, c->scores_dev, (size_t)need * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  return PRMF_OK;
+}
+
+int prmf_get_sweep_info(const prmf_ctx* c, prmf_sweep_info* out) {
+  if (!c || !out) return PRMF_ERR_ARG;
+  const int eb = elem_bytes(c->x_dtype);
+  out->bytes_x_sweep = round_up(c->m > 0 ? c->m : 1, 128) * c->Kpad_x * eb;
+  out->bytes_xt_sweep = round_up(c->n, 128) * c->Kpad_xt * eb;
+  out->splits_xv = c->plan_xv.splits;
+  out->splits_xtu = c->plan_xtu.splits;
+  out->grid_xv = c->plan_xv.panels * c->plan_xv.splits;
+  out->grid_xtu = c->plan_xtu.panels * c->plan_xtu.splits;
+  return PRMF_OK;
+}
+
+int prmf_get_timing(const prmf_ctx* c, double* ms_xv, double* ms_xtu, double* ms_total) {
+  if (!c) return PRMF_ERR_ARG;
+  if (!(c->flags & PRMF_FLAG_TIMING) || c->timed_iters == 0) return PRMF_ERR_STATE;
+  if (ms_xv) *ms_xv = c->ms_xv / c->timed_iters;
+  if (ms_xtu) *ms_xtu = c->ms_xtu / c->timed_iters;
+  if (ms_total) *ms_total = c->ms_total;
+  return PRMF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// Internal interface between the translation units of libprmf_hip.so.
+// gfx950 (MI355X / CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace prmf {
+
+// ---------------------------------------------------------------------------
+// Geometry shared by host and device code
+// ---------------------------------------------------------------------------
+// Both sweeps (P = X V and Q = X^T U) are the same kernel: C[M x KP] = A[M x K] * B[K x KP]
+// with A a zero-padded row-major matrix resident in HBM (X, resp. the X^T copy)
+// and B a factor (V resp. U) pre-packed into MFMA B-fragment order.
+constexpr int ROW_BYTES_PER_CHUNK = 128;   // one reduction chunk = 128 B of every A row
+constexpr int K_PAD = 64;                  // reduction length padded to 64 elements (both dtypes)
+constexpr int M_PAD = 256;                 // rows padded to the largest workgroup panel
+constexpr int MAX_KP = 128;                // latent columns padded to 32*NT, NT <= 4
+
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+static inline int chunk_elems(int x_dtype) { return x_dtype == 1 ? 64 : 32; }   // bf16 : f32
+static inline int elem_bytes(int x_dtype) { return x_dtype == 1 ? 2 : 4; }
+// bytes of packed B per chunk: chunk_elems x KP values, bf16 hi+lo (4 B) or f32 (4 B)
+static inline int64_t packed_chunk_bytes(int x_dtype, int NT) { return (int64_t)chunk_elems(x_dtype) * 32 * NT * 4; }
+
+// Factor value accessor: F(row, col) = src[(col / kc) * blk_stride + row * kc + col % kc].
+// Row-major n x k is kc = k (blk_stride unused); the all-gather receive buffer
+// is kc = columns per rank, blk_stride = floats per rank block.
+struct FactorView {
+  const float* src;
+  int rows;
+  int cols;          // valid columns (k)
+  int kc;
+  int64_t blk_stride;
+};
+
+// ---------------------------------------------------------------------------
+// gemm.hip
+// ---------------------------------------------------------------------------
+hipError_t launch_pack_factor(const FactorView& f, int x_dtype, int NT, int64_t Kpad, void* packed, hipStream_t s);
+struct GemmPlan {
+  int MT;            // 32-row MFMA tiles per wave
+  int panels;        // workgroups along M
+  int splits;        // workgroups along the reduction
+  int chunks_per_split;
+  int nchunks;
+};
+GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int force_splits);
+hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
+                       const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s);
+hipError_t launch_copy_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols,
+                           void* dst, int64_t ld_dst, hipStream_t s);
+hipError_t launch_transpose_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols,
+                                void* dst, int64_t ld_dst, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// update.hip
+// ---------------------------------------------------------------------------
+struct PathwayLibDev {
+  int P;
+  int max_support;
+  int64_t total_support, total_nnz;
+  const int64_t* sup_ptr;   // [P+1]
+  const int32_t* sup_idx;   // [total_support] gene index
+  const double* sup_deg;    // D_ii
+  const double* sup_dis;    // L_ii^-1/2 or 0     (normalize_laplacian, prmf_runner.py:56-65)
+  const int64_t* row_ptr;   // [total_support+1]
+  const int32_t* col_local; // [nnz] support-local column
+  const double* w;          // [nnz]
+};
+
+// U <- U * (P / (U Gv + U)), P = sum of `splits` slabs     (prmf_runner.py:420-422)
+hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, int splits, int64_t slab_stride,
+                           int KP, const double* Gv, hipStream_t s);
+// partial Gram: blocks of rows -> partial[nblk][k*k]; reduce -> G (double)
+int gram_blocks(int64_t rows);
+hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStream_t s);
+// Q slabs -> q_send[nranks][n][kc]
+hipError_t launch_slab_sum_blocks(const float* slabs, int splits, int64_t slab_stride, int KP, int64_t n, int k,
+                                  int kc, int nranks, float* q_send, hipStream_t s);
+// pos[n][kc] = index in the active pathway's support of gene j for own column c, or -1
+hipError_t launch_build_pos(const PathwayLibDev& lib, const int32_t* active_dev, int col0, int ncols, int kc,
+                            int64_t n, int32_t* pos, hipStream_t s);
+// gnum/gden[ncols][max_support]: gamma*W v + delta*(v+1)^-2, gamma*deg*v on the support  (:431-438)
+hipError_t launch_graph_terms(const PathwayLibDev& lib, const int32_t* active_dev, int col0, int ncols,
+                              const float* V, int k, const double* hyper, float* gnum, float* gden, hipStream_t s);
+int v_update_blocks(int64_t n);
+// V_own <- V * (Q + gnum) / max(V Gu + gden, eps), clamp; partial column sums of squares and <Q,V_new>
+hipError_t launch_v_update(const float* V, int64_t n, int k, int col0, int ncols, int kc, const float* q_recv,
+                           const double* Gu, const int32_t* pos, const float* gnum, const float* gden,
+                           int max_support, float* v_send, double* partial /*[blocks][kc+1]*/, hipStream_t s);
+// per own column: manifold / ignore of the normalised column (:344-352); then rank extras into v_send tail
+hipError_t launch_objective_terms(const PathwayLibDev& lib, const int32_t* active_dev, int col0, int ncols, int kc,
+                                  int64_t n, const float* v_send, const double* partial, int nblocks,
+                                  double* colres /*[kc][2]*/, double* scratch /*[kc][max_support]*/,
+                                  double* extras_out /*3 doubles in v_send tail*/, hipStream_t s);
+// V[n][k] row-major from the gathered blocks
+hipError_t launch_assemble_v(const float* v_recv, int nranks, int64_t blk_stride, int kc, int64_t n, int k,
+                             float* V, hipStream_t s);
+// objective record + tradeoff feedback
+hipError_t launch_finalize(const double* Gu, const double* Gv, int k, const float* v_recv, int nranks,
+                           int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* hyper /*gamma,delta,tradeoff*/,
+                           double* record /*8 doubles*/, hipStream_t s);
+// candidate scores k x P
+hipError_t launch_score_candidates(const PathwayLibDev& lib, const float* V, int64_t n, int k,
+                                   double* colnorm_scratch, double* scores, hipStream_t s);
+
+}  // namespace prmf

@@ -1,0 +1,578 @@
+// Everything of the PRMF iteration that is not the two big sweeps: the
+// multiplicative updates with their small k x k products, the Gram matrices, the
+// sparse pathway terms (CSR SpMM over the active supports, staged through LDS)
+// and the objective.  All of it is O((m+n) k^2) work on O((m+n) k) bytes -- a few
+// percent of the sweep traffic -- so these kernels favour exact reference
+// semantics and run-to-run determinism (fixed-order reductions, no atomics).
+//
+// Reference lines (script/prmf_runner.py):
+//   U update :420-422   V update :424-444   objective :336-372
+//   normalize_laplacian :56-65   restrict scoring :115-127
+#include "kernels.h"
+
+namespace prmf {
+
+// float32 machine epsilon used as the clamp value (prmf_runner.py:23)
+#define PRMF_EPS 1.1920928955078125e-07f
+
+// deterministic block-wide sum of one double per thread (256 threads)
+__device__ __forceinline__ double block_sum_256(double v, double* red /* [256] shared */) {
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+#pragma unroll
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// U <- U * (X V) / (U (V^T V) + U), 0/0 := 1          (prmf_runner.py:420-422)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+u_update_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs, int splits,
+                int64_t slab_stride, int KP, const double* __restrict__ Gv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k4 = (k + 3) & ~3;
+  const int ncg = k4 >> 2;
+  const int RT = 256 / ncg;
+  float* Gs = smem;              // [k][k4]
+  float* Us = smem + k * k4;     // [RT][k4]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < k * k4; i += 256) {
+    int q = i / k4, c = i - q * k4;
+    Gs[i] = c < k ? (float)Gv[q * k + c] : 0.f;
+  }
+  const int cg = tid % ncg, rt = tid / ncg;
+  const int64_t ntiles = (m + RT - 1) / RT;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    for (int i = tid; i < RT * k4; i += 256) {
+      int rr = i / k4, q = i - rr * k4;
+      int64_t row = tile * RT + rr;
+      Us[i] = (row < m && q < k) ? U[row * k + q] : 0.f;
+    }
+    __syncthreads();
+    const int64_t row = tile * RT + rt;
+    if (rt < RT && row < m) {
+      float den[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* urow = Us + rt * k4;
+      for (int q = 0; q < k; ++q) {
+        const float u = urow[q];
+        const float4 g = *reinterpret_cast<const float4*>(Gs + q * k4 + 4 * cg);
+        den[0] = fmaf(u, g.x, den[0]);
+        den[1] = fmaf(u, g.y, den[1]);
+        den[2] = fmaf(u, g.z, den[2]);
+        den[3] = fmaf(u, g.w, den[3]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = 4 * cg + j;
+        if (col < k) {
+          float p = 0.f;
+          for (int s = 0; s < splits; ++s) p += slabs[(int64_t)s * slab_stride + row * KP + col];
+          const float uu = urow[col];
+          const float d = den[j] + uu;
+          const float ratio = (d != 0.f) ? p / d : 1.f;
+          U[row * k + col] = uu * ratio;
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, int splits, int64_t slab_stride, int KP,
+                           const double* Gv, hipStream_t s) {
+  const int k4 = (k + 3) & ~3;
+  const int RT = 256 / (k4 >> 2);
+  size_t lds = (size_t)(k * k4 + RT * k4) * sizeof(float);
+  int64_t ntiles = (m + RT - 1) / RT;
+  int grid = (int)(ntiles < 2048 ? ntiles : 2048);
+  u_update_kernel<<<grid, 256, lds, s>>>(U, m, k, slabs, splits, slab_stride, KP, Gv);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Gram matrix F^T F: per-block float partials over 256 rows, reduced in double
+// ---------------------------------------------------------------------------
+constexpr int GRAM_ROWS = 256;
+int gram_blocks(int64_t rows) { return (int)((rows + GRAM_ROWS - 1) / GRAM_ROWS); }
+
+template <int NT>
+__global__ void __launch_bounds__(256) gram_partial_kernel(FactorView f, float* __restrict__ partial) {
+  constexpr int KP = 32 * NT, TN = 2 * NT;
+  __shared__ __attribute__((aligned(16))) float Fs[32][KP];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int k = f.cols;
+  float acc[TN][TN];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = 0.f;
+  const int64_t r0 = (int64_t)blockIdx.x * GRAM_ROWS;
+  for (int sub = 0; sub < GRAM_ROWS; sub += 32) {
+    __syncthreads();
+    for (int i = tid; i < 32 * KP; i += 256) {
+      int rr = i / KP, c = i - rr * KP;
+      int64_t row = r0 + sub + rr;
+      float v = 0.f;
+      if (row < f.rows && c < k) v = f.src[(int64_t)(c / f.kc) * f.blk_stride + row * f.kc + (c % f.kc)];
+      Fs[rr][c] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int rr = 0; rr < 32; ++rr) {
+      float av[TN], bv[TN];
+#pragma unroll
+      for (int a = 0; a < TN; ++a) av[a] = Fs[rr][ty * TN + a];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bv[b] = Fs[rr][tx * TN + b];
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = fmaf(av[a], bv[b], acc[a][b]);
+    }
+  }
+  float* out = partial + (int64_t)blockIdx.x * k * k;
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      int ia = ty * TN + a, ib = tx * TN + b;
+      if (ia < k && ib < k) out[ia * k + ib] = acc[a][b];
+    }
+}
+
+__global__ void __launch_bounds__(256) gram_reduce_kernel(const float* __restrict__ partial, int nblk, int kk2,
+                                                          double* __restrict__ G) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kk2) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[(int64_t)b * kk2 + i];
+  G[i] = s;
+}
+
+hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStream_t s) {
+  const int nblk = gram_blocks(f.rows);
+  const int NT = (f.cols + 31) / 32;
+  float* pf = reinterpret_cast<float*>(partial);
+  switch (NT) {
+    case 1: gram_partial_kernel<1><<<nblk, 256, 0, s>>>(f, pf); break;
+    case 2: gram_partial_kernel<2><<<nblk, 256, 0, s>>>(f, pf); break;
+    case 3: gram_partial_kernel<3><<<nblk, 256, 0, s>>>(f, pf); break;
+    case 4: gram_partial_kernel<4><<<nblk, 256, 0, s>>>(f, pf); break;
+    default: return hipErrorInvalidValue;
+  }
+  const int kk2 = f.cols * f.cols;
+  gram_reduce_kernel<<<(kk2 + 255) / 256, 256, 0, s>>>(pf, nblk, kk2, G);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Q slabs -> per-owner column blocks  q_send[r][j][c],  column kk = r*kc + c
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+slab_sum_blocks_kernel(const float* __restrict__ slabs, int splits, int64_t slab_stride, int KP, int64_t n, int k,
+                       int kc, float* __restrict__ q_send) {
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * k) return;
+  int64_t j = idx / k;
+  int kk = (int)(idx - j * k);
+  float v = 0.f;
+  for (int s = 0; s < splits; ++s) v += slabs[(int64_t)s * slab_stride + j * KP + kk];
+  int r = kk / kc, c = kk - r * kc;
+  q_send[((int64_t)r * n + j) * kc + c] = v;
+}
+
+hipError_t launch_slab_sum_blocks(const float* slabs, int splits, int64_t slab_stride, int KP, int64_t n, int k, int kc,
+                                  int nranks, float* q_send, hipStream_t s) {
+  (void)nranks;
+  int64_t total = n * k;
+  slab_sum_blocks_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(slabs, splits, slab_stride, KP, n, k, kc, q_send);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// active pathway -> dense position map for the own columns
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+build_pos_kernel(PathwayLibDev lib, const int32_t* __restrict__ active, int col0, int kc, int32_t* __restrict__ pos) {
+  const int c = blockIdx.x;
+  const int p = active[col0 + c];
+  const int64_t s0 = lib.sup_ptr[p];
+  const int ns = (int)(lib.sup_ptr[p + 1] - s0);
+  for (int s = threadIdx.x; s < ns; s += 256) pos[(int64_t)lib.sup_idx[s0 + s] * kc + c] = s;
+}
+
+hipError_t launch_build_pos(const PathwayLibDev& lib, const int32_t* active_dev, int col0, int ncols, int kc, int64_t n,
+                            int32_t* pos, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(pos, 0xFF, (size_t)n * kc * sizeof(int32_t), s);
+  if (e != hipSuccess) return e;
+  if (ncols > 0) build_pos_kernel<<<ncols, 256, 0, s>>>(lib, active_dev, col0, kc, pos);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// sparse pathway terms of the V update for the own columns   (:431-438)
+//   gnum = gamma * (W_k v_k) + delta * (v_k + 1)^-2   on the support S_k
+//   gden = gamma * deg_k * v_k
+// One workgroup per latent column: the column's support values are gathered
+// once into LDS, the CSR rows (support-local column indices) then read LDS only.
+// ---------------------------------------------------------------------------
+template <bool USE_LDS>
+__global__ void __launch_bounds__(256)
+graph_terms_kernel(PathwayLibDev lib, const int32_t* __restrict__ active, int col0, const float* __restrict__ V, int k,
+                   const double* __restrict__ hyper, float* __restrict__ gnum, float* __restrict__ gden) {
+  extern __shared__ __attribute__((aligned(16))) float vs[];
+  const int c = blockIdx.x, kk = col0 + c;
+  const int p = active[kk];
+  const int64_t s0 = lib.sup_ptr[p];
+  const int ns = (int)(lib.sup_ptr[p + 1] - s0);
+  const double gamma = hyper[0], delta = hyper[1];
+  if (USE_LDS) {
+    for (int s = threadIdx.x; s < ns; s += 256) vs[s] = V[(int64_t)lib.sup_idx[s0 + s] * k + kk];
+    __syncthreads();
+  }
+  for (int s = threadIdx.x; s < ns; s += 256) {
+    const double v = USE_LDS ? (double)vs[s] : (double)V[(int64_t)lib.sup_idx[s0 + s] * k + kk];
+    double wv = 0.0;
+    for (int64_t e = lib.row_ptr[s0 + s]; e < lib.row_ptr[s0 + s + 1]; ++e) {
+      const int cl = lib.col_local[e];
+      const double vc = USE_LDS ? (double)vs[cl] : (double)V[(int64_t)lib.sup_idx[s0 + cl] * k + kk];
+      wv += lib.w[e] * vc;
+    }
+    const double vp1 = v + 1.0;
+    gnum[(int64_t)c * lib.max_support + s] = (float)(gamma * wv + delta / (vp1 * vp1));
+    gden[(int64_t)c * lib.max_support + s] = (float)(gamma * (lib.sup_deg[s0 + s] * v));
+  }
+}
+
+hipError_t launch_graph_terms(const PathwayLibDev& lib, const int32_t* active_dev, int col0, int ncols, const float* V,
+                              int k, const double* hyper, float* gnum, float* gden, hipStream_t s) {
+  if (ncols <= 0) return hipSuccess;
+  size_t lds = (size_t)lib.max_support * sizeof(float);
+  if (lds <= 64 * 1024)
+    graph_terms_kernel<true><<<ncols, 256, lds, s>>>(lib, active_dev, col0, V, k, hyper, gnum, gden);
+  else
+    graph_terms_kernel<false><<<ncols, 256, 0, s>>>(lib, active_dev, col0, V, k, hyper, gnum, gden);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// V update for the own columns   (:424-425, :440-444)
+// ---------------------------------------------------------------------------
+constexpr int VUPD_MAX_BLOCKS = 1024;
+static inline int v_update_rt(int ncols) {
+  int ncg = ((ncols + 3) & ~3) >> 2;
+  if (ncg < 1) ncg = 1;
+  return 256 / ncg;
+}
+int v_update_blocks(int64_t n) {
+  // worst case (ncols=128): 8 rows per tile
+  int64_t t = (n + 7) / 8;
+  return (int)(t < VUPD_MAX_BLOCKS ? t : VUPD_MAX_BLOCKS);
+}
+
+__global__ void __launch_bounds__(256)
+v_update_kernel(const float* __restrict__ V, int64_t n, int k, int col0, int ncols, int kc,
+                const float* __restrict__ q_recv, const double* __restrict__ Gu, const int32_t* __restrict__ pos,
+                const float* __restrict__ gnum, const float* __restrict__ gden, int max_support,
+                float* __restrict__ v_send, double* __restrict__ partial, int nblocks_alloc) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k4 = (k + 3) & ~3;
+  const int nc4 = (ncols + 3) & ~3;
+  const int ncg = nc4 >> 2;
+  const int RT = 256 / ncg;
+  float* Gs = smem;              // [k][nc4]   own columns of U^T U
+  float* Vs = smem + k * nc4;    // [RT][k4]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < k * nc4; i += 256) {
+    int q = i / nc4, c = i - q * nc4;
+    Gs[i] = c < ncols ? (float)Gu[q * k + col0 + c] : 0.f;
+  }
+  const int cg = tid % ncg, rt = tid / ncg;
+  double colsq[4] = {0.0, 0.0, 0.0, 0.0};
+  double cross = 0.0;
+  const int64_t ntiles = (n + RT - 1) / RT;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    for (int i = tid; i < RT * k4; i += 256) {
+      int rr = i / k4, q = i - rr * k4;
+      int64_t row = tile * RT + rr;
+      Vs[i] = (row < n && q < k) ? V[row * k + q] : 0.f;
+    }
+    __syncthreads();
+    const int64_t row = tile * RT + rt;
+    if (rt < RT && row < n) {
+      float den[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* vrow = Vs + rt * k4;
+      for (int q = 0; q < k; ++q) {
+        const float v = vrow[q];
+        const float4 g = *reinterpret_cast<const float4*>(Gs + q * nc4 + 4 * cg);
+        den[0] = fmaf(v, g.x, den[0]);
+        den[1] = fmaf(v, g.y, den[1]);
+        den[2] = fmaf(v, g.z, den[2]);
+        den[3] = fmaf(v, g.w, den[3]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 4 * cg + j;
+        if (c < ncols) {
+          const float qv = q_recv[row * kc + c];
+          float num = qv, d = den[j];
+          const int ps = pos[row * kc + c];
+          if (ps >= 0) {
+            num += gnum[(int64_t)c * max_support + ps];
+            d += gden[(int64_t)c * max_support + ps];
+          }
+          if (d < PRMF_EPS) d = PRMF_EPS;
+          float vn = vrow[col0 + c] * (num / d);
+          if (vn < PRMF_EPS) vn = PRMF_EPS;
+          v_send[row * kc + c] = vn;
+          colsq[j] += (double)vn * (double)vn;
+          cross += (double)qv * (double)vn;
+        }
+      }
+    }
+  }
+  // deterministic block reduction: per own column over row-threads, cross over all
+  __syncthreads();
+  double* red = reinterpret_cast<double*>(smem);   // reuse: needs 256*5 doubles = 10 KB (host sizes LDS)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[tid * 5 + j] = colsq[j];
+  red[tid * 5 + 4] = cross;
+  __syncthreads();
+  double* out = partial + (int64_t)blockIdx.x * (kc + 1);
+  if (tid < ncols) {
+    const int mycg = tid >> 2, myj = tid & 3;
+    double s = 0.0;
+    for (int r2 = 0; r2 < RT; ++r2) s += red[(r2 * ncg + mycg) * 5 + myj];
+    out[tid] = s;
+  }
+  if (tid == 255) {
+    double s = 0.0;
+    for (int t2 = 0; t2 < 256; ++t2) s += red[t2 * 5 + 4];
+    out[kc] = s;
+  }
+  (void)nblocks_alloc;
+}
+
+hipError_t launch_v_update(const float* V, int64_t n, int k, int col0, int ncols, int kc, const float* q_recv,
+                           const double* Gu, const int32_t* pos, const float* gnum, const float* gden, int max_support,
+                           float* v_send, double* partial, hipStream_t s) {
+  const int nblk = v_update_blocks(n);
+  hipError_t e = hipMemsetAsync(partial, 0, (size_t)nblk * (kc + 1) * sizeof(double), s);
+  if (e != hipSuccess) return e;
+  if (ncols <= 0) return hipSuccess;
+  const int k4 = (k + 3) & ~3, nc4 = (ncols + 3) & ~3;
+  const int RT = v_update_rt(ncols);
+  size_t lds = (size_t)(k * nc4 + RT * k4) * sizeof(float);
+  if (lds < 256 * 5 * sizeof(double)) lds = 256 * 5 * sizeof(double);
+  int64_t ntiles = (n + RT - 1) / RT;
+  int grid = (int)(ntiles < nblk ? ntiles : nblk);
+  v_update_kernel<<<grid, 256, lds, s>>>(V, n, k, col0, ncols, kc, q_recv, Gu, pos, gnum, gden, max_support, v_send,
+                                         partial, nblk);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// objective pieces of the own columns   (:344-352 with normalize_laplacian :56-65)
+//   vhat = v / ||v|| ; y = D^-1/2 vhat on the support
+//   manifold_k = y^T (D y - W y) ; ignore_k = sum_{i in S} 1 / (vhat_i + 1)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+objective_col_kernel(PathwayLibDev lib, const int32_t* __restrict__ active, int col0, int kc,
+                     const float* __restrict__ v_send, const double* __restrict__ partial, int nblocks,
+                     double* __restrict__ colres, double* __restrict__ scratch) {
+  __shared__ double red[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double sq = 0.0;
+  for (int b = tid; b < nblocks; b += 256) sq += partial[(int64_t)b * (kc + 1) + c];
+  sq = block_sum_256(sq, red);
+  const double inv = 1.0 / sqrt(sq);
+  const int p = active[col0 + c];
+  const int64_t s0 = lib.sup_ptr[p];
+  const int ns = (int)(lib.sup_ptr[p + 1] - s0);
+  double* y = scratch + (int64_t)c * lib.max_support;
+  double ign = 0.0;
+  for (int s = tid; s < ns; s += 256) {
+    const double vh = (double)v_send[(int64_t)lib.sup_idx[s0 + s] * kc + c] * inv;
+    y[s] = vh * lib.sup_dis[s0 + s];
+    ign += 1.0 / (vh + 1.0);
+  }
+  __threadfence_block();
+  __syncthreads();
+  double man = 0.0;
+  for (int s = tid; s < ns; s += 256) {
+    const double ys = y[s];
+    double wy = 0.0;
+    for (int64_t e = lib.row_ptr[s0 + s]; e < lib.row_ptr[s0 + s + 1]; ++e) wy += lib.w[e] * y[lib.col_local[e]];
+    man += ys * (lib.sup_deg[s0 + s] * ys - wy);
+  }
+  man = block_sum_256(man, red);
+  ign = block_sum_256(ign, red);
+  if (tid == 0) {
+    colres[2 * c] = man;
+    colres[2 * c + 1] = ign;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+rank_extras_kernel(const double* __restrict__ partial, int nblocks, int kc, int ncols, const double* __restrict__ colres,
+                   double* __restrict__ extras) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  double cross = 0.0;
+  for (int b = tid; b < nblocks; b += 256) cross += partial[(int64_t)b * (kc + 1) + kc];
+  cross = block_sum_256(cross, red);
+  double man = 0.0, ign = 0.0;
+  for (int c = tid; c < ncols; c += 256) {
+    man += colres[2 * c];
+    ign += colres[2 * c + 1];
+  }
+  man = block_sum_256(man, red);
+  ign = block_sum_256(ign, red);
+  if (tid == 0) {
+    extras[0] = cross;
+    extras[1] = man;
+    extras[2] = ign;
+    extras[3] = 0.0;
+  }
+}
+
+hipError_t launch_objective_terms(const PathwayLibDev& lib, const int32_t* active_dev, int col0, int ncols, int kc,
+                                  int64_t n, const float* v_send, const double* partial, int nblocks, double* colres,
+                                  double* scratch, double* extras_out, hipStream_t s) {
+  (void)n;
+  if (ncols > 0)
+    objective_col_kernel<<<ncols, 256, 0, s>>>(lib, active_dev, col0, kc, v_send, partial, nblocks, colres, scratch);
+  rank_extras_kernel<<<1, 256, 0, s>>>(partial, nblocks, kc, ncols, colres, extras_out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// replicated V (row-major) from the gathered per-rank column blocks
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+assemble_v_kernel(const float* __restrict__ v_recv, int64_t blk_stride, int kc, int64_t n, int k, float* __restrict__ V) {
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * k) return;
+  int64_t j = idx / k;
+  int kk = (int)(idx - j * k);
+  int r = kk / kc, c = kk - r * kc;
+  V[idx] = v_recv[(int64_t)r * blk_stride + j * kc + c];
+}
+
+hipError_t launch_assemble_v(const float* v_recv, int nranks, int64_t blk_stride, int kc, int64_t n, int k, float* V,
+                             hipStream_t s) {
+  (void)nranks;
+  int64_t total = n * k;
+  assemble_v_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(v_recv, blk_stride, kc, n, k, V);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// objective record (:362-371) + tradeoff feedback (:542-548)
+//   recon^2 = ||X||^2 - 2 <X^T U, V> + <U^T U, V^T V>
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, int k, const float* __restrict__ v_recv,
+                int nranks, int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* __restrict__ hyper,
+                double* __restrict__ record) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  double gg = 0.0, fro = 0.0;
+  for (int i = tid; i < k * k; i += 256) gg += Gu[i] * Gv[i];
+  for (int a = tid; a < k; a += 256) fro += Gu[a * k + a];
+  gg = block_sum_256(gg, red);
+  fro = block_sum_256(fro, red);
+  if (tid == 0) {
+    double cross = 0.0, man = 0.0, ign = 0.0;
+    for (int r = 0; r < nranks; ++r) {
+      const double* ex = reinterpret_cast<const double*>(v_recv + (int64_t)r * blk_stride + extras_off);
+      cross += ex[0];
+      man += ex[1];
+      ign += ex[2];
+    }
+    const double gamma = hyper[0], delta = hyper[1], t = hyper[2];
+    const double recon_sq = norm_x_sq - 2.0 * cross + gg;
+    const double recon = sqrt(recon_sq > 0.0 ? recon_sq : 0.0);
+    record[0] = recon;
+    record[1] = man;
+    record[2] = ign;
+    record[3] = fro;
+    record[4] = gamma;
+    record[5] = delta;
+    record[6] = recon + gamma * man + delta * ign + fro;
+    record[7] = recon_sq;
+    if (t >= 0.0) {
+      const double denom = t * man;
+      const double g2 = (denom == 0.0) ? 1.0 : ((1.0 - t) * recon) / denom;
+      hyper[0] = g2;
+      hyper[1] = g2;
+    }
+  }
+}
+
+hipError_t launch_finalize(const double* Gu, const double* Gv, int k, const float* v_recv, int nranks,
+                           int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* hyper, double* record,
+                           hipStream_t s) {
+  finalize_kernel<<<1, 256, 0, s>>>(Gu, Gv, k, v_recv, nranks, blk_stride, extras_off, norm_x_sq, hyper, record);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// candidate scoring for restrict (:115-127): one wave per (pathway, latent)
+//   score = ||vhat[S_p]||_2 + 1 - vhat^T Lhat_p vhat
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) colnorm_kernel(const float* __restrict__ V, int64_t n, int k, double* __restrict__ out) {
+  __shared__ double red[256];
+  const int kk = blockIdx.x;
+  double s = 0.0;
+  for (int64_t j = threadIdx.x; j < n; j += 256) {
+    double v = (double)V[j * k + kk];
+    s += v * v;
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[kk] = sqrt(s);
+}
+
+__global__ void __launch_bounds__(64)
+score_kernel(PathwayLibDev lib, const float* __restrict__ V, int k, const double* __restrict__ colnorm,
+             double* __restrict__ scores) {
+  const int p = blockIdx.x, kk = blockIdx.y, lane = threadIdx.x;
+  const int64_t s0 = lib.sup_ptr[p];
+  const int ns = (int)(lib.sup_ptr[p + 1] - s0);
+  const double inv = 1.0 / colnorm[kk];
+  double mass = 0.0, man = 0.0;
+  for (int s = lane; s < ns; s += 64) {
+    const double vh = (double)V[(int64_t)lib.sup_idx[s0 + s] * k + kk] * inv;
+    const double ys = vh * lib.sup_dis[s0 + s];
+    double wy = 0.0;
+    for (int64_t e = lib.row_ptr[s0 + s]; e < lib.row_ptr[s0 + s + 1]; ++e) {
+      const int cl = lib.col_local[e];
+      wy += lib.w[e] * ((double)V[(int64_t)lib.sup_idx[s0 + cl] * k + kk] * inv * lib.sup_dis[s0 + cl]);
+    }
+    mass += vh * vh;
+    man += ys * (lib.sup_deg[s0 + s] * ys - wy);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mass += __shfl_down(mass, off);
+    man += __shfl_down(man, off);
+  }
+  if (lane == 0) scores[(int64_t)kk * lib.P + p] = sqrt(mass) + (1.0 - man);
+}
+
+hipError_t launch_score_candidates(const PathwayLibDev& lib, const float* V, int64_t n, int k, double* colnorm_scratch,
+                                   double* scores, hipStream_t s) {
+  colnorm_kernel<<<k, 256, 0, s>>>(V, n, k, colnorm_scratch);
+  score_kernel<<<dim3(lib.P, k), 64, 0, s>>>(lib, V, k, colnorm_scratch, scores);
+  return hipGetLastError();
+}
+
+}  // namespace prmf

@@ -1,0 +1,362 @@
+"""Host side of the MI355X PRMF hot path: a device-resident engine plus drop-in
+counterparts of the reference's solver functions
+
+    nmf_manifold_vec_update            script/prmf_runner.py:374-451
+    nmf_manifold_vec_update_tradeoff   script/prmf_runner.py:497-554
+    nmf_pathway                        script/prmf_runner.py:556-792
+
+with the same names, argument meaning, stdout trace and error behaviour.  All
+arithmetic of the iteration runs in libprmf_hip.so (hand-written HIP for gfx950)
+through the ctypes C-ABI of include/prmf_hip.h.  PyTorch is used only to own
+device buffers and to name the current HIP stream.  There is no CPU fallback.
+"""
+import ctypes as C
+import math
+import sys
+
+import numpy as np
+
+from . import _capi
+from .pathways import PathwayLibrary
+
+EPSILON = np.finfo(np.float32).eps     # prmf_runner.py:23
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("prmf_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU path for the PRMF inner loop")
+    return torch
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class PrmfEngine(object):
+    """One GPU's share of a PRMF solve: X (and X^T) resident in HBM, the pathway
+    library resident, U/V updated in place by `step`.
+
+    nranks > 1: X is row-sharded (this rank holds m_local samples) and the
+    phase_* methods are driven by prmf_amd.distributed with collectives between
+    them; see include/prmf_hip.h."""
+
+    def __init__(self, m_local, n, k, x_dtype="f32", device=None, nranks=1, rank=0, timing=False):
+        self.torch = _torch()
+        self.lib = _capi.load()
+        torch = self.torch
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.m, self.n, self.k = int(m_local), int(n), int(k)
+        self.x_dtype = {"f32": _capi.PRMF_X_F32, "fp32": _capi.PRMF_X_F32, "float32": _capi.PRMF_X_F32,
+                        "bf16": _capi.PRMF_X_BF16, "bfloat16": _capi.PRMF_X_BF16}[x_dtype]
+        self.torch_x_dtype = torch.float32 if self.x_dtype == _capi.PRMF_X_F32 else torch.bfloat16
+        self.nranks, self.rank = int(nranks), int(rank)
+        self.ctx = C.c_void_p()
+        flags = _capi.PRMF_FLAG_TIMING if timing else 0
+        rc = self.lib.prmf_create(C.byref(self.ctx), self.device, self.m, self.n, self.k, self.x_dtype,
+                                  self.nranks, self.rank, flags)
+        if rc != _capi.PRMF_OK:
+            raise _capi.PrmfError(rc, self.lib.prmf_last_error(None).decode())
+        self.library = None
+        self._comm = None
+        self.sizes = _capi.CommSizes()
+        self._check(self.lib.prmf_get_comm_sizes(self.ctx, C.byref(self.sizes)))
+
+    # -- plumbing -------------------------------------------------------------
+    def _check(self, rc):
+        _capi.check(self.lib, self.ctx, rc)
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "ctx", None) is not None and self.ctx.value:
+            self.lib.prmf_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_tensor(self, a, dtype=None):
+        """numpy / torch -> contiguous tensor on this engine's GPU."""
+        torch = self.torch
+        if not isinstance(a, torch.Tensor):
+            a = torch.from_numpy(np.ascontiguousarray(a))
+        return a.to(device="cuda:%d" % self.device, dtype=dtype or a.dtype).contiguous()
+
+    # -- inputs ---------------------------------------------------------------
+    def set_x(self, X, norm_x_sq=None):
+        """Upload this rank's rows of X (numpy or torch, any float dtype; rounded
+        to the engine's x dtype).  norm_x_sq = ||X||_F^2 of the GLOBAL matrix; if
+        None it is computed from the rounded local X (single rank)."""
+        torch = self.torch
+        Xd = self.device_tensor(X, self.torch_x_dtype)
+        if tuple(Xd.shape) != (self.m, self.n):
+            raise ValueError("X has shape {} != (m_local, n) = {}".format(tuple(Xd.shape), (self.m, self.n)))
+        if norm_x_sq is None:
+            if self.nranks != 1:
+                raise ValueError("norm_x_sq (global) is required with nranks > 1")
+            norm_x_sq = self.local_norm_sq(Xd)
+        self._check(self.lib.prmf_set_x(self.ctx, C.c_void_p(Xd.data_ptr()), self.n, float(norm_x_sq), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()   # Xd may be freed after this
+        self.norm_x_sq = float(norm_x_sq)
+        return self.norm_x_sq
+
+    def local_norm_sq(self, Xd):
+        """sum of squares of the rounded local X in float64 (chunked)."""
+        total = 0.0
+        rows = max(1, (1 << 24) // max(1, Xd.shape[1]))
+        for r0 in range(0, Xd.shape[0], rows):
+            total += float((Xd[r0:r0 + rows].double() ** 2).sum().item())
+        return total
+
+    def set_library(self, library):
+        if library.n != self.n:
+            raise ValueError("pathway library is over %d genes, engine over %d" % (library.n, self.n))
+        arrs = library.arrays()
+        self._check(self.lib.prmf_set_pathway_library(self.ctx, library.P, *[_ptr(a) for a in arrs], self._stream()))
+        self.library = library
+
+    def set_active(self, k_to_lapl):
+        a = np.ascontiguousarray(np.asarray(k_to_lapl, dtype=np.int32))
+        if a.shape != (self.k,):
+            raise ValueError("k_to_lapl must have k_latent = %d entries" % self.k)
+        self._check(self.lib.prmf_set_active(self.ctx, _ptr(a), self._stream()))
+
+    def invalidate_factors(self):
+        self._check(self.lib.prmf_invalidate_factors(self.ctx))
+
+    # -- the hot path ----------------------------------------------------------
+    def _check_factors(self, U, V):
+        torch = self.torch
+        for name, t, shape in (("U", U, (self.m, self.k)), ("V", V, (self.n, self.k))):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError("%s must be a contiguous float32 CUDA tensor" % name)
+            if tuple(t.shape) != shape:
+                raise ValueError("%s has shape %s != %s" % (name, tuple(t.shape), shape))
+
+    def step(self, U, V, n_steps, gamma, delta, tradeoff=None):
+        """n_steps iterations in place on device tensors U (m x k), V (n x k).
+        Returns (list of objective dicts, one per iteration; (gamma, delta) for
+        the next call)."""
+        self._check_factors(U, V)
+        obj = np.zeros((max(n_steps, 1), _capi.PRMF_OBJ_STRIDE))
+        gd = np.zeros(2)
+        t = -1.0 if tradeoff is None else float(tradeoff)
+        rc = self.lib.prmf_step(self.ctx, C.c_void_p(U.data_ptr()), C.c_void_p(V.data_ptr()), int(n_steps),
+                                float(gamma), float(delta), t, _ptr(obj), _ptr(gd), self._stream())
+        if rc == _capi.PRMF_ERR_NUMERIC:
+            # the reference runs under np.seterr(divide='raise') (prmf_runner.py:22)
+            raise FloatingPointError(self.lib.prmf_last_error(self.ctx).decode())
+        self._check(rc)
+        return self.records_to_dicts(obj[:n_steps]), (float(gd[0]), float(gd[1]))
+
+    @staticmethod
+    def records_to_dicts(obj):
+        return [{key: float(row[j]) for j, key in enumerate(_capi.OBJ_KEYS)} for row in obj]
+
+    def score_candidates(self, V):
+        """k x P matrix of restrict's match scores (prmf_runner.py:115-127)."""
+        out = np.zeros((self.k, self.library.P))
+        self._check(self.lib.prmf_score_candidates(self.ctx, C.c_void_p(V.data_ptr()), _ptr(out), self._stream()))
+        return out
+
+    def sweep_info(self):
+        info = _capi.SweepInfo()
+        self._check(self.lib.prmf_get_sweep_info(self.ctx, C.byref(info)))
+        return info
+
+    def timing(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self._check(self.lib.prmf_get_timing(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+
+# ---------------------------------------------------------------------------
+# drop-in inner loop  (prmf_runner.py:374-451 / :497-554)
+# ---------------------------------------------------------------------------
+def _run_inner(X, U, V, k_to_W, k_to_feat_inds, n_steps, gamma, delta, i, verbose, tradeoff, x_dtype, engine):
+    m, k_latent = U.shape
+    n, _ = V.shape
+    own = engine is None
+    if own:
+        engine = PrmfEngine(m, n, k_latent, x_dtype=x_dtype)
+        engine.set_x(X)
+    try:
+        library = PathwayLibrary.from_sparse([k_to_W[k] for k in range(k_latent)],
+                                             [k_to_feat_inds[k] for k in range(k_latent)])
+        engine.set_library(library)
+        engine.set_active(np.arange(k_latent))
+        torch = engine.torch
+        Ud = engine.device_tensor(np.asarray(U), torch.float32)
+        Vd = engine.device_tensor(np.asarray(V), torch.float32)
+        engine.invalidate_factors()
+        objs, gd = engine.step(Ud, Vd, n_steps, gamma, delta, tradeoff)
+        for s, od in enumerate(objs):
+            print(i + s + 1, od["obj"])               # :447
+            if verbose:
+                print(od)
+        U_new = Ud.cpu().numpy().astype(np.float64)
+        V_new = Vd.cpu().numpy().astype(np.float64)
+    finally:
+        if own:
+            engine.close()
+    return U_new, V_new, (objs[-1] if objs else None), gd
+
+
+def nmf_manifold_vec_update(X, U, V, k_to_W, k_to_D, k_to_L, k_to_feat_inds, n_steps=10, gamma=1.0, delta=1.0,
+                            i=0, verbose=False, norm_X=None, x_dtype="f32", engine=None):
+    """Same call as the reference (prmf_runner.py:374): `n_steps` update steps with a
+    fixed Laplacian per latent factor; returns (U, V, obj_data).  k_to_D / k_to_L
+    are accepted for signature compatibility (D and L are derived from W)."""
+    U2, V2, od, _ = _run_inner(X, U, V, k_to_W, k_to_feat_inds, n_steps, gamma, delta, i, verbose, None, x_dtype, engine)
+    return U2, V2, od
+
+
+def nmf_manifold_vec_update_tradeoff(X, U, V, k_to_W, k_to_D, k_to_L, k_to_feat_inds, n_steps=10, i=0, verbose=False,
+                                     norm_X=None, tradeoff=0.5, gamma=1, delta=1, x_dtype="f32", engine=None):
+    """Same call as the reference (prmf_runner.py:497): returns (U, V, obj_data, gamma, delta)."""
+    U2, V2, od, gd = _run_inner(X, U, V, k_to_W, k_to_feat_inds, n_steps, gamma, delta, i, verbose, tradeoff, x_dtype, engine)
+    return U2, V2, od, gd[0], gd[1]
+
+
+# ---------------------------------------------------------------------------
+# outer solver  (prmf_runner.py:556-792)
+# ---------------------------------------------------------------------------
+def restrict(scores_kP, latent_to_pathway_data, percentile=19.9):
+    """prmf_runner.py:129-194 on a precomputed k x P score matrix (the GPU scores
+    every pair; only the still-candidate ones are read here)."""
+    rv = {}
+    for k, data in latent_to_pathway_data.items():
+        inds = [x[0] for x in data]
+        if len(inds) > 1:
+            scores = scores_kP[k, inds]
+            keep = np.where(scores > np.percentile(scores, percentile))[0]
+            if len(keep) == 0:
+                # :174-182 all scores tie: the reference asks np.random.choice for a
+                # negative sample size here and raises ValueError; so do we.
+                size = math.ceil(len(inds) * (1 - percentile) / 100)
+                chosen = np.random.choice(np.array(inds), size=size, replace=False)
+                rv[k] = [(int(c), float(scores_kP[k, c])) for c in chosen]
+            else:
+                rv[k] = [(inds[i], float(scores[i])) for i in keep]
+        else:
+            rv[k] = data
+    return rv
+
+
+def force_distinct_lapls(V, library, latent_to_pathway_data, k_to_lapl, gamma, delta):
+    """prmf_runner.py:209-258: max-weight matching between latent factors and their
+    remaining candidate pathways, weight 1/(gamma v^T L v + delta*ignore).  As in the
+    reference the ignore term is overwritten (not summed) over the active supports
+    (:233-235), so it is the last latent's value."""
+    import networkx as nx
+    G = nx.Graph()
+    k_last = max(k_to_lapl.keys())
+    ign = float(np.sum(1.0 / (V[library.supports[k_to_lapl[k_last]], k_last] + 1)))
+    for k, data in latent_to_pathway_data.items():
+        for lapl, _score in data:
+            denom = gamma * library.laplacian_quadratic(lapl, V[:, k]) + delta * ign
+            G.add_edge("k{}".format(k), "l{}".format(lapl), weight=0 if denom == 0 else 1 / denom)
+    for a, b in nx.max_weight_matching(G):
+        if a[0] != "k":
+            a, b = b, a
+        latent_to_pathway_data[int(a[1:])] = [(int(b[1:]), 2)]
+    return latent_to_pathway_data
+
+
+def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3, max_iter=1000, nodelist=None,
+                modulus=10, U_init=None, V_init=None, verbose=False, x_dtype="f32", library=None, round_log=None,
+                trace=None):
+    """Same call and return value as the reference's nmf_pathway (prmf_runner.py:556).
+
+    Extra keyword-only arguments: x_dtype ("f32" | "bf16" storage of X on the
+    GPU), library (a prebuilt PathwayLibrary instead of Gs), round_log / trace
+    (lists that receive the per-round active assignment / per-iteration records).
+    Randomness comes from the legacy global numpy stream in the reference's order:
+    rand(m,k), rand(n,k) (:651-653), one multinomial draw per latent per round (:723)."""
+    from scipy.stats import multinomial
+    X = np.asarray(X)
+    m, n = X.shape
+    engine = PrmfEngine(m, n, k_latent, x_dtype=x_dtype)
+    try:
+        torch = engine.torch
+        norm_X = math.sqrt(engine.set_x(X))                       # :640 (of the X the GPU holds)
+        print("norm(X) = {}".format(norm_X))                      # :641
+        gamma = gamma * norm_X / k_latent                         # :644
+        delta = delta * 10 / norm_X                               # :645
+        if U_init is None:
+            U_init = 3 * (1 - np.random.rand(m, k_latent))
+        if V_init is None:
+            V_init = 3 * (1 - np.random.rand(n, k_latent))
+        if U_init.shape != (m, k_latent):
+            raise ValueError("Invalid U_init with shape {} != (m_obs, k_latent) = {}".format(U_init.shape, (m, k_latent)))
+        if V_init.shape != (n, k_latent):
+            raise ValueError("Invalid V_init with shape {} != (n_feature, k_latent) = {}".format(V_init.shape, (n, k_latent)))
+        if library is None:
+            library = PathwayLibrary.from_graphs(Gs, nodelist)    # :670-696
+        engine.set_library(library)
+        U = engine.device_tensor(U_init, torch.float32)
+        V = engine.device_tensor(V_init, torch.float32)
+
+        l2p = {k: [(p, 1) for p in range(library.P)] for k in range(k_latent)}     # :700
+        converged, candidates_remain = False, True
+        obj, obj_data = math.inf, {}
+        best = {"obj_data": {"obj": np.inf}}
+        i = 0
+        k_to_lapl = {}
+        while i < max_iter and (candidates_remain or not converged):
+            for k in range(k_latent):                              # :717-729
+                inds = [x[0] for x in l2p[k]]
+                scores = np.array([x[1] for x in l2p[k]])
+                sample = multinomial.rvs(1, scores / np.sum(scores))
+                k_to_lapl[k] = inds[np.where(sample != 0)[0][0]]
+            if round_log is not None:
+                round_log.append([int(k_to_lapl[k]) for k in range(k_latent)])
+            if verbose:
+                print('--------------------------------------------')
+                print('Latent/Pathway association at this iteration')
+                print('--------------------------------------------')
+                for k, lapl_ind in k_to_lapl.items():
+                    print(k, lapl_ind)
+                print('--------------------------------------------')
+            engine.set_active([k_to_lapl[k] for k in range(k_latent)])
+            objs, (g2, d2) = engine.step(U, V, modulus, gamma, delta, tradeoff)          # :740 / :742
+            if tradeoff is not None:
+                gamma, delta = g2, d2
+            for s, od in enumerate(objs):
+                print(i + s + 1, od["obj"])
+                if verbose:
+                    print(od)
+                if trace is not None:
+                    trace.append(od)
+            obj_data = objs[-1]
+            i += modulus
+            if obj_data["obj"] < best["obj_data"]["obj"]:           # :747-750
+                best = {"U": U.clone(), "V": V.clone(), "obj_data": obj_data}
+            if candidates_remain:                                   # :754-770
+                if min(len(v) for v in l2p.values()) <= k_latent:
+                    Vh = V.cpu().numpy().astype(np.float64)
+                    l2p = force_distinct_lapls(Vh, library, l2p, dict(k_to_lapl), gamma, delta)
+                    candidates_remain = False
+                else:
+                    sys.stderr.write('Before restrict\n')
+                    l2p = restrict(engine.score_candidates(V), l2p)
+                    sys.stderr.write('After restrict\n')
+                    candidates_remain = any(len(v) > 1 for v in l2p.values())
+            prev_obj, obj = obj, obj_data["obj"]
+            converged = abs(obj - prev_obj) / obj < tol              # :772-774
+        if best["obj_data"]["obj"] < obj_data["obj"]:                # :778-782
+            print('Local optima at convergence (or after max iterations) is not the best among all iterates; returning best instead')
+            U, V, obj_data = best["U"], best["V"], best["obj_data"]
+        U_out = U.cpu().numpy().astype(np.float64)
+        V_out = V.cpu().numpy().astype(np.float64)
+        obj_data = dict(obj_data)
+        obj_data["latent_to_pathway_data"] = l2p
+        return U_out, V_out, obj_data
+    finally:
+        engine.close()
