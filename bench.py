@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""Benchmark of the PRMF inner loop on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5]
+
+One "step" = one iteration of the hot path (U-update + V-update + the objective
+record, script/prmf_runner.py:420-447) on synthetic inputs of the configuration
+BASELINE.json's target is quoted on (c3: X 50000 x 20000 bf16, k = 64, 300 tree
+pathways).  X, U, V are resident in HBM before the timed
+region.  With N > 1 (launched by torch.distributed.run, one rank per GPU) the
+SAME global problem is row-sharded over the ranks (strong scaling), exchanges go
+over RCCL.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(torch, Xd, U0, V0, pathways, active, gamma, delta, m_full, budget_s):
+    """The oracle (float64 NumPy/SciPy restatement of prmf_runner.py:419-447,
+    faithful mode: materialised residual) timed on this box's host cores on a row
+    sample of the same workload; scaled linearly in m to the full problem."""
+    from oracle import prmf_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    n, k = V0.shape
+    m_s = min(Xd.shape[0], 2000)
+    Xs = Xd[:m_s].to(torch.float64).cpu().numpy()
+    Us = U0[:m_s].to(torch.float64).cpu().numpy()
+    Vs = V0.to(torch.float64).cpu().numpy()
+    pws = [orc.pathway_from_edges(n, *[pathways[p][i] for i in (0, 2, 1)]) for p in active]
+    # one untimed warm-up iteration, then as many as fit in the budget (>= 2)
+    Us, Vs, _ = orc.nmf_manifold_vec_update(Xs, Us, Vs, pws, n_steps=1, gamma=gamma, delta=delta)
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        Us, Vs, od = orc.nmf_manifold_vec_update(Xs, Us, Vs, pws, n_steps=1, gamma=gamma, delta=delta)
+        iters += 1
+        el = time.perf_counter() - t0
+        if (el > budget_s and iters >= 2) or iters >= 200:
+            break
+    it_s_sample = iters / el
+    return {"value": it_s_sample * m_s / m_full, "unit": "iterations/s", "cores": int(threads), "kind": "port",
+            "sample": "oracle/prmf_oracle.py (float64, faithful residual) on the first %d of %d sample rows "
+                      "(all %d genes, k=%d, %d active pathways): %d iterations in %.1f s = %.3f it/s, "
+                      "scaled by %d/%d (cost is linear in m)" % (m_s, m_full, n, k, len(active), iters, el,
+                                                                 it_s_sample, m_s, m_full)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from prmf_amd import PathwayLibrary
+    from prmf_amd import synthetic as syn
+    from prmf_amd.solver import PrmfEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    m, n, k, P, x_dtype = syn.CONFIGS[args.workload]
+    tdt = torch.bfloat16 if x_dtype == "bf16" else torch.float32
+    lo, hi = syn.shard_rows(m, world, rank)
+    Xd = syn.x_rows_torch(torch, dev, args.seed, n, k, lo, hi, tdt)
+    eng = PrmfEngine(hi - lo, n, k, x_dtype=x_dtype, device=local_rank, nranks=world, rank=rank)
+    nsq = torch.tensor([eng.local_norm_sq(Xd)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(nsq)
+    norm_x = math.sqrt(float(nsq.item()))
+    eng.set_x(Xd, norm_x_sq=float(nsq.item()))
+    pathways = syn.tree_pathways(n, P, 300, args.seed)
+    eng.set_library(PathwayLibrary.from_edge_lists(n, pathways))
+    active = [kk % P for kk in range(k)]
+    eng.set_active(active)
+    gamma, delta = norm_x / k, 10.0 / norm_x                     # CLI defaults (prmf_runner.py:644-645)
+    U = syn.init_factor_torch(torch, dev, args.seed + 1, m, k, lo, hi)
+    V = syn.init_factor_torch(torch, dev, args.seed + 2, n, k)
+    U0, V0 = U.clone(), V.clone()
+
+    if world > 1:
+        from prmf_amd.distributed import DistributedPrmf
+        runner = DistributedPrmf(eng)
+        step = lambda s: runner.step(U, V, s, gamma, delta)
+    else:
+        step = lambda s: eng.step(U, V, s, gamma, delta)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        step(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    objs, _ = step(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    # live roofline of the dominant kernel (the X / X^T sweep): HIP events on the
+    # launch stream around every sweep launch of a short extra run
+    eng.set_timing(True)
+    step(min(args.steps, 20))
+    torch.cuda.synchronize()
+    ms_xv, ms_xtu, _ = eng.timing()
+    eng.set_timing(False)
+    eb = 2 if x_dtype == "bf16" else 4
+    ml = hi - lo
+    # algorithmic bytes per sweep launch: the data matrix once + the factor once + the product once
+    bytes_launch = 0.5 * ((ml * n * eb + n * k * 4 + ml * k * 4) + (ml * n * eb + ml * k * 4 + n * k * 4))
+    avg_ms = 0.5 * (ms_xv + ms_xtu)
+    achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
+
+    out = None
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.workload)
+        if world == 1 and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_sweep_launch")
+        out = {
+            "metric": "nmf_update_iterations_per_sec", "value": args.steps / elapsed, "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16" if x_dtype == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "%s: synthetic X %dx%d (%s), k=%d, %d random tree pathways of 300 genes, "
+                                   "active pathway k mod P, gamma=||X||/k, delta=10/||X||"
+                                   % (args.workload, m, n, x_dtype, k, P),
+                       "samples": m, "genes": n, "k_latent": k, "pathways": P,
+                       "parallelism": "X row-sharded x%d, V-update column-sharded" % world},
+            "recon_err": objs[-1]["recon"], "objective": objs[-1]["obj"],
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "sweep_kernel (X*V and X^T*U, 2 launches/iteration)",
+                         "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": avg_ms,
+                         "ms_xv": ms_xv, "ms_xtu": ms_xtu,
+                         "sweep_share_of_step": 2 * avg_ms / (1e3 * elapsed / args.steps)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(torch, Xd, U0, V0, pathways, active, gamma, delta, m, args.cpu_seconds)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

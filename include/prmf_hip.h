@@ -192,10 +192,14 @@ typedef struct prmf_sweep_info {
 } prmf_sweep_info;
 int prmf_get_sweep_info(const prmf_ctx* ctx, prmf_sweep_info* out);
 
-/* Time (ms, HIP events on `stream`) of the last `prmf_step`'s two sweeps and of
- * everything else, averaged per iteration; valid only if the ctx was created
- * with PRMF_FLAG_TIMING. */
+/* Average duration (ms, HIP events recorded on the launch stream around each
+ * launch) of the X*V sweep and of the X^T*U sweep over the iterations of the last
+ * prmf_begin..prmf_end span (prmf_step = one span per <=256 iterations); needs
+ * timing enabled (PRMF_FLAG_TIMING at creation or prmf_set_timing). */
 #define PRMF_FLAG_TIMING 0x1u
+/* Switch the per-launch event timing on or off after creation (bench.py times its
+ * throughput run without events and a second short run with them). */
+int prmf_set_timing(prmf_ctx* ctx, int enabled);
 int prmf_get_timing(const prmf_ctx* ctx, double* ms_xv, double* ms_xtu, double* ms_total);
 
 #ifdef __cplusplus

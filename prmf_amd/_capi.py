@@ -54,6 +54,7 @@ SIGNATURES = {
     "prmf_end": (_i, [_vp, _i, _vp, _vp, _vp]),
     "prmf_score_candidates": (_i, [_vp, _vp, _vp, _vp]),
     "prmf_get_sweep_info": (_i, [_vp, C.POINTER(SweepInfo)]),
+    "prmf_set_timing": (_i, [_vp, _i]),
     "prmf_get_timing": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)]),
 }
 
@@ -76,6 +77,12 @@ def load(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64.  libprmf_hip.so
+    # must share that HIP runtime instance (torch owns the device buffers and the
+    # stream), so torch is always loaded first: the dynamic loader then resolves our
+    # DT_NEEDED libamdhip64.so.7 to the copy that is already mapped.  Loading ours
+    # first leaves two runtimes in the process and the second one finds no device.
+    import torch  # noqa: F401
     if not os.path.exists(p):
         raise PrmfLibraryError(
             "%s not found: build it with `python -m prmf_amd._build` (hipcc, gfx950). "

@@ -78,7 +78,7 @@ struct prmf_ctx {
   bool prepared = false;
 
   // timing
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> ev;          // [MAX_RECORDS][4] with PRMF_FLAG_TIMING
   double ms_xv = 0, ms_xtu = 0, ms_total = 0;
   int timed_iters = 0;
 
@@ -237,12 +237,7 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
     fail(c, PRMF_ERR_HIP, "hipHostMalloc failed");
     return bail(PRMF_ERR_HIP);
   }
-  if (flags & PRMF_FLAG_TIMING)
-    for (auto& ev : c->ev)
-      if (hipEventCreate(&ev) != hipSuccess) {
-        fail(c, PRMF_ERR_HIP, "hipEventCreate failed");
-        return bail(PRMF_ERR_HIP);
-      }
+  if ((flags & PRMF_FLAG_TIMING) && (rc = prmf_set_timing(c, 1))) return bail(rc);
   *out = c;
   return PRMF_OK;
 }
@@ -453,14 +448,15 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
   int rc;
   if ((rc = check_ready(c))) return rc;
   if (!c->prepared) return fail(c, PRMF_ERR_STATE, "prmf_begin has not been called");
+  if (c->cursor >= MAX_RECORDS) return fail(c, PRMF_ERR_STATE, "more than %d iterations between prmf_begin and prmf_end", MAX_RECORDS);
   if ((rc = set_device(c))) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (c->m > 0) {
     const bool timing = (c->flags & PRMF_FLAG_TIMING) != 0;
-    if (timing) HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 0], s));
     // P = X V                                             (prmf_runner.py:420)
     HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xv, c->X, c->ldx, c->m, c->Vp, c->NT, c->slabs, c->slab_stride_p, s));
-    if (timing) HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 1], s));
     // U <- U * P / (U Gv + U)                              (:421-422)
     HIP_TRY(c, launch_u_update(c->U, c->m, c->k, c->slabs, c->plan_xv.splits, c->slab_stride_p, c->KP, c->Gv, s));
     FactorView fu{c->U, (int)c->m, c->k, c->k, 0};
@@ -479,10 +475,10 @@ int prmf_phase_q(prmf_ctx* c, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const bool timing = (c->flags & PRMF_FLAG_TIMING) != 0;
   if (c->m > 0) {
-    if (timing) HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 2], s));
     // Q = X^T U_new                                       (:424)
     HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xtu, c->XT, c->ldxt, c->n, c->Up, c->NT, c->slabs, c->slab_stride_q, s));
-    if (timing) HIP_TRY(c, hipEventRecord(c->ev[3], s));
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 3], s));
     HIP_TRY(c, launch_slab_sum_blocks(c->slabs, c->plan_xtu.splits, c->slab_stride_q, c->KP, c->n, c->k, c->kc,
                                       c->nranks, c->q_send, s));
   } else {
@@ -534,6 +530,18 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
                               (size_t)n_steps * PRMF_OBJ_STRIDE * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipMemcpyAsync(c->hyper_host, c->hyper, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
+  if ((c->flags & PRMF_FLAG_TIMING) && c->m > 0) {
+    c->ms_xv = c->ms_xtu = 0;
+    c->timed_iters = 0;
+    for (int i = 0; i < c->cursor; ++i) {
+      float a = 0, b = 0;
+      HIP_TRY(c, hipEventElapsedTime(&a, c->ev[(size_t)i * 4 + 0], c->ev[(size_t)i * 4 + 1]));
+      HIP_TRY(c, hipEventElapsedTime(&b, c->ev[(size_t)i * 4 + 2], c->ev[(size_t)i * 4 + 3]));
+      c->ms_xv += a;
+      c->ms_xtu += b;
+      c->timed_iters++;
+    }
+  }
   if (obj_out && n_steps > 0) std::memcpy(obj_out, c->records_host, (size_t)n_steps * PRMF_OBJ_STRIDE * sizeof(double));
   if (gamma_delta_out) {
     gamma_delta_out[0] = c->hyper_host[0];
@@ -551,8 +559,6 @@ int prmf_step(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma, doub
   if (!c) return PRMF_ERR_ARG;
   if (c->nranks != 1) return fail(c, PRMF_ERR_STATE, "prmf_step is the single-rank form; use the phase calls with nranks > 1");
   if (n_steps < 0) return fail(c, PRMF_ERR_ARG, "n_steps < 0");
-  const bool timing = (c->flags & PRMF_FLAG_TIMING) != 0;
-  if (timing) { c->ms_xv = c->ms_xtu = c->ms_total = 0; c->timed_iters = 0; }
   int done = 0;
   int rc;
   while (done < n_steps || (n_steps == 0 && done == 0)) {
@@ -563,17 +569,6 @@ int prmf_step(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma, doub
       if ((rc = prmf_phase_q(c, stream))) return rc;
       if ((rc = prmf_phase_v(c, stream))) return rc;
       if ((rc = prmf_phase_post(c, stream))) return rc;
-      if (timing && i == batch - 1) {
-        // events of the last iteration of the batch
-        hipStream_t s = (hipStream_t)stream;
-        HIP_TRY(c, hipStreamSynchronize(s));
-        float a = 0, b = 0;
-        HIP_TRY(c, hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
-        HIP_TRY(c, hipEventElapsedTime(&b, c->ev[2], c->ev[3]));
-        c->ms_xv += a;
-        c->ms_xtu += b;
-        c->timed_iters++;
-      }
     }
     double gd[2] = {gamma, delta};
     if ((rc = prmf_end(c, batch, obj_out ? obj_out + (size_t)done * PRMF_OBJ_STRIDE : nullptr, gd, stream))) return rc;
@@ -618,6 +613,20 @@ int prmf_get_sweep_info(const prmf_ctx* c, prmf_sweep_info* out) {
   out->splits_xtu = c->plan_xtu.splits;
   out->grid_xv = c->plan_xv.panels * c->plan_xv.splits;
   out->grid_xtu = c->plan_xtu.panels * c->plan_xtu.splits;
+  return PRMF_OK;
+}
+
+int prmf_set_timing(prmf_ctx* c, int enabled) {
+  if (!c) return PRMF_ERR_ARG;
+  if (enabled && c->ev.empty()) {
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    c->ev.assign((size_t)MAX_RECORDS * 4, nullptr);
+    for (auto& ev : c->ev)
+      if (hipEventCreate(&ev) != hipSuccess) return fail(c, PRMF_ERR_HIP, "hipEventCreate failed");
+  }
+  if (enabled) c->flags |= PRMF_FLAG_TIMING; else c->flags &= ~PRMF_FLAG_TIMING;
+  c->timed_iters = 0;
   return PRMF_OK;
 }
 

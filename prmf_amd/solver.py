@@ -159,6 +159,56 @@ class PrmfEngine(object):
     def records_to_dicts(obj):
         return [{key: float(row[j]) for j, key in enumerate(_capi.OBJ_KEYS)} for row in obj]
 
+    # -- phase interface (multi-rank; driven by prmf_amd.distributed) -------------
+    def comm_buffers(self):
+        """Allocate the collective buffers as torch tensors on this GPU and hand
+        their pointers to the library.  With one rank q_recv / v_recv alias the
+        send buffers."""
+        if self._comm is None:
+            torch, s = self.torch, self.sizes
+            dev = "cuda:%d" % self.device
+            b = {"gram": torch.zeros(s.gram_doubles, dtype=torch.float64, device=dev),
+                 "q_send": torch.zeros(s.q_send_floats, dtype=torch.float32, device=dev),
+                 "v_send": torch.zeros(s.v_send_floats, dtype=torch.float32, device=dev)}
+            if self.nranks == 1:
+                b["q_recv"], b["v_recv"] = b["q_send"], b["v_send"]
+            else:
+                b["q_recv"] = torch.zeros(s.q_recv_floats, dtype=torch.float32, device=dev)
+                b["v_recv"] = torch.zeros(s.v_recv_floats, dtype=torch.float32, device=dev)
+            p = lambda t: C.c_void_p(t.data_ptr())
+            self._check(self.lib.prmf_set_comm_buffers(self.ctx, p(b["gram"]), p(b["q_send"]), p(b["q_recv"]),
+                                                       p(b["v_send"]), p(b["v_recv"])))
+            self._comm = b
+        return self._comm
+
+    def begin(self, U, V, gamma, delta, tradeoff=None):
+        self._check_factors(U, V)
+        self._bound = (U, V)      # keep the tensors alive while the library holds their pointers
+        t = -1.0 if tradeoff is None else float(tradeoff)
+        self._check(self.lib.prmf_begin(self.ctx, C.c_void_p(U.data_ptr()), C.c_void_p(V.data_ptr()),
+                                        float(gamma), float(delta), t, self._stream()))
+
+    def phase_u(self):
+        self._check(self.lib.prmf_phase_u(self.ctx, self._stream()))
+
+    def phase_q(self):
+        self._check(self.lib.prmf_phase_q(self.ctx, self._stream()))
+
+    def phase_v(self):
+        self._check(self.lib.prmf_phase_v(self.ctx, self._stream()))
+
+    def phase_post(self):
+        self._check(self.lib.prmf_phase_post(self.ctx, self._stream()))
+
+    def end(self, n_steps):
+        obj = np.zeros((max(n_steps, 1), _capi.PRMF_OBJ_STRIDE))
+        gd = np.zeros(2)
+        rc = self.lib.prmf_end(self.ctx, int(n_steps), _ptr(obj), _ptr(gd), self._stream())
+        if rc == _capi.PRMF_ERR_NUMERIC:
+            raise FloatingPointError(self.lib.prmf_last_error(self.ctx).decode())
+        self._check(rc)
+        return self.records_to_dicts(obj[:n_steps]), (float(gd[0]), float(gd[1]))
+
     def score_candidates(self, V):
         """k x P matrix of restrict's match scores (prmf_runner.py:115-127)."""
         out = np.zeros((self.k, self.library.P))
@@ -169,6 +219,9 @@ class PrmfEngine(object):
         info = _capi.SweepInfo()
         self._check(self.lib.prmf_get_sweep_info(self.ctx, C.byref(info)))
         return info
+
+    def set_timing(self, enabled):
+        self._check(self.lib.prmf_set_timing(self.ctx, 1 if enabled else 0))
 
     def timing(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()

@@ -148,13 +148,5 @@ def bench_x_rows(seed, m, n, k, row0, row1):
 
 
 def tree_pathways(n, P, order, seed):
-    """P random recursive trees on `order` distinct genes (after
-    script/gen_sim.py:17-51), unit weights.  Returns [(edges, weights, nodes)]."""
-    rs = np.random.RandomState([seed, 104729])
-    out = []
-    for _ in range(P):
-        nodes = rs.choice(n, size=order, replace=False)
-        parent = (rs.rand(order - 1) * np.arange(1, order)).astype(np.int64)
-        edges = np.stack([nodes[1:], nodes[parent]], axis=1)
-        out.append((edges, np.ones(len(edges)), nodes))
-    return out
+    from prmf_amd.synthetic import tree_pathways as _tp
+    return _tp(n, P, order, seed)
