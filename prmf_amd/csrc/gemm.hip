@@ -32,6 +32,7 @@ namespace prmf {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native 128-bit value (asm "v" operand)
 
 __device__ __forceinline__ unsigned short f2bf_bits(float f) {
   return __builtin_bit_cast(unsigned short, (__bf16)f);
@@ -107,29 +108,149 @@ hipError_t launch_pack_factor(const FactorView& f, int x_dtype, int NT, int64_t 
 // ---------------------------------------------------------------------------
 // BF16 = true : A bf16, B hi/lo bf16, 2 MFMA (32x32x16) per fragment pair
 // BF16 = false: A f32,  B f32,        MFMA 32x32x2 f32 (exact f32 products)
-template <bool BF16, int MT, int NT, int PF>
+template <bool BF16, int MT, int NT>
+__device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], const u32x4 (&cur)[MT][4], const u32x4* __restrict__ sb,
+                                              int lane) {
+  if constexpr (BF16) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const u32x4 bh = sb[((s4 * NT + t) * 2 + 0) * 64 + lane];
+        const u32x4 bl = sb[((s4 * NT + t) * 2 + 1) * 64 + lane];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, cur[mt][s4]), __builtin_bit_cast(bf16x8, bh), acc[mt][t], 0, 0, 0);
+          acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, cur[mt][s4]), __builtin_bit_cast(bf16x8, bl), acc[mt][t], 0, 0, 0);
+        }
+      }
+    }
+  } else {
+    // f32: piece s4 of the chunk = floats [8 s4 + 4 h, +4) of the row = 8-row group s4 of B
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const u32x4 bv = sb[(s4 * NT + t) * 64 + lane];
+        const float b4[4] = {__uint_as_float(bv.x), __uint_as_float(bv.y), __uint_as_float(bv.z), __uint_as_float(bv.w)};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const u32x4 av = cur[mt][s4];
+          const float a4[4] = {__uint_as_float(av.x), __uint_as_float(av.y), __uint_as_float(av.z), __uint_as_float(av.w)};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[q], acc[mt][t], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// ---- hand-issued global loads --------------------------------------------------
+// hipcc sinks ordinary loads to their first use and waits for the newest load
+// whenever an older one is needed, which drains the whole prefetch queue at every
+// chunk.  The sweep therefore issues its global loads itself (volatile asm keeps
+// program order: B of the next chunk first, then the A prefetch) and retires them
+// with counted s_waitcnt vmcnt(N): vmcnt completes in order, so "all but the N
+// youngest" is exactly "B landed, A prefetch still in flight".  Every destination
+// register is named "+v" in the wait statement that covers it, so no consumer can
+// be scheduled above that wait (cdna_hip_programming.md 5.7, form (ii)).
+//   address = SGPR base (uniform: kernel args + blockIdx) + 32-bit lane offset + imm
+template <int OFF>
+__device__ __forceinline__ void gload16(u32x4& dst, unsigned voff, const void* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF));
+}
+
+template <int N, int NB, int MT>
+__device__ __forceinline__ void wait_vm(u32x4 (&b)[NB], u32x4 (&a)[MT][4]) {
+  static_assert(NB == 1 || NB == 2 || NB == 3 || NB == 4 || NB == 6 || NB == 8, "unsupported B staging width");
+  static_assert(MT == 1 || MT == 2, "unsupported MT");
+  // clang-format off
+#define PRMF_B1 "+v"(b[0])
+#define PRMF_B2 PRMF_B1, "+v"(b[1])
+#define PRMF_B3 PRMF_B2, "+v"(b[2])
+#define PRMF_B4 PRMF_B3, "+v"(b[3])
+#define PRMF_B6 PRMF_B4, "+v"(b[4]), "+v"(b[5])
+#define PRMF_B8 PRMF_B6, "+v"(b[6]), "+v"(b[7])
+#define PRMF_A1 "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3])
+#define PRMF_A2 PRMF_A1, "+v"(a[MT - 1][0]), "+v"(a[MT - 1][1]), "+v"(a[MT - 1][2]), "+v"(a[MT - 1][3])
+#define PRMF_WAIT(BL, AL) asm volatile("s_waitcnt vmcnt(%c[n])" : BL, AL : [n] "n"(N))
+  if constexpr (MT == 1) {
+    if constexpr (NB == 1) PRMF_WAIT(PRMF_B1, PRMF_A1); else if constexpr (NB == 2) PRMF_WAIT(PRMF_B2, PRMF_A1);
+    else if constexpr (NB == 3) PRMF_WAIT(PRMF_B3, PRMF_A1); else if constexpr (NB == 4) PRMF_WAIT(PRMF_B4, PRMF_A1);
+    else if constexpr (NB == 6) PRMF_WAIT(PRMF_B6, PRMF_A1); else PRMF_WAIT(PRMF_B8, PRMF_A1);
+  } else {
+    if constexpr (NB == 1) PRMF_WAIT(PRMF_B1, PRMF_A2); else if constexpr (NB == 2) PRMF_WAIT(PRMF_B2, PRMF_A2);
+    else if constexpr (NB == 3) PRMF_WAIT(PRMF_B3, PRMF_A2); else if constexpr (NB == 4) PRMF_WAIT(PRMF_B4, PRMF_A2);
+    else if constexpr (NB == 6) PRMF_WAIT(PRMF_B6, PRMF_A2); else PRMF_WAIT(PRMF_B8, PRMF_A2);
+  }
+#undef PRMF_WAIT
+  // clang-format on
+}
+
+template <int MT>
+__device__ __forceinline__ void load_a_chunk(u32x4 (&dst)[MT][4], const unsigned (&voff)[MT], const uint4* sbase) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    gload16<0>(dst[mt][0], voff[mt], sbase);
+    gload16<32>(dst[mt][1], voff[mt], sbase);
+    gload16<64>(dst[mt][2], voff[mt], sbase);
+    gload16<96>(dst[mt][3], voff[mt], sbase);
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void load_b_chunk(u32x4 (&dst)[NB], unsigned voff, const uint4* sbase) {
+  // thread tid takes uint4 #tid of every 4 KiB slice of the packed chunk
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    if (i % 4 == 0) gload16<0>(dst[i], voff, sbase + 256 * i);      // immediates reach +-4 KiB only
+    else if (i % 4 == 1) gload16<0>(dst[i], voff, sbase + 256 * i);
+    else if (i % 4 == 2) gload16<0>(dst[i], voff, sbase + 256 * i);
+    else gload16<0>(dst[i], voff, sbase + 256 * i);
+  }
+}
+
+// The reduction is padded on the host to a multiple of NSET = 3 chunks and every
+// split gets a multiple of 3 chunks, so the register ring (3 A-fragment sets: one
+// being multiplied, two in flight) is rotated by a fully unrolled, branch-free body.
+// Per chunk c (ring slot u = c mod 3):
+//     issue   B(c+1) -> bs,   A(c+2) -> a[u+2]        (indices clamped to the last chunk)
+//     compute chunk c from a[u] and LDS buffer c&1
+//     wait    vmcnt(4 MT): B(c+1) and everything older (A(c+1)) have landed
+//     write   bs -> LDS buffer (c+1)&1 ; barrier
+template <bool BF16, int MT, int NT>
 __global__ void __launch_bounds__(256, 2)
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
-             const uint4* __restrict__ Bp, int nchunks, int chunks_per_split,
+             const uint4* __restrict__ Bp, int ngroups /* total chunks / 3 */, int nsplits,
              float* __restrict__ slabs, int64_t slab_stride) {
   constexpr int KP = 32 * NT;
   constexpr int BCH = BF16 ? 512 * NT : 256 * NT;   // uint4 per packed chunk
   constexpr int BPT = BCH / 256;                    // uint4 staged per thread per chunk
-  constexpr int NSET = PF + 1;
-  __shared__ uint4 sB[2][BCH];
+  constexpr int NSET = SWEEP_NSET;
+  static_assert(NSET == 3, "ring rotation below is written for 3 sets");
+  __shared__ u32x4 sB[2][BCH];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int split = blockIdx.y;
-  const int c0 = split * chunks_per_split;
-  const int nch = min(nchunks - c0, chunks_per_split);
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * (32 * MT);
+  const int gbase = ngroups / nsplits, grem = ngroups % nsplits;
+  const int c0 = NSET * (split * gbase + min(split, grem));
+  const int nch = NSET * (gbase + (split < grem ? 1 : 0));
+  const int last = nch - 1;
+  const int64_t prow0 = (int64_t)blockIdx.x * (128 * MT);          // first row of this workgroup's panel
+  const int64_t row0 = prow0 + wave * (32 * MT);                    // first row of this wave
 
-  // lane (r,h) reads 16 B at byte 32*s + 16*h of its row's 128-B chunk piece, s = 0..3
-  const uint4* ap[MT];
+  // uniform bases (SGPR) + per-lane byte offsets (VGPR, < 128*MT rows * row bytes)
+  const uint4* abase = A + prow0 * lda16 + (int64_t)c0 * 8;         // chunk = 8 x 16 B of each row
+  const uint4* bbase = Bp + (int64_t)c0 * BCH;
+  unsigned avoff[MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) ap[mt] = A + (row0 + 32 * mt + r) * lda16 + (int64_t)c0 * 8 + h;
-  const uint4* bp = Bp + (int64_t)c0 * BCH + tid;
+  for (int mt = 0; mt < MT; ++mt)
+    avoff[mt] = (unsigned)(((int64_t)(wave * (32 * MT) + 32 * mt + r) * lda16 + h) * 16);
+  const unsigned bvoff = (unsigned)tid * 16u;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -139,67 +260,16 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mt][t][i] = 0.f;
 
-  uint4 a[NSET][MT][4];
-  uint4 bs[BPT];
+  u32x4 a[NSET][MT][4];
+  u32x4 bs[BPT];
 
-  auto load_a = [&](uint4 (&dst)[MT][4], int chunk) {
+  // prologue: B(0), A(0), A(1)
+  load_b_chunk<BPT>(bs, bvoff, bbase);
+  load_a_chunk<MT>(a[0], avoff, abase);
+  load_a_chunk<MT>(a[1], avoff, abase + (int64_t)min(1, last) * 8);
+  wait_vm<4 * MT, BPT, MT>(bs, a[0]);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) dst[mt][s4] = ap[mt][(int64_t)chunk * 8 + 2 * s4];
-  };
-  auto load_b = [&](int chunk) {
-#pragma unroll
-    for (int i = 0; i < BPT; ++i) bs[i] = bp[(int64_t)chunk * BCH + 256 * i];
-  };
-  auto store_b = [&](uint4* dst) {
-#pragma unroll
-    for (int i = 0; i < BPT; ++i) dst[tid + 256 * i] = bs[i];
-  };
-  auto compute = [&](const uint4 (&cur)[MT][4], const uint4* sb) {
-    if constexpr (BF16) {
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const uint4 bh = sb[((s4 * NT + t) * 2 + 0) * 64 + lane];
-          const uint4 bl = sb[((s4 * NT + t) * 2 + 1) * 64 + lane];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8, cur[mt][s4]), __builtin_bit_cast(bf16x8, bh), acc[mt][t], 0, 0, 0);
-            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8, cur[mt][s4]), __builtin_bit_cast(bf16x8, bl), acc[mt][t], 0, 0, 0);
-          }
-        }
-      }
-    } else {
-      // f32: piece s4 of the chunk = floats [8 s4 + 4 h, +4) of the row = group g = s4
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const uint4 bv = sb[(s4 * NT + t) * 64 + lane];
-          const float b4[4] = {__uint_as_float(bv.x), __uint_as_float(bv.y), __uint_as_float(bv.z), __uint_as_float(bv.w)};
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const uint4 av = cur[mt][s4];
-            const float a4[4] = {__uint_as_float(av.x), __uint_as_float(av.y), __uint_as_float(av.z), __uint_as_float(av.w)};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[q], acc[mt][t], 0, 0, 0);
-          }
-        }
-      }
-    }
-  };
-
-  // prologue: B chunk 0 -> LDS, A chunks 0..PF-1 -> registers
-  load_b(0);
-#pragma unroll
-  for (int p = 0; p < PF; ++p)
-    if (p < nch) load_a(a[p], p);
-  store_b(sB[0]);
+  for (int i = 0; i < BPT; ++i) sB[0][tid + 256 * i] = bs[i];
   __syncthreads();
 
   int cur_b = 0;
@@ -207,19 +277,18 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 #pragma unroll
     for (int u = 0; u < NSET; ++u) {
       const int cc = c + u;
-      if (cc < nch) {
-        const bool has_next = cc + 1 < nch;
-        // B for chunk cc+1 first (it is waited for at the end of this step, and
-        // vmcnt retires in order), then the A prefetch PF chunks ahead.
-        if (has_next) load_b(cc + 1);
-        if (cc + PF < nch) load_a(a[(u + PF) % NSET], cc + PF);
-        compute(a[u], sB[cur_b]);
-        if (has_next) store_b(sB[cur_b ^ 1]);
-        __syncthreads();
-        cur_b ^= 1;
-      }
+      load_b_chunk<BPT>(bs, bvoff, bbase + (int64_t)min(cc + 1, last) * BCH);
+      load_a_chunk<MT>(a[(u + 2) % NSET], avoff, abase + (int64_t)min(cc + 2, last) * 8);
+      sweep_compute<BF16, MT, NT>(acc, a[u], sB[cur_b], lane);
+      wait_vm<4 * MT, BPT, MT>(bs, a[(u + 1) % NSET]);
+#pragma unroll
+      for (int i = 0; i < BPT; ++i) sB[cur_b ^ 1][tid + 256 * i] = bs[i];
+      __syncthreads();
+      cur_b ^= 1;
     }
   }
+  // the clamped prefetches of the last two steps are still in flight
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*h
   float* out = slabs + (int64_t)split * slab_stride;
@@ -240,28 +309,30 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int force_split
   p.MT = 1;
   const int rows_wg = 4 * 32 * p.MT;
   p.panels = (int)(round_up(M, rows_wg) / rows_wg);
-  p.nchunks = (int)(Kpad / chunk_elems(x_dtype));
-  // enough workgroups to keep 256 CUs x (2..4 resident workgroups) streaming; at
-  // least 8 chunks per split so the prologue/epilogue stay small.
+  p.nchunks = (int)(Kpad / chunk_elems(x_dtype));          // multiple of SWEEP_NSET (K_PAD)
+  const int ngroups = p.nchunks / SWEEP_NSET;
+  // enough workgroups to keep 256 CUs x (2..4 resident workgroups) streaming, but
+  // at least 4 ring rotations (12 chunks) per split so prologue/epilogue stay small
   int target_wgs = 256 * 4;
   int splits = force_splits > 0 ? force_splits : (target_wgs + p.panels - 1) / p.panels;
-  int max_splits = p.nchunks / 8 > 0 ? p.nchunks / 8 : 1;
+  int max_splits = ngroups / 4 > 0 ? ngroups / 4 : 1;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   if (splits > 64) splits = 64;
-  p.chunks_per_split = (p.nchunks + splits - 1) / splits;
-  p.splits = (p.nchunks + p.chunks_per_split - 1) / p.chunks_per_split;
+  p.splits = splits;
+  p.chunks_per_split = SWEEP_NSET * ((ngroups + splits - 1) / splits);
   (void)NT;
   return p;
 }
 
-template <bool BF16, int MT, int PF>
+template <bool BF16, int MT>
 static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda16, int64_t M_store, const void* Bp,
                                   int NT, float* slabs, int64_t slab_stride, hipStream_t s) {
   dim3 grid(p.panels, p.splits), block(256);
-#define PRMF_LAUNCH(NTV)                                                                                   \
-  sweep_kernel<BF16, MT, NTV, PF><<<grid, block, 0, s>>>((const uint4*)A, lda16, M_store, (const uint4*)Bp, \
-                                                         p.nchunks, p.chunks_per_split, slabs, slab_stride)
+  const int ngroups = p.nchunks / SWEEP_NSET;
+#define PRMF_LAUNCH(NTV)                                                                               \
+  sweep_kernel<BF16, MT, NTV><<<grid, block, 0, s>>>((const uint4*)A, lda16, M_store, (const uint4*)Bp, \
+                                                     ngroups, p.splits, slabs, slab_stride)
   switch (NT) {
     case 1: PRMF_LAUNCH(1); break;
     case 2: PRMF_LAUNCH(2); break;
@@ -276,8 +347,8 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
                        const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s) {
   const int64_t lda16 = lda * elem_bytes(x_dtype) / 16;
-  if (x_dtype == 1) return launch_sweep_nt<true, 1, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
-  return launch_sweep_nt<false, 1, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
+  if (x_dtype == 1) return launch_sweep_nt<true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
+  return launch_sweep_nt<false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
 }
 
 // ---------------------------------------------------------------------------
