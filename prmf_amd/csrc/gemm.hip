@@ -28,6 +28,8 @@
 // between waves: no LDS round trip), PF chunks ahead of the MFMAs.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace prmf {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -108,40 +110,50 @@ hipError_t launch_pack_factor(const FactorView& f, int x_dtype, int NT, int64_t 
 // ---------------------------------------------------------------------------
 // BF16 = true : A bf16, B hi/lo bf16, 2 MFMA (32x32x16) per fragment pair
 // BF16 = false: A f32,  B f32,        MFMA 32x32x2 f32 (exact f32 products)
+//
+// A path.  The MFMA A fragment of lane (r = lane&31, h = lane>>5) is 16 B of row
+// r, i.e. a wave-wide fragment load touches 32 different 128-B lines with 32 B
+// each -- measured 22% slower than line-complete loads (texture-address bound).
+// So A is loaded line-complete (one instruction = 8 rows x 128 B, lane l -> row
+// l>>3, 16-B piece l&7), PF chunks ahead into registers, then bounced through a
+// wave-private 4 KiB LDS tile from which the fragments are read with ds_read_b128.
+// The tile is XOR-swizzled on the SOURCE side (LDS image linear per instruction):
+//   LDS slot (16-B units) of (row r, piece q) = 8 r + (q ^ ((r >> 1) & 7))
+// which makes every 16-lane group of the fragment read hit 16 distinct 16-B slots
+// of the 256-B bank row (rows of equal parity in a group differ in (r>>1)&7).
+// No barrier is needed for A: a wave only reads what it wrote, and the LDS
+// executes one wave's instructions in order.
 template <bool BF16, int MT, int NT>
-__device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], const u32x4 (&cur)[MT][4], const u32x4* __restrict__ sb,
-                                              int lane) {
-  if constexpr (BF16) {
+__device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], const u32x4* __restrict__ sa,
+                                              const u32x4* __restrict__ sb, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int swz = (r >> 1) & 7;
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
+  for (int s4 = 0; s4 < 4; ++s4) {
+    u32x4 av[MT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
+    for (int mt = 0; mt < MT; ++mt) av[mt] = sa[mt * 256 + r * 8 + ((2 * s4 + h) ^ swz)];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if constexpr (BF16) {
         const u32x4 bh = sb[((s4 * NT + t) * 2 + 0) * 64 + lane];
         const u32x4 bl = sb[((s4 * NT + t) * 2 + 1) * 64 + lane];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, cur[mt][s4]), __builtin_bit_cast(bf16x8, bh), acc[mt][t], 0, 0, 0);
+              __builtin_bit_cast(bf16x8, av[mt]), __builtin_bit_cast(bf16x8, bh), acc[mt][t], 0, 0, 0);
           acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, cur[mt][s4]), __builtin_bit_cast(bf16x8, bl), acc[mt][t], 0, 0, 0);
+              __builtin_bit_cast(bf16x8, av[mt]), __builtin_bit_cast(bf16x8, bl), acc[mt][t], 0, 0, 0);
         }
-      }
-    }
-  } else {
-    // f32: piece s4 of the chunk = floats [8 s4 + 4 h, +4) of the row = 8-row group s4 of B
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
+      } else {
+        // f32: piece 2 s4 + h of the row = floats [8 s4 + 4 h, +4) = 8-row group s4 of B
         const u32x4 bv = sb[(s4 * NT + t) * 64 + lane];
-        const float b4[4] = {__uint_as_float(bv.x), __uint_as_float(bv.y), __uint_as_float(bv.z), __uint_as_float(bv.w)};
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const u32x4 av = cur[mt][s4];
-          const float a4[4] = {__uint_as_float(av.x), __uint_as_float(av.y), __uint_as_float(av.z), __uint_as_float(av.w)};
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[q], acc[mt][t], 0, 0, 0);
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av[mt][q]), __uint_as_float(bv[q]),
+                                                              acc[mt][t], 0, 0, 0);
         }
       }
     }
@@ -154,13 +166,12 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], const u32x4
 // chunk.  The sweep therefore issues its global loads itself (volatile asm keeps
 // program order: B of the next chunk first, then the A prefetch) and retires them
 // with counted s_waitcnt vmcnt(N): vmcnt completes in order, so "all but the N
-// youngest" is exactly "B landed, A prefetch still in flight".  Every destination
-// register is named "+v" in the wait statement that covers it, so no consumer can
-// be scheduled above that wait (cdna_hip_programming.md 5.7, form (ii)).
-//   address = SGPR base (uniform: kernel args + blockIdx) + 32-bit lane offset + imm
-template <int OFF>
+// youngest" is exactly "B and the older A landed, newest A prefetch in flight".
+// Every destination register is named "+v" in the wait statement that covers it,
+// so no consumer can be scheduled above that wait (cdna_hip_programming.md 5.7,
+// form (ii)).   address = SGPR base (uniform) + 32-bit lane offset
 __device__ __forceinline__ void gload16(u32x4& dst, unsigned voff, const void* sbase) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF));
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase));
 }
 
 template <int N, int NB, int MT>
@@ -191,47 +202,40 @@ __device__ __forceinline__ void wait_vm(u32x4 (&b)[NB], u32x4 (&a)[MT][4]) {
 }
 
 template <int MT>
-__device__ __forceinline__ void load_a_chunk(u32x4 (&dst)[MT][4], const unsigned (&voff)[MT], const uint4* sbase) {
+__device__ __forceinline__ void load_a_chunk(u32x4 (&dst)[MT][4], const unsigned (&voff)[MT][4], const uint4* sbase) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    gload16<0>(dst[mt][0], voff[mt], sbase);
-    gload16<32>(dst[mt][1], voff[mt], sbase);
-    gload16<64>(dst[mt][2], voff[mt], sbase);
-    gload16<96>(dst[mt][3], voff[mt], sbase);
-  }
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gload16(dst[mt][i], voff[mt][i], sbase);
 }
 
 template <int NB>
 __device__ __forceinline__ void load_b_chunk(u32x4 (&dst)[NB], unsigned voff, const uint4* sbase) {
   // thread tid takes uint4 #tid of every 4 KiB slice of the packed chunk
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    if (i % 4 == 0) gload16<0>(dst[i], voff, sbase + 256 * i);      // immediates reach +-4 KiB only
-    else if (i % 4 == 1) gload16<0>(dst[i], voff, sbase + 256 * i);
-    else if (i % 4 == 2) gload16<0>(dst[i], voff, sbase + 256 * i);
-    else gload16<0>(dst[i], voff, sbase + 256 * i);
-  }
+  for (int i = 0; i < NB; ++i) gload16(dst[i], voff, sbase + 256 * i);
 }
 
-// The reduction is padded on the host to a multiple of NSET = 3 chunks and every
-// split gets a multiple of 3 chunks, so the register ring (3 A-fragment sets: one
-// being multiplied, two in flight) is rotated by a fully unrolled, branch-free body.
-// Per chunk c (ring slot u = c mod 3):
-//     issue   B(c+1) -> bs,   A(c+2) -> a[u+2]        (indices clamped to the last chunk)
-//     compute chunk c from a[u] and LDS buffer c&1
-//     wait    vmcnt(4 MT): B(c+1) and everything older (A(c+1)) have landed
-//     write   bs -> LDS buffer (c+1)&1 ; barrier
+// The reduction is padded on the host to a multiple of SWEEP_NSET = 2 chunks and
+// every split gets a multiple of 2 chunks, so the two A register sets are rotated
+// by a fully unrolled, branch-free body.  Per chunk c (register set u = c & 1):
+//     issue   B(c+1) -> bs,  A(c+2) -> a[u]        (indices clamped to the last chunk;
+//                                                  a[u] held A(c), already in LDS)
+//     compute chunk c: A fragments from the wave's LDS tile, B from LDS buffer c&1
+//     wait    vmcnt(4 MT): B(c+1) and the older A(c+1) (in a[u^1]) have landed
+//     write   bs -> LDS buffer (c+1)&1 ; a[u^1] -> the wave's A tile ; barrier
 template <bool BF16, int MT, int NT>
 __global__ void __launch_bounds__(256, 2)
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
-             const uint4* __restrict__ Bp, int ngroups /* total chunks / 3 */, int nsplits,
+             const uint4* __restrict__ Bp, int ngroups /* total chunks / 2 */, int nsplits,
              float* __restrict__ slabs, int64_t slab_stride) {
   constexpr int KP = 32 * NT;
   constexpr int BCH = BF16 ? 512 * NT : 256 * NT;   // uint4 per packed chunk
   constexpr int BPT = BCH / 256;                    // uint4 staged per thread per chunk
   constexpr int NSET = SWEEP_NSET;
-  static_assert(NSET == 3, "ring rotation below is written for 3 sets");
+  static_assert(NSET == 2, "ring rotation below is written for 2 sets");
   __shared__ u32x4 sB[2][BCH];
+  __shared__ u32x4 sA[4][MT * 256];                 // per wave: MT tiles of 32 rows x 128 B
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -246,11 +250,17 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   // uniform bases (SGPR) + per-lane byte offsets (VGPR, < 128*MT rows * row bytes)
   const uint4* abase = A + prow0 * lda16 + (int64_t)c0 * 8;         // chunk = 8 x 16 B of each row
   const uint4* bbase = Bp + (int64_t)c0 * BCH;
-  unsigned avoff[MT];
+  unsigned avoff[MT][4];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
-    avoff[mt] = (unsigned)(((int64_t)(wave * (32 * MT) + 32 * mt + r) * lda16 + h) * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lr = 8 * i + (lane >> 3);                           // row within the 32-row tile
+      const int piece = (lane & 7) ^ ((lr >> 1) & 7);               // source-side swizzle
+      avoff[mt][i] = (unsigned)(((int64_t)(wave * (32 * MT) + 32 * mt + lr) * lda16 + piece) * 16);
+    }
   const unsigned bvoff = (unsigned)tid * 16u;
+  u32x4* const myA = sA[wave];
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -263,13 +273,17 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   u32x4 a[NSET][MT][4];
   u32x4 bs[BPT];
 
-  // prologue: B(0), A(0), A(1)
+  // prologue: B(0), A(0) -> LDS ; A(1) in flight in a[1]
   load_b_chunk<BPT>(bs, bvoff, bbase);
   load_a_chunk<MT>(a[0], avoff, abase);
   load_a_chunk<MT>(a[1], avoff, abase + (int64_t)min(1, last) * 8);
   wait_vm<4 * MT, BPT, MT>(bs, a[0]);
 #pragma unroll
   for (int i = 0; i < BPT; ++i) sB[0][tid + 256 * i] = bs[i];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) myA[mt * 256 + i * 64 + lane] = a[0][mt][i];
   __syncthreads();
 
   int cur_b = 0;
@@ -278,16 +292,20 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
     for (int u = 0; u < NSET; ++u) {
       const int cc = c + u;
       load_b_chunk<BPT>(bs, bvoff, bbase + (int64_t)min(cc + 1, last) * BCH);
-      load_a_chunk<MT>(a[(u + 2) % NSET], avoff, abase + (int64_t)min(cc + 2, last) * 8);
-      sweep_compute<BF16, MT, NT>(acc, a[u], sB[cur_b], lane);
-      wait_vm<4 * MT, BPT, MT>(bs, a[(u + 1) % NSET]);
+      load_a_chunk<MT>(a[u], avoff, abase + (int64_t)min(cc + 2, last) * 8);
+      sweep_compute<BF16, MT, NT>(acc, myA, sB[cur_b], lane);
+      wait_vm<4 * MT, BPT, MT>(bs, a[u ^ 1]);
 #pragma unroll
       for (int i = 0; i < BPT; ++i) sB[cur_b ^ 1][tid + 256 * i] = bs[i];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) myA[mt * 256 + i * 64 + lane] = a[u ^ 1][mt][i];
       __syncthreads();
       cur_b ^= 1;
     }
   }
-  // the clamped prefetches of the last two steps are still in flight
+  // the clamped prefetch of the last step is still in flight
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*h
@@ -314,6 +332,7 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int force_split
   // enough workgroups to keep 256 CUs x (2..4 resident workgroups) streaming, but
   // at least 4 ring rotations (12 chunks) per split so prologue/epilogue stay small
   int target_wgs = 256 * 4;
+  if (force_splits <= 0 && getenv("PRMF_SWEEP_SPLITS")) force_splits = atoi(getenv("PRMF_SWEEP_SPLITS"));
   int splits = force_splits > 0 ? force_splits : (target_wgs + p.panels - 1) / p.panels;
   int max_splits = ngroups / 4 > 0 ? ngroups / 4 : 1;
   if (splits > max_splits) splits = max_splits;
