@@ -161,21 +161,24 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], const u32x4
 }
 
 // ---- hand-issued global loads --------------------------------------------------
-// hipcc sinks ordinary loads to their first use and waits for the newest load
-// whenever an older one is needed, which drains the whole prefetch queue at every
-// chunk.  The sweep therefore issues its global loads itself (volatile asm keeps
-// program order: B of the next chunk first, then the A prefetch) and retires them
-// with counted s_waitcnt vmcnt(N): vmcnt completes in order, so "all but the N
-// youngest" is exactly "B and the older A landed, newest A prefetch in flight".
-// Every destination register is named "+v" in the wait statement that covers it,
-// so no consumer can be scheduled above that wait (cdna_hip_programming.md 5.7,
-// form (ii)).   address = SGPR base (uniform) + 32-bit lane offset
+// hipcc sinks ordinary loads to their first use (right in front of the ds_write
+// that consumes them), which serialises load latency and compute.  The sweep
+// therefore issues its global loads itself, at the top of each step (volatile asm
+// keeps them there), and retires them with one s_waitcnt vmcnt(0) after the MFMAs
+// of the step.  A counted vmcnt(N) that leaves the newest loads in flight was
+// measured UNSAFE here: global_load completion is not strictly in issue order on
+// gfx950 (about 1e-5 of the wave-steps saw an older A load still outstanding with
+// only the N youngest pending -> a wrong 32-row tile per launch), so the design
+// does not rely on completion order; latency is covered by occupancy instead.
+// Every destination register is named "+v" in the wait statement, so no consumer
+// can be scheduled above it (cdna_hip_programming.md 5.7, form (ii)).
+//   address = SGPR base (uniform) + 32-bit lane offset
 __device__ __forceinline__ void gload16(u32x4& dst, unsigned voff, const void* sbase) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase));
 }
 
-template <int N, int NB, int MT>
-__device__ __forceinline__ void wait_vm(u32x4 (&b)[NB], u32x4 (&a)[MT][4]) {
+template <int NB, int MT>
+__device__ __forceinline__ void wait_all_loads(u32x4 (&b)[NB], u32x4 (&a)[MT][4]) {
   static_assert(NB == 1 || NB == 2 || NB == 3 || NB == 4 || NB == 6 || NB == 8, "unsupported B staging width");
   static_assert(MT == 1 || MT == 2, "unsupported MT");
   // clang-format off
@@ -187,7 +190,7 @@ __device__ __forceinline__ void wait_vm(u32x4 (&b)[NB], u32x4 (&a)[MT][4]) {
 #define PRMF_B8 PRMF_B6, "+v"(b[6]), "+v"(b[7])
 #define PRMF_A1 "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3])
 #define PRMF_A2 PRMF_A1, "+v"(a[MT - 1][0]), "+v"(a[MT - 1][1]), "+v"(a[MT - 1][2]), "+v"(a[MT - 1][3])
-#define PRMF_WAIT(BL, AL) asm volatile("s_waitcnt vmcnt(%c[n])" : BL, AL : [n] "n"(N))
+#define PRMF_WAIT(BL, AL) asm volatile("s_waitcnt vmcnt(0)" : BL, AL)
   if constexpr (MT == 1) {
     if constexpr (NB == 1) PRMF_WAIT(PRMF_B1, PRMF_A1); else if constexpr (NB == 2) PRMF_WAIT(PRMF_B2, PRMF_A1);
     else if constexpr (NB == 3) PRMF_WAIT(PRMF_B3, PRMF_A1); else if constexpr (NB == 4) PRMF_WAIT(PRMF_B4, PRMF_A1);
@@ -209,45 +212,58 @@ __device__ __forceinline__ void load_a_chunk(u32x4 (&dst)[MT][4], const unsigned
     for (int i = 0; i < 4; ++i) gload16(dst[mt][i], voff[mt][i], sbase);
 }
 
-template <int NB>
-__device__ __forceinline__ void load_b_chunk(u32x4 (&dst)[NB], unsigned voff, const uint4* sbase) {
-  // thread tid takes uint4 #tid of every 4 KiB slice of the packed chunk
+template <int NB, int NTHREADS, int BCH>
+__device__ __forceinline__ void load_b_chunk(u32x4 (&dst)[NB], unsigned voff, const uint4* sbase, int tid) {
+  // thread tid takes uint4 #tid of every NTHREADS*16-byte slice of the packed chunk
 #pragma unroll
-  for (int i = 0; i < NB; ++i) gload16(dst[i], voff, sbase + 256 * i);
+  for (int i = 0; i < NB; ++i) {
+    if ((i + 1) * NTHREADS <= BCH || tid + NTHREADS * i < BCH) gload16(dst[i], voff, sbase + NTHREADS * i);
+  }
 }
 
-// The reduction is padded on the host to a multiple of SWEEP_NSET = 2 chunks and
-// every split gets a multiple of 2 chunks, so the two A register sets are rotated
-// by a fully unrolled, branch-free body.  Per chunk c (register set u = c & 1):
-//     issue   B(c+1) -> bs,  A(c+2) -> a[u]        (indices clamped to the last chunk;
-//                                                  a[u] held A(c), already in LDS)
-//     compute chunk c: A fragments from the wave's LDS tile, B from LDS buffer c&1
-//     wait    vmcnt(4 MT): B(c+1) and the older A(c+1) (in a[u^1]) have landed
-//     write   bs -> LDS buffer (c+1)&1 ; a[u^1] -> the wave's A tile ; barrier
-template <bool BF16, int MT, int NT>
-__global__ void __launch_bounds__(256, 2)
+template <int NB, int NTHREADS, int BCH>
+__device__ __forceinline__ void store_b_chunk(u32x4* sb, const u32x4 (&src)[NB], int tid) {
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    if ((i + 1) * NTHREADS <= BCH || tid + NTHREADS * i < BCH) sb[tid + NTHREADS * i] = src[i];
+  }
+}
+
+// One workgroup = NW waves x MT 32-row tiles (a panel of 32*MT*NW rows) and one
+// contiguous range of reduction chunks (a "split").  Per chunk c:
+//     issue   B(c+1) -> bs,  A(c+1) -> a      (clamped to the split's last chunk)
+//     compute chunk c: A fragments from the wave's LDS tile, B from LDS
+//     wait    vmcnt(0)
+//     write   bs -> LDS (other buffer if BDB, else after a barrier) ; a -> the wave's A tile
+//     barrier
+// BDB = true : B double-buffered in LDS, one barrier per chunk
+// BDB = false: B single-buffered, two barriers per chunk, 16*NT KiB less LDS per
+//              workgroup -> more resident workgroups (bytes in flight) per CU
+// The host pads the reduction to an even number of chunks and gives every split an
+// even number, so the chunk loop is unrolled x2 with compile-time LDS buffer offsets.
+template <bool BF16, int MT, int NT, int NW, bool BDB, int DBG = 0>
+__global__ void __launch_bounds__(64 * NW)
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
              const uint4* __restrict__ Bp, int ngroups /* total chunks / 2 */, int nsplits,
              float* __restrict__ slabs, int64_t slab_stride) {
   constexpr int KP = 32 * NT;
+  constexpr int NTHR = 64 * NW;
   constexpr int BCH = BF16 ? 512 * NT : 256 * NT;   // uint4 per packed chunk
-  constexpr int BPT = BCH / 256;                    // uint4 staged per thread per chunk
-  constexpr int NSET = SWEEP_NSET;
-  static_assert(NSET == 2, "ring rotation below is written for 2 sets");
-  __shared__ u32x4 sB[2][BCH];
-  __shared__ u32x4 sA[4][MT * 256];                 // per wave: MT tiles of 32 rows x 128 B
+  constexpr int BPT = (BCH + NTHR - 1) / NTHR;      // uint4 staged per thread per chunk (last one may be partial)
+  __shared__ u32x4 sB[BDB ? 2 : 1][BCH];
+  __shared__ u32x4 sA[NW][MT * 256];                // per wave: MT tiles of 32 rows x 128 B
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int split = blockIdx.y;
   const int gbase = ngroups / nsplits, grem = ngroups % nsplits;
-  const int c0 = NSET * (split * gbase + min(split, grem));
-  const int nch = NSET * (gbase + (split < grem ? 1 : 0));
+  const int c0 = 2 * (split * gbase + min(split, grem));
+  const int nch = 2 * (gbase + (split < grem ? 1 : 0));
   const int last = nch - 1;
-  const int64_t prow0 = (int64_t)blockIdx.x * (128 * MT);          // first row of this workgroup's panel
+  const int64_t prow0 = (int64_t)blockIdx.x * (32 * MT * NW);      // first row of this workgroup's panel
   const int64_t row0 = prow0 + wave * (32 * MT);                    // first row of this wave
 
-  // uniform bases (SGPR) + per-lane byte offsets (VGPR, < 128*MT rows * row bytes)
+  // uniform bases (SGPR) + per-lane byte offsets (VGPR, < panel rows * row bytes)
   const uint4* abase = A + prow0 * lda16 + (int64_t)c0 * 8;         // chunk = 8 x 16 B of each row
   const uint4* bbase = Bp + (int64_t)c0 * BCH;
   unsigned avoff[MT][4];
@@ -270,43 +286,38 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mt][t][i] = 0.f;
 
-  u32x4 a[NSET][MT][4];
+  u32x4 a[MT][4];
   u32x4 bs[BPT];
 
-  // prologue: B(0), A(0) -> LDS ; A(1) in flight in a[1]
-  load_b_chunk<BPT>(bs, bvoff, bbase);
-  load_a_chunk<MT>(a[0], avoff, abase);
-  load_a_chunk<MT>(a[1], avoff, abase + (int64_t)min(1, last) * 8);
-  wait_vm<4 * MT, BPT, MT>(bs, a[0]);
-#pragma unroll
-  for (int i = 0; i < BPT; ++i) sB[0][tid + 256 * i] = bs[i];
+  // prologue: B(0), A(0) -> LDS
+  load_b_chunk<BPT, NTHR, BCH>(bs, bvoff, bbase, tid);
+  load_a_chunk<MT>(a, avoff, abase);
+  wait_all_loads<BPT, MT>(bs, a);
+  store_b_chunk<BPT, NTHR, BCH>(sB[0], bs, tid);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) myA[mt * 256 + i * 64 + lane] = a[0][mt][i];
+    for (int i = 0; i < 4; ++i) myA[mt * 256 + i * 64 + lane] = a[mt][i];
   __syncthreads();
 
-  int cur_b = 0;
-  for (int c = 0; c < nch; c += NSET) {
+  for (int c = 0; c < nch; c += 2) {
 #pragma unroll
-    for (int u = 0; u < NSET; ++u) {
-      const int cc = c + u;
-      load_b_chunk<BPT>(bs, bvoff, bbase + (int64_t)min(cc + 1, last) * BCH);
-      load_a_chunk<MT>(a[u], avoff, abase + (int64_t)min(cc + 2, last) * 8);
-      sweep_compute<BF16, MT, NT>(acc, myA, sB[cur_b], lane);
-      wait_vm<4 * MT, BPT, MT>(bs, a[u ^ 1]);
-#pragma unroll
-      for (int i = 0; i < BPT; ++i) sB[cur_b ^ 1][tid + 256 * i] = bs[i];
+    for (int u = 0; u < 2; ++u) {
+      const int cn = min(c + u + 1, last);
+      load_b_chunk<BPT, NTHR, BCH>(bs, bvoff, bbase + (int64_t)(DBG == 1 ? (cn & 1) : cn) * BCH, tid);
+      load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
+      if constexpr (DBG != 2) sweep_compute<BF16, MT, NT>(acc, myA, sB[BDB ? u : 0], lane);
+      else { acc[0][0][0] += __uint_as_float(myA[lane][0]) + __uint_as_float(sB[BDB ? u : 0][lane][0]); }
+      wait_all_loads<BPT, MT>(bs, a);
+      if constexpr (!BDB) __syncthreads();          // everyone has finished reading B(c)
+      store_b_chunk<BPT, NTHR, BCH>(sB[BDB ? (u ^ 1) : 0], bs, tid);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) myA[mt * 256 + i * 64 + lane] = a[u ^ 1][mt][i];
+        for (int i = 0; i < 4; ++i) myA[mt * 256 + i * 64 + lane] = a[mt][i];
       __syncthreads();
-      cur_b ^= 1;
     }
   }
-  // the clamped prefetch of the last step is still in flight
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*h
   float* out = slabs + (int64_t)split * slab_stride;
@@ -322,36 +333,53 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
     }
 }
 
+struct SweepVariant { int nw; bool bdb; };
+static SweepVariant sweep_variant() {
+  static const SweepVariant v = [] {
+    SweepVariant r{8, true};
+    if (const char* e = getenv("PRMF_SWEEP_NW")) r.nw = atoi(e) == 4 ? 4 : 8;
+    if (const char* e = getenv("PRMF_SWEEP_BDB")) r.bdb = atoi(e) != 0;
+    return r;
+  }();
+  return v;
+}
+
 GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int force_splits) {
   GemmPlan p;
   p.MT = 1;
-  const int rows_wg = 4 * 32 * p.MT;
+  const int rows_wg = sweep_variant().nw * 32 * p.MT;
   p.panels = (int)(round_up(M, rows_wg) / rows_wg);
-  p.nchunks = (int)(Kpad / chunk_elems(x_dtype));          // multiple of SWEEP_NSET (K_PAD)
-  const int ngroups = p.nchunks / SWEEP_NSET;
-  // enough workgroups to keep 256 CUs x (2..4 resident workgroups) streaming, but
-  // at least 4 ring rotations (12 chunks) per split so prologue/epilogue stay small
-  int target_wgs = 256 * 4;
+  p.nchunks = (int)(Kpad / chunk_elems(x_dtype));          // even (K_PAD)
+  const int ngroups = p.nchunks / 2;
+  // about two rounds of the 512 resident workgroups (2 per CU), but at least 8
+  // chunks per split so prologue/epilogue stay small
+  int target_wgs = 1100;
   if (force_splits <= 0 && getenv("PRMF_SWEEP_SPLITS")) force_splits = atoi(getenv("PRMF_SWEEP_SPLITS"));
-  int splits = force_splits > 0 ? force_splits : (target_wgs + p.panels - 1) / p.panels;
+  int splits = force_splits > 0 ? force_splits : (target_wgs + p.panels / 2) / p.panels;
   int max_splits = ngroups / 4 > 0 ? ngroups / 4 : 1;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   if (splits > 64) splits = 64;
   p.splits = splits;
-  p.chunks_per_split = SWEEP_NSET * ((ngroups + splits - 1) / splits);
+  p.chunks_per_split = 2 * ((ngroups + splits - 1) / splits);
   (void)NT;
   return p;
 }
 
-template <bool BF16, int MT>
+template <bool BF16, int NW, bool BDB>
 static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda16, int64_t M_store, const void* Bp,
                                   int NT, float* slabs, int64_t slab_stride, hipStream_t s) {
-  dim3 grid(p.panels, p.splits), block(256);
-  const int ngroups = p.nchunks / SWEEP_NSET;
-#define PRMF_LAUNCH(NTV)                                                                               \
-  sweep_kernel<BF16, MT, NTV><<<grid, block, 0, s>>>((const uint4*)A, lda16, M_store, (const uint4*)Bp, \
-                                                     ngroups, p.splits, slabs, slab_stride)
+  dim3 grid(p.panels, p.splits), block(64 * NW);
+  const int ngroups = p.nchunks / 2;
+  static const int dbg = getenv("PRMF_SWEEP_DEBUG") ? atoi(getenv("PRMF_SWEEP_DEBUG")) : 0;
+  if (dbg && NT == 2) {
+    if (dbg == 1) sweep_kernel<BF16, 1, 2, NW, BDB, 1><<<grid, block, 0, s>>>((const uint4*)A, lda16, M_store, (const uint4*)Bp, ngroups, p.splits, slabs, slab_stride);
+    else sweep_kernel<BF16, 1, 2, NW, BDB, 2><<<grid, block, 0, s>>>((const uint4*)A, lda16, M_store, (const uint4*)Bp, ngroups, p.splits, slabs, slab_stride);
+    return hipGetLastError();
+  }
+#define PRMF_LAUNCH(NTV)                                                                                          \
+  sweep_kernel<BF16, 1, NTV, NW, BDB><<<grid, block, 0, s>>>((const uint4*)A, lda16, M_store, (const uint4*)Bp, \
+                                                             ngroups, p.splits, slabs, slab_stride)
   switch (NT) {
     case 1: PRMF_LAUNCH(1); break;
     case 2: PRMF_LAUNCH(2); break;
@@ -366,8 +394,14 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
                        const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s) {
   const int64_t lda16 = lda * elem_bytes(x_dtype) / 16;
-  if (x_dtype == 1) return launch_sweep_nt<true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
-  return launch_sweep_nt<false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
+  const SweepVariant v = sweep_variant();
+#define PRMF_DISPATCH(BF)                                                                                              \
+  (v.nw == 8 ? (v.bdb ? launch_sweep_nt<BF, 8, true>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)         \
+                      : launch_sweep_nt<BF, 8, false>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s))       \
+              : (v.bdb ? launch_sweep_nt<BF, 4, true>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)        \
+                      : launch_sweep_nt<BF, 4, false>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)))
+  return x_dtype == 1 ? PRMF_DISPATCH(true) : PRMF_DISPATCH(false);
+#undef PRMF_DISPATCH
 }
 
 // ---------------------------------------------------------------------------

@@ -13,8 +13,7 @@ namespace prmf {
 // with A a zero-padded row-major matrix resident in HBM (X, resp. the X^T copy)
 // and B a factor (V resp. U) pre-packed into MFMA B-fragment order.
 constexpr int ROW_BYTES_PER_CHUNK = 128;   // one reduction chunk = 128 B of every A row
-constexpr int SWEEP_NSET = 2;              // A register sets of the sweep (one landed, one in flight): chunk loop unrolled x2
-constexpr int K_PAD = 64 * SWEEP_NSET;     // reduction length padded to 128 elements: an even number of chunks (both dtypes)
+constexpr int K_PAD = 128;                 // reduction length padded to 128 elements: an even number of chunks (both dtypes)
 constexpr int M_PAD = 256;                 // rows padded to the largest workgroup panel
 constexpr int MAX_KP = 128;                // latent columns padded to 32*NT, NT <= 4
 

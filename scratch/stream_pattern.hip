@@ -1,0 +1,59 @@
+// Pure streaming microbenchmark: how fast can HBM be read with the sweep's access
+// pattern?  Each wave owns R rows; per step it reads W bytes (W = 128,256,512,1024)
+// contiguous from each of its rows, line-complete loads (8 lanes x 16 B per 128 B).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int W>   // bytes per row per step
+__global__ void __launch_bounds__(256) stream_k(const uint4* __restrict__ A, long lda16, int steps_total, int nsplits, unsigned* out) {
+  constexpr int LPR = W / 16;          // lanes per row
+  constexpr int RPI = 64 / LPR;        // rows per instruction
+  constexpr int NI = 32 / RPI;         // instructions per 32-row tile per step
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row0 = ((long)blockIdx.x * 4 + wave) * 32;
+  const int per = steps_total / nsplits;
+  const int s0 = blockIdx.y * per;
+  const uint4* p = A + (row0 + lane / LPR) * lda16 + (long)s0 * LPR + (lane % LPR);
+  unsigned acc = 0;
+  for (int s = 0; s < per; ++s) {
+    uint4 v[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) v[i] = p[(long)i * RPI * lda16];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc += v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+    p += LPR;
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
+int main(int argc, char** argv) {
+  const long m = 50048, n = 20096;   // bf16 elements
+  const long lda16 = n * 2 / 16;
+  uint4* A; unsigned* out;
+  hipMalloc(&A, m * n * 2); hipMalloc(&out, 4);
+  hipMemset(A, 1, m * n * 2);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int panels = m / 128;
+  auto run = [&](int W, int nsplits) {
+    int steps_total = (int)(n * 2 / W);
+    steps_total -= steps_total % nsplits;
+    dim3 grid(panels, nsplits);
+    float best = 1e9;
+    for (int rep = 0; rep < 5; ++rep) {
+      hipEventRecord(e0);
+      if (W == 128) stream_k<128><<<grid, 256>>>(A, lda16, steps_total, nsplits, out);
+      if (W == 256) stream_k<256><<<grid, 256>>>(A, lda16, steps_total, nsplits, out);
+      if (W == 512) stream_k<512><<<grid, 256>>>(A, lda16, steps_total, nsplits, out);
+      if (W == 1024) stream_k<1024><<<grid, 256>>>(A, lda16, steps_total, nsplits, out);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    double bytes = (double)panels * 128 * steps_total * W;
+    printf("W=%4d splits=%2d grid=%5d  %.3f ms  %.2f TB/s\n", W, nsplits, panels * nsplits, best, bytes / best / 1e9);
+  };
+  for (int W : {128, 256, 512, 1024}) for (int sp : {2, 3, 4, 6, 8}) run(W, sp);
+  return 0;
+}
