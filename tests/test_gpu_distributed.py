@@ -1,0 +1,79 @@
+"""Two ranks sharing the one GPU of the test box (gloo between the processes):
+the real HIP phases with row-sharded X and column-sharded V-update must reproduce
+the single-rank result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, k, x_dtype, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from prmf_amd import PathwayLibrary
+        from prmf_amd.distributed import DistributedPrmf
+        from prmf_amd.solver import PrmfEngine
+        from prmf_amd.synthetic import shard_rows
+        case = synth.small_case(seed=13, m=700, n=1500, k=k, P=6, order=80, bf16_x=(x_dtype == "bf16"))
+        X = case["X"]
+        lo, hi = shard_rows(X.shape[0], world, rank)
+        eng = PrmfEngine(hi - lo, X.shape[1], k, x_dtype=x_dtype, device=0, nranks=world, rank=rank)
+        eng.set_x(X[lo:hi], norm_x_sq=float(np.sum(X * X)))
+        eng.set_library(PathwayLibrary.from_edge_lists(X.shape[1], case["pathways"]))
+        eng.set_active(np.arange(k) % 6)
+        U = eng.device_tensor(case["U0"][lo:hi], torch.float32)
+        V = eng.device_tensor(case["V0"], torch.float32)
+        objs, gd = DistributedPrmf(eng).step(U, V, 6, case["gamma"], case["delta"])
+        q.put((rank, U.cpu().numpy(), V.cpu().numpy(), objs))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,x_dtype", [(16, "f32"), (13, "bf16")])
+def test_two_ranks_match_single_rank(k, x_dtype):
+    import torch
+    import torch.multiprocessing as mp
+    from oracle import prmf_oracle as orc
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, x_dtype, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r, U, V, objs = q.get()
+        res[r] = (U, V, objs)
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]      # replicated state agrees bitwise
+    U = np.concatenate([res[0][0], res[1][0]])
+    case = synth.small_case(seed=13, m=700, n=1500, k=k, P=6, order=80, bf16_x=(x_dtype == "bf16"))
+    pws = [orc.pathway_from_edges(1500, e, nodes, w) for (e, w, nodes) in case["pathways"]]
+    tr = []
+    Ur, Vr, od = orc.nmf_manifold_vec_update(case["X"], case["U0"], case["V0"], [pws[i % 6] for i in range(k)],
+                                             n_steps=6, gamma=case["gamma"], delta=case["delta"], trace=tr)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert rel(U, Ur) < 1e-4 and rel(res[0][1], Vr) < 1e-4
+    for a, b in zip(res[0][2], tr):
+        for key in ("recon", "manifold", "ignore", "fro", "obj"):
+            assert abs(a[key] - b[key]) <= 1e-4 * max(abs(b[key]), 1e-12), key

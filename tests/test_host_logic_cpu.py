@@ -1,0 +1,132 @@
+"""Host-side logic of the product (no GPU): pathway library construction, the
+restrict / matching control code and the CLI front end, against the oracle and the
+reference-generated goldens."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import synth
+from oracle import prmf_oracle as orc
+from prmf_amd import PathwayLibrary
+from prmf_amd import runner
+from prmf_amd import solver
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_from_edge_lists_matches_oracle_pathways():
+    case = synth.small_case(seed=4, P=7)
+    n = case["X"].shape[1]
+    lib = PathwayLibrary.from_edge_lists(n, case["pathways"])
+    assert lib.P == 7 and lib.sup_ptr[-1] == len(lib.sup_idx)
+    for p, (e, w, nodes) in enumerate(case["pathways"]):
+        pw = orc.pathway_from_edges(n, e, nodes, w)
+        s0, s1 = lib.sup_ptr[p], lib.sup_ptr[p + 1]
+        assert np.array_equal(lib.sup_idx[s0:s1], pw.support)
+        assert np.allclose(lib.sup_deg[s0:s1], pw.deg[pw.support])
+        assert np.allclose(lib.sup_ldiag[s0:s1], pw.L.diagonal()[pw.support])
+        # rebuild W from the support-local CSR
+        W = np.zeros((n, n))
+        for s in range(s0, s1):
+            for e_ in range(lib.row_ptr[s], lib.row_ptr[s + 1]):
+                W[lib.sup_idx[s], lib.sup_idx[s0 + lib.col_local[e_]]] = lib.w[e_]
+        assert np.allclose(W, pw.W.toarray())
+        v = np.random.RandomState(p).rand(n)
+        assert abs(lib.laplacian_quadratic(p, v) - pw.L.dot(v).dot(v)) < 1e-9
+
+
+def test_library_from_graphs_and_from_sparse(tmp_path):
+    import networkx as nx
+    c = synth.cli_case(str(tmp_path), variant=2)
+    Gs = [runner.relabel_nodes(nx.read_graphml(fp).to_undirected(), "name") for fp in c["manifolds"]]
+    lib = PathwayLibrary.from_graphs(Gs, c["nodelist_ids"])
+    pws = [orc.pathway_from_graph(G, c["nodelist_ids"]) for G in Gs]
+    for p, pw in enumerate(pws):
+        s0, s1 = lib.sup_ptr[p], lib.sup_ptr[p + 1]
+        assert np.array_equal(lib.sup_idx[s0:s1], pw.support)
+        assert np.allclose(lib.sup_deg[s0:s1], pw.deg[pw.support])
+    # the isolated unmeasured node is in the support with degree 0
+    assert (lib.sup_deg == 0).sum() == len(Gs)
+    lib2 = PathwayLibrary.from_sparse([pw.W for pw in pws], [pw.support for pw in pws])
+    for a, b in zip(lib.arrays(), lib2.arrays()):
+        assert np.array_equal(a, b)
+    bad = pws[0].W.tolil()
+    outside = [i for i in range(lib.n) if i not in set(pws[0].support)][:2]
+    bad[outside[0], outside[1]] = 1.0
+    with pytest.raises(ValueError):
+        PathwayLibrary.from_sparse([bad.tocsr()], [pws[0].support])
+
+
+def test_restrict_matches_reference_kept_sets(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g5_restrict.npz"))
+    k, P = g["scores"].shape
+    l2p = {kk: [(p, 1) for p in range(P)] for kk in range(k)}
+    kept = solver.restrict(g["scores"], l2p)
+    mask = np.zeros_like(g["kept"])
+    for kk, lst in kept.items():
+        for p, s in lst:
+            mask[kk, p] = 1
+            assert s == g["scores"][kk, p]
+    assert np.array_equal(mask, g["kept"])
+    # a latent with a single candidate is left alone; ties raise like the reference
+    assert solver.restrict(g["scores"], {0: [(3, 2)]}) == {0: [(3, 2)]}
+    # (sample size ceil(n*(1-19.9)/100) is negative from n = 6 candidates on, prmf_runner.py:179)
+    with pytest.raises(ValueError):
+        solver.restrict(np.ones((1, 8)), {0: [(p, 1) for p in range(8)]})
+
+
+def test_force_distinct_matches_oracle():
+    case = synth.small_case(seed=6, P=5)
+    n, k = case["X"].shape[1], case["k"]
+    lib = PathwayLibrary.from_edge_lists(n, case["pathways"])
+    pws = [orc.pathway_from_edges(n, e, nodes, w) for (e, w, nodes) in case["pathways"]]
+    V = case["V0"]
+    l2p_a = {kk: [(p, 1) for p in range(5)] for kk in range(k)}
+    l2p_b = {kk: [(p, 1) for p in range(5)] for kk in range(k)}
+    k_to_lapl = {kk: kk % 5 for kk in range(k)}
+    a = solver.force_distinct_lapls(V, lib, l2p_a, k_to_lapl, case["gamma"], case["delta"])
+    b = orc.force_distinct_lapls(V, pws, l2p_b, {kk: pws[k_to_lapl[kk]].support for kk in range(k)},
+                                 case["gamma"], case["delta"])
+    assert {kk: v[0][0] for kk, v in a.items()} == {kk: v[0][0] for kk, v in b.items()}
+    assert len({v[0][0] for v in a.values()}) == k
+
+
+def test_cli_front_end_helpers(tmp_path):
+    c = synth.cli_case(str(tmp_path), variant=1)
+    assert runner.check_header(c["data_header"], "\t") and not runner.check_header(c["data"], "\t")
+    assert not runner.check_row_names(c["data"], "\t", False)
+    with open(c["nodelist"]) as fh:
+        assert runner.parse_nodelist(fh) == c["nodelist_ids"]
+    arr = np.arange(6.0).reshape(2, 3)
+    assert np.array_equal(runner.embed_arr(list("abcde"), list("eca"), arr), orc.embed_arr(list("abcde"), list("eca"), arr))
+    rs = np.random.RandomState(0)
+    V = rs.rand(40, 3)
+    Xt = rs.rand(4, 40)
+    assert np.allclose(runner.measure_cv_performance(V, Xt), orc.measure_cv_performance(V, Xt))
+
+
+def _run_cli(args, cwd):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "script", "prmf_runner.py")] + args,
+                          cwd=cwd, capture_output=True, text=True)
+
+
+def test_cli_exit_codes(tmp_path):
+    c = synth.cli_case(str(tmp_path), variant=1)
+    out = str(tmp_path)
+    r = _run_cli(["--data", c["data"], "--outdir", out], out)
+    assert r.returncode == 22 and "Exactly one of --manifolds" in r.stderr
+    mf = os.path.join(out, "mf.txt")
+    open(mf, "w").write("\n".join(c["manifolds"]))
+    r = _run_cli(["--data", c["data"], "--outdir", out, "--manifolds", c["manifolds"][0], "--manifolds-file", mf], out)
+    assert r.returncode == 23
+    r = _run_cli(["--data", c["data"], "--outdir", out, "--manifolds", c["manifolds"][0], "--delimiter", "\t"], out)
+    assert r.returncode == 25 and "--nodelist is not provided" in r.stderr
+    bad_nodes = os.path.join(out, "bad_nodelist.txt")
+    open(bad_nodes, "w").write("\n".join("X%d" % i for i in range(1000)))
+    r = _run_cli(["--data", c["data"], "--outdir", out, "--manifolds", c["manifolds"][0], "--delimiter", "\t",
+                  "--nodelist", bad_nodes], out)
+    assert r.returncode == 24 and "Invalid manifolds" in r.stderr
