@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -39,6 +40,8 @@ struct prmf_ctx {
   void* Vp = nullptr;
   void* Up = nullptr;
   GemmPlan plan_xv{}, plan_xtu{};
+  int* nseg_xv = nullptr;             // device copies of the plans' per-panel segment counts
+  int* nseg_xtu = nullptr;
   float* slabs = nullptr;             // shared by both sweeps
   int64_t slab_stride_p = 0, slab_stride_q = 0;
 
@@ -64,6 +67,7 @@ struct prmf_ctx {
   double* colres = nullptr;           // [kc][2]
   double* vpartial = nullptr;         // [v_update_blocks][kc+1]
   int vblocks = 0;
+  bool fused_u = false, fused_v = false;   // MFMA epilogues (k % 4 == 0; V path single-rank only)
 
   // hyper-parameters + records
   double* hyper = nullptr;            // device: gamma, delta, tradeoff
@@ -210,12 +214,22 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
 
   c->Kpad_x = round_up(n, K_PAD);
   c->Kpad_xt = round_up(m_local > 0 ? m_local : 1, K_PAD);
-  c->plan_xv = plan_gemm(x_dtype, m_local > 0 ? m_local : 1, c->Kpad_x, c->NT, 0);
-  c->plan_xtu = plan_gemm(x_dtype, n, c->Kpad_xt, c->NT, 0);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { fail(c, PRMF_ERR_HIP, "hipGetDeviceProperties failed"); return bail(PRMF_ERR_HIP); }
+  const int n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  c->plan_xv = plan_gemm(x_dtype, m_local > 0 ? m_local : 1, c->Kpad_x, c->NT, n_cus);
+  c->plan_xtu = plan_gemm(x_dtype, n, c->Kpad_xt, c->NT, n_cus);
   c->slab_stride_p = (m_local > 0 ? m_local : 1) * (int64_t)c->KP;
   c->slab_stride_q = n * (int64_t)c->KP;
-  int64_t slab_floats = c->slab_stride_p * c->plan_xv.splits;
-  if (c->slab_stride_q * c->plan_xtu.splits > slab_floats) slab_floats = c->slab_stride_q * c->plan_xtu.splits;
+  int64_t slab_floats = c->slab_stride_p * c->plan_xv.max_seg;
+  if (c->slab_stride_q * c->plan_xtu.max_seg > slab_floats) slab_floats = c->slab_stride_q * c->plan_xtu.max_seg;
+  if ((rc = dev_alloc(c, &c->nseg_xv, c->plan_xv.nseg.size(), false))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->nseg_xtu, c->plan_xtu.nseg.size(), false))) return bail(rc);
+  if (hipMemcpy(c->nseg_xv, c->plan_xv.nseg.data(), c->plan_xv.nseg.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->nseg_xtu, c->plan_xtu.nseg.data(), c->plan_xtu.nseg.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+    fail(c, PRMF_ERR_HIP, "hipMemcpy(plan) failed");
+    return bail(PRMF_ERR_HIP);
+  }
 
   if ((rc = dev_alloc(c, (char**)&c->Vp, (size_t)packed_bytes(c, c->Kpad_x)))) return bail(rc);
   if ((rc = dev_alloc(c, (char**)&c->Up, (size_t)packed_bytes(c, c->Kpad_xt)))) return bail(rc);
@@ -225,7 +239,9 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, &c->Gv, (size_t)k * k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->active_dev, (size_t)k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->pos, (size_t)n * c->kc, false))) return bail(rc);
-  c->vblocks = v_update_blocks(n);
+  c->fused_u = (k % 4 == 0) && !getenv("PRMF_NO_FUSED_EPILOGUE");
+  c->fused_v = c->fused_u && nranks == 1;
+  c->vblocks = c->fused_v ? v_epilogue_waves(n) : v_update_blocks(n);
   if ((rc = dev_alloc(c, &c->vpartial, (size_t)c->vblocks * (c->kc + 1)))) return bail(rc);
   if ((rc = dev_alloc(c, &c->colres, (size_t)c->kc * 2))) return bail(rc);
   if ((rc = dev_alloc(c, &c->hyper, 4))) return bail(rc);
@@ -251,6 +267,8 @@ int prmf_destroy(prmf_ctx* c) {
   dev_free(c->Vp);
   dev_free(c->Up);
   dev_free(c->slabs);
+  dev_free(c->nseg_xv);
+  dev_free(c->nseg_xtu);
   dev_free(c->gram_partial);
   dev_free(c->Gv);
   if (c->own_comm) {
@@ -458,9 +476,14 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
     HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xv, c->X, c->ldx, c->m, c->Vp, c->NT, c->slabs, c->slab_stride_p, s));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 1], s));
     // U <- U * P / (U Gv + U)                              (:421-422)
-    HIP_TRY(c, launch_u_update(c->U, c->m, c->k, c->slabs, c->plan_xv.splits, c->slab_stride_p, c->KP, c->Gv, s));
     FactorView fu{c->U, (int)c->m, c->k, c->k, 0};
-    HIP_TRY(c, launch_pack_factor(fu, c->x_dtype, c->NT, c->Kpad_xt, c->Up, s));
+    if (c->fused_u) {
+      HIP_TRY(c, launch_u_epilogue(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP,
+                                   c->Gv, c->x_dtype, c->Up, c->Kpad_xt, s));
+    } else {
+      HIP_TRY(c, launch_u_update(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP, c->Gv, s));
+      HIP_TRY(c, launch_pack_factor(fu, c->x_dtype, c->NT, c->Kpad_xt, c->Up, s));
+    }
     HIP_TRY(c, launch_gram(fu, c->gram_partial, c->gram_buf, s));
   } else {
     HIP_TRY(c, hipMemsetAsync(c->gram_buf, 0, (size_t)c->k * c->k * sizeof(double), s));
@@ -479,8 +502,9 @@ int prmf_phase_q(prmf_ctx* c, void* stream) {
     // Q = X^T U_new                                       (:424)
     HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xtu, c->XT, c->ldxt, c->n, c->Up, c->NT, c->slabs, c->slab_stride_q, s));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 3], s));
-    HIP_TRY(c, launch_slab_sum_blocks(c->slabs, c->plan_xtu.splits, c->slab_stride_q, c->KP, c->n, c->k, c->kc,
-                                      c->nranks, c->q_send, s));
+    if (!c->fused_v)
+      HIP_TRY(c, launch_slab_sum_blocks(c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP, c->n, c->k, c->kc,
+                                        c->nranks, c->q_send, s));
   } else {
     HIP_TRY(c, hipMemsetAsync(c->q_send, 0, (size_t)c->n * c->kc * c->nranks * sizeof(float), s));
   }
@@ -495,9 +519,18 @@ int prmf_phase_v(prmf_ctx* c, void* stream) {
   // sparse pathway terms on the OLD V                    (:431-438)
   HIP_TRY(c, launch_graph_terms(c->lib, c->active_dev, c->col0, c->ncols, c->V, c->k, c->hyper, c->gnum, c->gden, s));
   // V_own <- V * (Q + gnum) / max(V Gu + gden, eps)      (:425, :440-444)
+  double* extras = reinterpret_cast<double*>(c->v_send + c->extras_off);
+  if (c->fused_v) {
+    // single rank: V updated in place straight from the sweep's slabs, packed for the next sweep in the same pass
+    HIP_TRY(c, launch_v_epilogue(c->V, c->n, c->k, c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP,
+                                 c->gram_buf, c->pos, c->gnum, c->gden, c->lib.max_support, c->x_dtype, c->Vp, c->Kpad_x,
+                                 c->vpartial, s));
+    HIP_TRY(c, launch_objective_terms(c->lib, c->active_dev, 0, c->k, c->k, c->n, c->V, c->vpartial, c->vblocks, c->colres,
+                                      c->obj_scratch, extras, s));
+    return PRMF_OK;
+  }
   HIP_TRY(c, launch_v_update(c->V, c->n, c->k, c->col0, c->ncols, c->kc, c->q_recv, c->gram_buf, c->pos, c->gnum, c->gden,
                              c->lib.max_support, c->v_send, c->vpartial, s));
-  double* extras = reinterpret_cast<double*>(c->v_send + c->extras_off);
   HIP_TRY(c, launch_objective_terms(c->lib, c->active_dev, c->col0, c->ncols, c->kc, c->n, c->v_send, c->vpartial,
                                     c->vblocks, c->colres, c->obj_scratch, extras, s));
   return PRMF_OK;
@@ -509,9 +542,11 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
   if ((rc = set_device(c))) return rc;
   if (c->cursor >= MAX_RECORDS) return fail(c, PRMF_ERR_STATE, "more than %d iterations between prmf_begin and prmf_end", MAX_RECORDS);
   hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(c, launch_assemble_v(c->v_recv, c->nranks, c->v_send_floats, c->kc, c->n, c->k, c->V, s));
   FactorView fv{c->V, (int)c->n, c->k, c->k, 0};
-  HIP_TRY(c, launch_pack_factor(fv, c->x_dtype, c->NT, c->Kpad_x, c->Vp, s));
+  if (!c->fused_v) {
+    HIP_TRY(c, launch_assemble_v(c->v_recv, c->nranks, c->v_send_floats, c->kc, c->n, c->k, c->V, s));
+    HIP_TRY(c, launch_pack_factor(fv, c->x_dtype, c->NT, c->Kpad_x, c->Vp, s));
+  }
   HIP_TRY(c, launch_gram(fv, c->gram_partial, c->Gv, s));
   HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->nranks, c->v_send_floats, c->extras_off,
                              c->norm_x_sq, c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, s));
@@ -609,10 +644,10 @@ int prmf_get_sweep_info(const prmf_ctx* c, prmf_sweep_info* out) {
   const int eb = elem_bytes(c->x_dtype);
   out->bytes_x_sweep = round_up(c->m > 0 ? c->m : 1, 128) * c->Kpad_x * eb;
   out->bytes_xt_sweep = round_up(c->n, 128) * c->Kpad_xt * eb;
-  out->splits_xv = c->plan_xv.splits;
-  out->splits_xtu = c->plan_xtu.splits;
-  out->grid_xv = c->plan_xv.panels * c->plan_xv.splits;
-  out->grid_xtu = c->plan_xtu.panels * c->plan_xtu.splits;
+  out->splits_xv = c->plan_xv.max_seg;
+  out->splits_xtu = c->plan_xtu.max_seg;
+  out->grid_xv = c->plan_xv.grid;
+  out->grid_xtu = c->plan_xtu.grid;
   return PRMF_OK;
 }
 

@@ -241,10 +241,10 @@ __device__ __forceinline__ void store_b_chunk(u32x4* sb, const u32x4 (&src)[NB],
 //              workgroup -> more resident workgroups (bytes in flight) per CU
 // The host pads the reduction to an even number of chunks and gives every split an
 // even number, so the chunk loop is unrolled x2 with compile-time LDS buffer offsets.
-template <bool BF16, int MT, int NT, int NW, bool BDB, int DBG = 0>
+template <bool BF16, int MT, int NT, int NW, bool BDB>
 __global__ void __launch_bounds__(64 * NW)
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
-             const uint4* __restrict__ Bp, int ngroups /* total chunks / 2 */, int nsplits,
+             const uint4* __restrict__ Bp, int npanels, int ngroups /* chunk pairs per row */,
              float* __restrict__ slabs, int64_t slab_stride) {
   constexpr int KP = 32 * NT;
   constexpr int NTHR = 64 * NW;
@@ -255,17 +255,18 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int split = blockIdx.y;
-  const int gbase = ngroups / nsplits, grem = ngroups % nsplits;
-  const int c0 = 2 * (split * gbase + min(split, grem));
-  const int nch = 2 * (gbase + (split < grem ? 1 : 0));
-  const int last = nch - 1;
-  const int64_t prow0 = (int64_t)blockIdx.x * (32 * MT * NW);      // first row of this workgroup's panel
-  const int64_t row0 = prow0 + wave * (32 * MT);                    // first row of this wave
 
-  // uniform bases (SGPR) + per-lane byte offsets (VGPR, < panel rows * row bytes)
-  const uint4* abase = A + prow0 * lda16 + (int64_t)c0 * 8;         // chunk = 8 x 16 B of each row
-  const uint4* bbase = Bp + (int64_t)c0 * BCH;
+  // Balanced persistent decomposition: the launch has one workgroup per resident
+  // slot; the npanels x ngroups units (a unit = 2 chunks of one row panel) are cut
+  // into gridDim.x equal contiguous ranges in panel-major order.  A range that
+  // crosses a panel boundary is processed as separate segments; segment number
+  // `seg` of a panel (counted from the workgroup that holds the panel's first
+  // unit) goes to slab `seg`, and the consumer sums a panel's segments in order.
+  const int64_t T = (int64_t)npanels * ngroups;
+  const int64_t G = gridDim.x, wg = blockIdx.x;
+  int64_t unit = wg * T / G;
+  const int64_t unit_end = (wg + 1) * T / G;
+
   unsigned avoff[MT][4];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -277,6 +278,22 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
     }
   const unsigned bvoff = (unsigned)tid * 16u;
   u32x4* const myA = sA[wave];
+
+  while (unit < unit_end) {
+  const int panel = (int)(unit / ngroups);
+  const int g0 = (int)(unit - (int64_t)panel * ngroups);
+  const int g1 = (int)min((int64_t)ngroups, g0 + (unit_end - unit));
+  const int seg = (int)(wg - (((int64_t)panel * ngroups + 1) * G - 1) / T);   // wg minus the first workgroup of this panel
+  unit += g1 - g0;
+  const int c0 = 2 * g0;
+  const int nch = 2 * (g1 - g0);
+  const int last = nch - 1;
+  const int64_t prow0 = (int64_t)panel * (32 * MT * NW);            // first row of this panel
+  const int64_t row0 = prow0 + wave * (32 * MT);                    // first row of this wave
+
+  // uniform bases (SGPR) + per-lane byte offsets (VGPR, < panel rows * row bytes)
+  const uint4* abase = A + prow0 * lda16 + (int64_t)c0 * 8;         // chunk = 8 x 16 B of each row
+  const uint4* bbase = Bp + (int64_t)c0 * BCH;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -304,10 +321,9 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int cn = min(c + u + 1, last);
-      load_b_chunk<BPT, NTHR, BCH>(bs, bvoff, bbase + (int64_t)(DBG == 1 ? (cn & 1) : cn) * BCH, tid);
+      load_b_chunk<BPT, NTHR, BCH>(bs, bvoff, bbase + (int64_t)cn * BCH, tid);
       load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
-      if constexpr (DBG != 2) sweep_compute<BF16, MT, NT>(acc, myA, sB[BDB ? u : 0], lane);
-      else { acc[0][0][0] += __uint_as_float(myA[lane][0]) + __uint_as_float(sB[BDB ? u : 0][lane][0]); }
+      sweep_compute<BF16, MT, NT>(acc, myA, sB[BDB ? u : 0], lane);
       wait_all_loads<BPT, MT>(bs, a);
       if constexpr (!BDB) __syncthreads();          // everyone has finished reading B(c)
       store_b_chunk<BPT, NTHR, BCH>(sB[BDB ? (u ^ 1) : 0], bs, tid);
@@ -320,7 +336,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   }
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*h
-  float* out = slabs + (int64_t)split * slab_stride;
+  float* out = slabs + (int64_t)seg * slab_stride;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -331,55 +347,57 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
         for (int t = 0; t < NT; ++t) out[row * KP + 32 * t + r] = acc[mt][t][i];
       }
     }
+  }   // segments
 }
 
-struct SweepVariant { int nw; bool bdb; };
+struct SweepVariant { int nw; bool bdb; int wgs_per_cu; };
 static SweepVariant sweep_variant() {
   static const SweepVariant v = [] {
-    SweepVariant r{8, true};
+    SweepVariant r{8, true, 2};
     if (const char* e = getenv("PRMF_SWEEP_NW")) r.nw = atoi(e) == 4 ? 4 : 8;
     if (const char* e = getenv("PRMF_SWEEP_BDB")) r.bdb = atoi(e) != 0;
+    // resident workgroups per CU by LDS at k <= 64 (the grid is sized to fill exactly these slots)
+    r.wgs_per_cu = r.nw == 8 ? (r.bdb ? 2 : 3) : (r.bdb ? 3 : 5);
+    if (const char* e = getenv("PRMF_SWEEP_WGS_PER_CU")) r.wgs_per_cu = atoi(e) > 0 ? atoi(e) : r.wgs_per_cu;
     return r;
   }();
   return v;
 }
 
-GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int force_splits) {
+static int64_t first_wg_of_unit(int64_t u, int64_t G, int64_t T) { return ((u + 1) * G - 1) / T; }
+
+GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus) {
   GemmPlan p;
-  p.MT = 1;
-  const int rows_wg = sweep_variant().nw * 32 * p.MT;
-  p.panels = (int)(round_up(M, rows_wg) / rows_wg);
+  const SweepVariant v = sweep_variant();
+  p.panel_rows = v.nw * 32;
+  p.panels = (int)(round_up(M, p.panel_rows) / p.panel_rows);
   p.nchunks = (int)(Kpad / chunk_elems(x_dtype));          // even (K_PAD)
-  const int ngroups = p.nchunks / 2;
-  // about two rounds of the 512 resident workgroups (2 per CU), but at least 8
-  // chunks per split so prologue/epilogue stay small
-  int target_wgs = 1100;
-  if (force_splits <= 0 && getenv("PRMF_SWEEP_SPLITS")) force_splits = atoi(getenv("PRMF_SWEEP_SPLITS"));
-  int splits = force_splits > 0 ? force_splits : (target_wgs + p.panels / 2) / p.panels;
-  int max_splits = ngroups / 4 > 0 ? ngroups / 4 : 1;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  if (splits > 64) splits = 64;
-  p.splits = splits;
-  p.chunks_per_split = 2 * ((ngroups + splits - 1) / splits);
-  (void)NT;
+  p.ngroups = p.nchunks / 2;
+  const int64_t T = (int64_t)p.panels * p.ngroups;
+  // one workgroup per resident slot, but at least 4 units (8 chunks) each
+  int64_t G = (int64_t)n_cus * v.wgs_per_cu;
+  if (NT > 2) G = (int64_t)n_cus * (v.wgs_per_cu > 1 ? v.wgs_per_cu - 1 : 1);   // larger B tiles: fewer resident workgroups
+  if (G > T / 4) G = T / 4;
+  if (G < 1) G = 1;
+  p.grid = (int)G;
+  p.nseg.assign(p.panels, 0);
+  p.max_seg = 1;
+  for (int q = 0; q < p.panels; ++q) {
+    const int64_t w0 = first_wg_of_unit((int64_t)q * p.ngroups, G, T);
+    const int64_t w1 = first_wg_of_unit((int64_t)(q + 1) * p.ngroups - 1, G, T);
+    p.nseg[q] = (int)(w1 - w0 + 1);
+    if (p.nseg[q] > p.max_seg) p.max_seg = p.nseg[q];
+  }
   return p;
 }
 
 template <bool BF16, int NW, bool BDB>
 static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda16, int64_t M_store, const void* Bp,
                                   int NT, float* slabs, int64_t slab_stride, hipStream_t s) {
-  dim3 grid(p.panels, p.splits), block(64 * NW);
-  const int ngroups = p.nchunks / 2;
-  static const int dbg = getenv("PRMF_SWEEP_DEBUG") ? atoi(getenv("PRMF_SWEEP_DEBUG")) : 0;
-  if (dbg && NT == 2) {
-    if (dbg == 1) sweep_kernel<BF16, 1, 2, NW, BDB, 1><<<grid, block, 0, s>>>((const uint4*)A, lda16, M_store, (const uint4*)Bp, ngroups, p.splits, slabs, slab_stride);
-    else sweep_kernel<BF16, 1, 2, NW, BDB, 2><<<grid, block, 0, s>>>((const uint4*)A, lda16, M_store, (const uint4*)Bp, ngroups, p.splits, slabs, slab_stride);
-    return hipGetLastError();
-  }
+  dim3 grid(p.grid), block(64 * NW);
 #define PRMF_LAUNCH(NTV)                                                                                          \
   sweep_kernel<BF16, 1, NTV, NW, BDB><<<grid, block, 0, s>>>((const uint4*)A, lda16, M_store, (const uint4*)Bp, \
-                                                             ngroups, p.splits, slabs, slab_stride)
+                                                             p.panels, p.ngroups, slabs, slab_stride)
   switch (NT) {
     case 1: PRMF_LAUNCH(1); break;
     case 2: PRMF_LAUNCH(2); break;

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace prmf {
 
 // ---------------------------------------------------------------------------
@@ -39,13 +41,15 @@ struct FactorView {
 // ---------------------------------------------------------------------------
 hipError_t launch_pack_factor(const FactorView& f, int x_dtype, int NT, int64_t Kpad, void* packed, hipStream_t s);
 struct GemmPlan {
-  int MT;            // 32-row MFMA tiles per wave
-  int panels;        // workgroups along M
-  int splits;        // workgroups along the reduction
-  int chunks_per_split;
-  int nchunks;
+  int panel_rows = 0;       // rows per panel (= rows of one workgroup tile)
+  int panels = 0;           // row panels
+  int nchunks = 0;          // reduction chunks per row (even)
+  int ngroups = 0;          // nchunks / 2: the work unit is (panel, chunk pair)
+  int grid = 0;             // workgroups launched: one per resident slot, equal contiguous unit ranges
+  int max_seg = 1;          // slabs needed: most segments any panel is cut into
+  std::vector<int> nseg;    // [panels] segments (= slabs to sum) of each panel
 };
-GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int force_splits);
+GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus);
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
                        const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s);
 hipError_t launch_copy_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols,
@@ -70,14 +74,24 @@ struct PathwayLibDev {
 };
 
 // U <- U * (P / (U Gv + U)), P = sum of `splits` slabs     (prmf_runner.py:420-422)
-hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, int splits, int64_t slab_stride,
-                           int KP, const double* Gv, hipStream_t s);
-// partial Gram: blocks of rows -> partial[nblk][k*k]; reduce -> G (double)
+hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const int* nseg, int panel_rows,
+                           int64_t slab_stride, int KP, const double* Gv, hipStream_t s);
+// fused U epilogue (k % 4 == 0): slab sum + U (V^T V) on the f32 MFMA + update + fragment packing
+hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const int* nseg, int panel_rows,
+                             int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
+                             hipStream_t s);
+// fused single-rank V epilogue (k % 4 == 0): in place, + packing + per-wave partials [waves][k+1]
+int v_epilogue_waves(int64_t n);
+hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const int* nseg, int panel_rows,
+                             int64_t slab_stride, int KP, const double* Gu, const int32_t* pos, const float* gnum,
+                             const float* gden, int max_support, int x_dtype, void* packed, int64_t Kpad,
+                             double* partial, hipStream_t s);
+// partial Gram: per-wave partials -> partial[gram_blocks][k*k]; reduce -> G (double)
 int gram_blocks(int64_t rows);
 hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStream_t s);
 // Q slabs -> q_send[nranks][n][kc]
-hipError_t launch_slab_sum_blocks(const float* slabs, int splits, int64_t slab_stride, int KP, int64_t n, int k,
-                                  int kc, int nranks, float* q_send, hipStream_t s);
+hipError_t launch_slab_sum_blocks(const float* slabs, const int* nseg, int panel_rows, int64_t slab_stride, int KP,
+                                  int64_t n, int k, int kc, int nranks, float* q_send, hipStream_t s);
 // pos[n][kc] = index in the active pathway's support of gene j for own column c, or -1
 hipError_t launch_build_pos(const PathwayLibDev& lib, const int32_t* active_dev, int col0, int ncols, int kc,
                             int64_t n, int32_t* pos, hipStream_t s);

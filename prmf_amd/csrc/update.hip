@@ -34,8 +34,9 @@ __device__ __forceinline__ double block_sum_256(double v, double* red /* [256] s
 // U <- U * (X V) / (U (V^T V) + U), 0/0 := 1          (prmf_runner.py:420-422)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-u_update_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs, int splits,
-                int64_t slab_stride, int KP, const double* __restrict__ Gv) {
+u_update_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs,
+                const int* __restrict__ nseg, int panel_rows, int64_t slab_stride, int KP,
+                const double* __restrict__ Gv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int k4 = (k + 3) & ~3;
   const int ncg = k4 >> 2;
@@ -74,7 +75,8 @@ u_update_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict
         const int col = 4 * cg + j;
         if (col < k) {
           float p = 0.f;
-          for (int s = 0; s < splits; ++s) p += slabs[(int64_t)s * slab_stride + row * KP + col];
+          const int ns = nseg[row / panel_rows];
+          for (int s = 0; s < ns; ++s) p += slabs[(int64_t)s * slab_stride + row * KP + col];
           const float uu = urow[col];
           const float d = den[j] + uu;
           const float ratio = (d != 0.f) ? p / d : 1.f;
@@ -85,90 +87,448 @@ u_update_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict
   }
 }
 
-hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, int splits, int64_t slab_stride, int KP,
-                           const double* Gv, hipStream_t s) {
+hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const int* nseg, int panel_rows,
+                           int64_t slab_stride, int KP, const double* Gv, hipStream_t s) {
   const int k4 = (k + 3) & ~3;
   const int RT = 256 / (k4 >> 2);
   size_t lds = (size_t)(k * k4 + RT * k4) * sizeof(float);
   int64_t ntiles = (m + RT - 1) / RT;
   int grid = (int)(ntiles < 2048 ? ntiles : 2048);
-  u_update_kernel<<<grid, 256, lds, s>>>(U, m, k, slabs, splits, slab_stride, KP, Gv);
+  u_update_kernel<<<grid, 256, lds, s>>>(U, m, k, slabs, nseg, panel_rows, slab_stride, KP, Gv);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
-// Gram matrix F^T F: per-block float partials over 256 rows, reduced in double
+// Gram matrix F^T F on the f32 MFMA (v_mfma_f32_32x32x2_f32: exact f32 products).
+// A wave loads a 32-row tile in the MFMA C/D layout (lane (c,h), register i holds
+// F[row(i,h)][32t + c], row(i,h) = (i&3) + 8(i>>2) + 4h): with that value as BOTH
+// operands -- A[i=c][k=h] from column tile t1, B[k=h][j=c] from column tile t2 --
+// one MFMA per register adds the two rows {row(i,0), row(i,1)} to the 32x32 block
+// (t1,t2) of the Gram matrix; 16 MFMAs cover the 32 rows, no data movement at all.
+// Per-wave float partials (a few hundred rows each), reduced in float64 in a fixed
+// order (deterministic).
 // ---------------------------------------------------------------------------
-constexpr int GRAM_ROWS = 256;
-int gram_blocks(int64_t rows) { return (int)((rows + GRAM_ROWS - 1) / GRAM_ROWS); }
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int GRAM_MAX_BLOCKS = 128;
+int gram_blocks(int64_t rows) {            // number of per-workgroup partials the launch writes
+  int64_t tiles = (rows + 31) / 32;
+  int64_t blocks = (tiles + 3) / 4;
+  if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
 
 template <int NT>
-__global__ void __launch_bounds__(256) gram_partial_kernel(FactorView f, float* __restrict__ partial) {
-  constexpr int KP = 32 * NT, TN = 2 * NT;
-  __shared__ __attribute__((aligned(16))) float Fs[32][KP];
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+__global__ void __launch_bounds__(256) gram_mfma_kernel(FactorView f, float* __restrict__ partial) {
+  constexpr int NP = NT * (NT + 1) / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
   const int k = f.cols;
-  float acc[TN][TN];
+  f32x16 g[NP];
 #pragma unroll
-  for (int a = 0; a < TN; ++a)
+  for (int p = 0; p < NP; ++p)
 #pragma unroll
-    for (int b = 0; b < TN; ++b) acc[a][b] = 0.f;
-  const int64_t r0 = (int64_t)blockIdx.x * GRAM_ROWS;
-  for (int sub = 0; sub < GRAM_ROWS; sub += 32) {
-    __syncthreads();
-    for (int i = tid; i < 32 * KP; i += 256) {
-      int rr = i / KP, c = i - rr * KP;
-      int64_t row = r0 + sub + rr;
-      float v = 0.f;
-      if (row < f.rows && c < k) v = f.src[(int64_t)(c / f.kc) * f.blk_stride + row * f.kc + (c % f.kc)];
-      Fs[rr][c] = v;
+    for (int i = 0; i < 16; ++i) g[p][i] = 0.f;
+  const int64_t ntiles = ((int64_t)f.rows + 31) / 32;
+  const int64_t wstride = (int64_t)gridDim.x * 4;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += wstride) {
+    float v[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = 32 * t + c;
+      const int64_t cb = (int64_t)(col / f.kc) * f.blk_stride + (col % f.kc);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t row = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        v[t][i] = (row < f.rows && col < k) ? f.src[cb + row * f.kc] : 0.f;
+      }
     }
-    __syncthreads();
-#pragma unroll 4
-    for (int rr = 0; rr < 32; ++rr) {
-      float av[TN], bv[TN];
+    int p = 0;
 #pragma unroll
-      for (int a = 0; a < TN; ++a) av[a] = Fs[rr][ty * TN + a];
+    for (int t1 = 0; t1 < NT; ++t1)
 #pragma unroll
-      for (int b = 0; b < TN; ++b) bv[b] = Fs[rr][tx * TN + b];
+      for (int t2 = t1; t2 < NT; ++t2, ++p)
 #pragma unroll
-      for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = fmaf(av[a], bv[b], acc[a][b]);
-    }
+        for (int i = 0; i < 16; ++i) g[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[t1][i], v[t2][i], g[p], 0, 0, 0);
   }
+  // sum the block's 4 waves through LDS (one 32x32 block at a time), write one partial per workgroup
+  __shared__ float red[4][16][64];
   float* out = partial + (int64_t)blockIdx.x * k * k;
+  int p = 0;
 #pragma unroll
-  for (int a = 0; a < TN; ++a)
+  for (int t1 = 0; t1 < NT; ++t1)
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      int ia = ty * TN + a, ib = tx * TN + b;
-      if (ia < k && ib < k) out[ia * k + ib] = acc[a][b];
+    for (int t2 = t1; t2 < NT; ++t2, ++p) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[wave][i][lane] = g[p][i];
+      __syncthreads();
+      // thread (wave, lane) finishes registers i = 4*wave .. 4*wave+3
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = 4 * wave + ii;
+        const float v = ((red[0][i][lane] + red[1][i][lane]) + red[2][i][lane]) + red[3][i][lane];
+        const int a = 32 * t1 + (i & 3) + 8 * (i >> 2) + 4 * h, b = 32 * t2 + c;
+        if (a < k && b < k) {
+          out[a * k + b] = v;
+          if (t1 != t2) out[b * k + a] = v;
+        }
+      }
     }
 }
 
-__global__ void __launch_bounds__(256) gram_reduce_kernel(const float* __restrict__ partial, int nblk, int kk2,
+// G[e] = sum over the workgroup partials in float64, fixed order: 8 threads per entry,
+// thread `sub` sums partials sub, sub+8, ... with 4 independent loads in flight, the 8
+// sub-sums are then combined in order.
+__global__ void __launch_bounds__(256) gram_reduce_kernel(const float* __restrict__ partial, int nparts, int kk2,
                                                           double* __restrict__ G) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= kk2) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(int64_t)b * kk2 + i];
-  G[i] = s;
+  __shared__ double red[8][32];
+  const int el = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (e < kk2) {
+    int b = sub;
+    for (; b + 24 < nparts; b += 32) {
+      const float v0 = partial[(int64_t)b * kk2 + e], v1 = partial[(int64_t)(b + 8) * kk2 + e];
+      const float v2 = partial[(int64_t)(b + 16) * kk2 + e], v3 = partial[(int64_t)(b + 24) * kk2 + e];
+      s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+    }
+    for (; b < nparts; b += 8) s0 += (double)partial[(int64_t)b * kk2 + e];
+  }
+  red[sub][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sub == 0 && e < kk2) {
+    double t = red[0][el];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) t += red[j][el];
+    G[e] = t;
+  }
 }
 
 hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStream_t s) {
-  const int nblk = gram_blocks(f.rows);
+  const int nparts = gram_blocks(f.rows);
   const int NT = (f.cols + 31) / 32;
   float* pf = reinterpret_cast<float*>(partial);
   switch (NT) {
-    case 1: gram_partial_kernel<1><<<nblk, 256, 0, s>>>(f, pf); break;
-    case 2: gram_partial_kernel<2><<<nblk, 256, 0, s>>>(f, pf); break;
-    case 3: gram_partial_kernel<3><<<nblk, 256, 0, s>>>(f, pf); break;
-    case 4: gram_partial_kernel<4><<<nblk, 256, 0, s>>>(f, pf); break;
+    case 1: gram_mfma_kernel<1><<<nparts, 256, 0, s>>>(f, pf); break;
+    case 2: gram_mfma_kernel<2><<<nparts, 256, 0, s>>>(f, pf); break;
+    case 3: gram_mfma_kernel<3><<<nparts, 256, 0, s>>>(f, pf); break;
+    case 4: gram_mfma_kernel<4><<<nparts, 256, 0, s>>>(f, pf); break;
     default: return hipErrorInvalidValue;
   }
   const int kk2 = f.cols * f.cols;
-  gram_reduce_kernel<<<(kk2 + 255) / 256, 256, 0, s>>>(pf, nblk, kk2, G);
+  gram_reduce_kernel<<<(kk2 + 31) / 32, 256, 0, s>>>(pf, nparts, kk2, G);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Fused epilogues (k % 4 == 0): one pass per factor after its sweep.
+//
+//   den = F * G  on the f32 MFMA.  A operand = F in "A layout": lane (r,h) holds
+//   F[row0 + r][(KP/2) h + j], j = 0..KP/2-1 (contiguous float4 loads); MFMA step s
+//   pairs column s with column s + KP/2 (the k order of an MFMA is free as long as
+//   B uses the same one): B[k=h][j=c] = G[s + (KP/2) h][32 t + c] from LDS.
+//   The element-wise update then runs in the MFMA C/D layout (lane (c,h), register
+//   i <-> row (i&3)+8(i>>2)+4h, column 32t+c), where the sweep's slabs, F itself and
+//   the result are all read/written as 128-B row segments.
+//
+//   Packing for the next sweep happens from the same registers: the f32 fragment
+//   order needs no data movement at all; the bf16 order (8 consecutive rows per
+//   lane) needs one v_permlane32_swap per register pair.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pack_bf16_pair(float a, float b) {
+  unsigned short ha = __builtin_bit_cast(unsigned short, (__bf16)a), hb = __builtin_bit_cast(unsigned short, (__bf16)b);
+  return (unsigned)ha | ((unsigned)hb << 16);
+}
+__device__ __forceinline__ float bf16_trunc_back(float a) {
+  unsigned short ha = __builtin_bit_cast(unsigned short, (__bf16)a);
+  return __uint_as_float(((unsigned)ha) << 16);
+}
+
+// un[t][16]: a 32-row tile in C/D layout -> packed fragments of rows [row0, row0+32)
+template <int NT, bool BF16>
+__device__ __forceinline__ void pack_tile_from_cd(const float (&un)[NT][16], int64_t row0, int lane, void* packed) {
+  if constexpr (BF16) {
+    uint4* out = reinterpret_cast<uint4*>(packed);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float e[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // lanes 32-63 of x swap with lanes 0-31 of y: afterwards lane (c,0) holds rows 0-3 | 4-7,
+          // lane (c,1) rows 8-11 | 12-15 of this 16-row block
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(un[t][8 * kb + i]), __float_as_uint(un[t][8 * kb + 4 + i]), false, false);
+          e[i] = __uint_as_float(sw[0]);
+          e[4 + i] = __uint_as_float(sw[1]);
+        }
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          hi[j] = pack_bf16_pair(e[2 * j], e[2 * j + 1]);
+          lo[j] = pack_bf16_pair(e[2 * j] - bf16_trunc_back(e[2 * j]), e[2 * j + 1] - bf16_trunc_back(e[2 * j + 1]));
+        }
+        const int64_t blk = ((row0 / 16 + kb) * NT + t) * 2;
+        out[blk * 64 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        out[(blk + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+      }
+  } else {
+    float4* out = reinterpret_cast<float4*>(packed);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        out[((row0 / 8 + g) * NT + t) * 64 + lane] = make_float4(un[t][4 * g], un[t][4 * g + 1], un[t][4 * g + 2], un[t][4 * g + 3]);
+  }
+}
+
+// den[t] = (F tile) * G  for one 32-row tile; Gs = G in LDS, [KP][KP] floats (rows/cols >= k are zero)
+template <int NT>
+__device__ __forceinline__ void tile_times_gram(const float* __restrict__ F, int64_t rows, int k, int64_t row0, int lane,
+                                                const float* __restrict__ Gs, f32x16 (&den)[NT]) {
+  constexpr int KP = 32 * NT, HALF = KP / 2;
+  const int r = lane & 31, h = lane >> 5;
+  float ua[HALF];
+  const int64_t row = row0 + r;
+#pragma unroll
+  for (int q = 0; q < HALF / 4; ++q) {
+    const int col = HALF * h + 4 * q;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < rows && col < k) v = *reinterpret_cast<const float4*>(F + row * k + col);
+    ua[4 * q] = v.x; ua[4 * q + 1] = v.y; ua[4 * q + 2] = v.z; ua[4 * q + 3] = v.w;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) den[t][i] = 0.f;
+#pragma unroll
+  for (int s2 = 0; s2 < HALF; ++s2)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      den[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[s2], Gs[(s2 + HALF * h) * KP + 32 * t + r], den[t], 0, 0, 0);
+}
+
+template <int NT>
+__device__ __forceinline__ void stage_gram(const double* __restrict__ G, int k, int col0, int ncols, float* Gs) {
+  constexpr int KP = 32 * NT;
+  for (int i = threadIdx.x; i < KP * KP; i += blockDim.x) {
+    const int q = i / KP, c = i - q * KP;
+    Gs[i] = (q < k && c < ncols) ? (float)G[q * k + col0 + c] : 0.f;
+  }
+}
+
+template <int NT, bool BF16>
+__global__ void __launch_bounds__(256)
+u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs, const int* __restrict__ nseg,
+                  int panel_rows, int64_t slab_stride, const double* __restrict__ Gv, void* __restrict__ packed,
+                  int64_t ntiles_pack) {
+  constexpr int KP = 32 * NT;
+  __shared__ float Gs[KP * KP];
+  stage_gram<NT>(Gv, k, 0, k, Gs);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t wstride = (int64_t)gridDim.x * 4;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles_pack; tile += wstride) {
+    const int64_t row0 = tile * 32;
+    f32x16 den[NT];
+    float un[NT][16];
+    if (row0 < m) {
+      tile_times_gram<NT>(U, m, k, row0, lane, Gs, den);
+      const int ns = nseg[row0 / panel_rows];
+      // all loads of the tile are issued as independent batches (segment-outermost): a per-element
+      // loop over the segments would serialise 32 x ns dependent round trips
+      float p[NT][16], uu[NT][16];
+      int64_t off[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        off[i] = row < m ? row : m - 1;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = 32 * t + c;
+        const int colc = col < k ? col : k - 1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          uu[t][i] = U[off[i] * k + colc];
+          p[t][i] = 0.f;
+        }
+      }
+      for (int sg = 0; sg < ns; ++sg) {
+        const float* sl = slabs + (int64_t)sg * slab_stride;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) p[t][i] += sl[off[i] * KP + 32 * t + c];
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = 32 * t + c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          float r2 = 0.f;
+          if (row < m && col < k) {
+            const float d = den[t][i] + uu[t][i];            // U (V^T V) + U      (prmf_runner.py:421)
+            r2 = uu[t][i] * ((d != 0.f) ? p[t][i] / d : 1.f); // 0/0 := 1           (:422)
+            U[row * k + col] = r2;
+          }
+          un[t][i] = r2;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) un[t][i] = 0.f;
+    }
+    pack_tile_from_cd<NT, BF16>(un, row0, lane, packed);
+  }
+}
+
+hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const int* nseg, int panel_rows,
+                             int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
+                             hipStream_t s) {
+  const int NT = KP / 32;
+  const int64_t ntiles = Kpad / 32;          // every tile of the packed buffer is (re)written, zero beyond m
+  int grid = (int)((ntiles + 3) / 4 < 1024 ? (ntiles + 3) / 4 : 1024);
+#define PRMF_UEP(NTV)                                                                                              \
+  if (x_dtype == 1) u_epilogue_kernel<NTV, true><<<grid, 256, 0, s>>>(U, m, k, slabs, nseg, panel_rows, slab_stride, Gv, packed, ntiles); \
+  else u_epilogue_kernel<NTV, false><<<grid, 256, 0, s>>>(U, m, k, slabs, nseg, panel_rows, slab_stride, Gv, packed, ntiles)
+  switch (NT) {
+    case 1: PRMF_UEP(1); break;
+    case 2: PRMF_UEP(2); break;
+    case 3: PRMF_UEP(3); break;
+    case 4: PRMF_UEP(4); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef PRMF_UEP
+  return hipGetLastError();
+}
+
+// Single-rank V epilogue: V <- V * (Q + g_num) / max(V (U^T U) + g_den, eps), clamp
+// (prmf_runner.py:424-444), in place, + packing + per-wave partial column sums of
+// squares and <Q, V_new> (float64).
+template <int NT, bool BF16>
+__global__ void __launch_bounds__(256)
+v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ slabs, const int* __restrict__ nseg,
+                  int panel_rows, int64_t slab_stride, const double* __restrict__ Gu, const int32_t* __restrict__ pos,
+                  const float* __restrict__ gnum, const float* __restrict__ gden, int max_support,
+                  void* __restrict__ packed, int64_t ntiles_pack, double* __restrict__ partial /*[waves][k+1]*/) {
+  constexpr int KP = 32 * NT;
+  __shared__ float Gs[KP * KP];
+  stage_gram<NT>(Gu, k, 0, k, Gs);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t wstride = (int64_t)gridDim.x * 4;
+  double colsq[NT], cross = 0.0;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) colsq[t] = 0.0;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles_pack; tile += wstride) {
+    const int64_t row0 = tile * 32;
+    f32x16 den[NT];
+    float vn[NT][16];
+    if (row0 < n) {
+      tile_times_gram<NT>(V, n, k, row0, lane, Gs, den);
+      const int ns = nseg[row0 / panel_rows];
+      float q[NT][16], vv[NT][16];
+      int ps[NT][16];
+      int64_t off[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        off[i] = row < n ? row : n - 1;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = 32 * t + c;
+        const int colc = col < k ? col : k - 1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          vv[t][i] = V[off[i] * k + colc];
+          ps[t][i] = pos[off[i] * k + colc];
+          q[t][i] = 0.f;
+        }
+      }
+      for (int sg = 0; sg < ns; ++sg) {
+        const float* sl = slabs + (int64_t)sg * slab_stride;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) q[t][i] += sl[off[i] * KP + 32 * t + c];
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = 32 * t + c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          float r2 = 0.f;
+          if (row < n && col < k) {
+            float num = q[t][i], d = den[t][i];
+            if (ps[t][i] >= 0) {
+              num += gnum[(int64_t)col * max_support + ps[t][i]];
+              d += gden[(int64_t)col * max_support + ps[t][i]];
+            }
+            if (d < PRMF_EPS) d = PRMF_EPS;
+            r2 = vv[t][i] * (num / d);
+            if (r2 < PRMF_EPS) r2 = PRMF_EPS;
+            V[row * k + col] = r2;
+            colsq[t] += (double)r2 * (double)r2;
+            cross += (double)q[t][i] * (double)r2;
+          }
+          vn[t][i] = r2;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vn[t][i] = 0.f;
+    }
+    pack_tile_from_cd<NT, BF16>(vn, row0, lane, packed);
+  }
+  // per-wave partials: column sums from the two half-waves, cross over all lanes (fixed order)
+  double* out = partial + ((int64_t)blockIdx.x * 4 + wave) * (k + 1);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const double tot = colsq[t] + __shfl_xor(colsq[t], 32);
+    if (h == 0 && 32 * t + c < k) out[32 * t + c] = tot;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cross += __shfl_xor(cross, off);
+  if (lane == 0) out[k] = cross;
+}
+
+int v_epilogue_waves(int64_t n) {
+  int64_t tiles = (n + 31) / 32;
+  int64_t blocks = (tiles + 3) / 4;
+  if (blocks > 512) blocks = 512;
+  return (int)blocks * 4;
+}
+
+hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const int* nseg, int panel_rows,
+                             int64_t slab_stride, int KP, const double* Gu, const int32_t* pos, const float* gnum,
+                             const float* gden, int max_support, int x_dtype, void* packed, int64_t Kpad,
+                             double* partial, hipStream_t s) {
+  const int NT = KP / 32;
+  const int64_t ntiles = Kpad / 32;
+  // the grid must match v_epilogue_waves(n): every partial row is written by exactly one wave
+  const int grid = v_epilogue_waves(n) / 4;
+#define PRMF_VEP(NTV)                                                                                               \
+  if (x_dtype == 1) v_epilogue_kernel<NTV, true><<<grid, 256, 0, s>>>(V, n, k, slabs, nseg, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial); \
+  else v_epilogue_kernel<NTV, false><<<grid, 256, 0, s>>>(V, n, k, slabs, nseg, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial)
+  switch (NT) {
+    case 1: PRMF_VEP(1); break;
+    case 2: PRMF_VEP(2); break;
+    case 3: PRMF_VEP(3); break;
+    case 4: PRMF_VEP(4); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef PRMF_VEP
   return hipGetLastError();
 }
 
@@ -176,23 +536,24 @@ hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStrea
 // Q slabs -> per-owner column blocks  q_send[r][j][c],  column kk = r*kc + c
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-slab_sum_blocks_kernel(const float* __restrict__ slabs, int splits, int64_t slab_stride, int KP, int64_t n, int k,
-                       int kc, float* __restrict__ q_send) {
+slab_sum_blocks_kernel(const float* __restrict__ slabs, const int* __restrict__ nseg, int panel_rows,
+                       int64_t slab_stride, int KP, int64_t n, int k, int kc, float* __restrict__ q_send) {
   int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n * k) return;
   int64_t j = idx / k;
   int kk = (int)(idx - j * k);
   float v = 0.f;
-  for (int s = 0; s < splits; ++s) v += slabs[(int64_t)s * slab_stride + j * KP + kk];
+  const int ns = nseg[j / panel_rows];
+  for (int s = 0; s < ns; ++s) v += slabs[(int64_t)s * slab_stride + j * KP + kk];
   int r = kk / kc, c = kk - r * kc;
   q_send[((int64_t)r * n + j) * kc + c] = v;
 }
 
-hipError_t launch_slab_sum_blocks(const float* slabs, int splits, int64_t slab_stride, int KP, int64_t n, int k, int kc,
-                                  int nranks, float* q_send, hipStream_t s) {
+hipError_t launch_slab_sum_blocks(const float* slabs, const int* nseg, int panel_rows, int64_t slab_stride, int KP,
+                                  int64_t n, int k, int kc, int nranks, float* q_send, hipStream_t s) {
   (void)nranks;
   int64_t total = n * k;
-  slab_sum_blocks_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(slabs, splits, slab_stride, KP, n, k, kc, q_send);
+  slab_sum_blocks_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(slabs, nseg, panel_rows, slab_stride, KP, n, k, kc, q_send);
   return hipGetLastError();
 }
 
