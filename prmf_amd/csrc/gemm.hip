@@ -160,80 +160,47 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], const u32x4
   }
 }
 
-// ---- hand-issued global loads --------------------------------------------------
-// hipcc sinks ordinary loads to their first use (right in front of the ds_write
-// that consumes them), which serialises load latency and compute.  The sweep
-// therefore issues its global loads itself, at the top of each step (volatile asm
-// keeps them there), and retires them with one s_waitcnt vmcnt(0) after the MFMAs
-// of the step.  A counted vmcnt(N) that leaves the newest loads in flight was
-// measured UNSAFE here: global_load completion is not strictly in issue order on
-// gfx950 (about 1e-5 of the wave-steps saw an older A load still outstanding with
-// only the N youngest pending -> a wrong 32-row tile per launch), so the design
-// does not rely on completion order; latency is covered by occupancy instead.
-// Every destination register is named "+v" in the wait statement, so no consumer
-// can be scheduled above it (cdna_hip_programming.md 5.7, form (ii)).
-//   address = SGPR base (uniform) + 32-bit lane offset
-__device__ __forceinline__ void gload16(u32x4& dst, unsigned voff, const void* sbase) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase));
-}
-
-template <int NB, int MT>
-__device__ __forceinline__ void wait_all_loads(u32x4 (&b)[NB], u32x4 (&a)[MT][4]) {
-  static_assert(NB == 1 || NB == 2 || NB == 3 || NB == 4 || NB == 6 || NB == 8, "unsupported B staging width");
-  static_assert(MT == 1 || MT == 2, "unsupported MT");
-  // clang-format off
-#define PRMF_B1 "+v"(b[0])
-#define PRMF_B2 PRMF_B1, "+v"(b[1])
-#define PRMF_B3 PRMF_B2, "+v"(b[2])
-#define PRMF_B4 PRMF_B3, "+v"(b[3])
-#define PRMF_B6 PRMF_B4, "+v"(b[4]), "+v"(b[5])
-#define PRMF_B8 PRMF_B6, "+v"(b[6]), "+v"(b[7])
-#define PRMF_A1 "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3])
-#define PRMF_A2 PRMF_A1, "+v"(a[MT - 1][0]), "+v"(a[MT - 1][1]), "+v"(a[MT - 1][2]), "+v"(a[MT - 1][3])
-#define PRMF_WAIT(BL, AL) asm volatile("s_waitcnt vmcnt(0)" : BL, AL)
-  if constexpr (MT == 1) {
-    if constexpr (NB == 1) PRMF_WAIT(PRMF_B1, PRMF_A1); else if constexpr (NB == 2) PRMF_WAIT(PRMF_B2, PRMF_A1);
-    else if constexpr (NB == 3) PRMF_WAIT(PRMF_B3, PRMF_A1); else if constexpr (NB == 4) PRMF_WAIT(PRMF_B4, PRMF_A1);
-    else if constexpr (NB == 6) PRMF_WAIT(PRMF_B6, PRMF_A1); else PRMF_WAIT(PRMF_B8, PRMF_A1);
-  } else {
-    if constexpr (NB == 1) PRMF_WAIT(PRMF_B1, PRMF_A2); else if constexpr (NB == 2) PRMF_WAIT(PRMF_B2, PRMF_A2);
-    else if constexpr (NB == 3) PRMF_WAIT(PRMF_B3, PRMF_A2); else if constexpr (NB == 4) PRMF_WAIT(PRMF_B4, PRMF_A2);
-    else if constexpr (NB == 6) PRMF_WAIT(PRMF_B6, PRMF_A2); else PRMF_WAIT(PRMF_B8, PRMF_A2);
-  }
-#undef PRMF_WAIT
-  // clang-format on
-}
+// ---- loads ----------------------------------------------------------------------
+// The next chunk's A lines and B slice are loaded (plain loads) right after the MFMAs
+// of the current chunk and written to LDS as soon as they arrive; the latency is
+// covered by the other resident workgroup(s) of the CU, not by a software pipeline.
+// History (kept because it cost a day): a deeper pipeline with hand-issued asm loads
+// and counted `s_waitcnt vmcnt(N)` (newest loads left in flight) was (a) not faster at
+// this occupancy and (b) UNSAFE: at 50000x20000 about 1e-5 of the wave-steps saw an
+// OLDER load still outstanding with only the N youngest pending -> 2-4 wrong 32-row
+// tiles per launch, different every run.  With vmcnt(0)-style full waits the results
+// are bit-identical run to run.  The design therefore never relies on the completion
+// order of global loads.
 
 template <int MT>
-__device__ __forceinline__ void load_a_chunk(u32x4 (&dst)[MT][4], const unsigned (&voff)[MT][4], const uint4* sbase) {
+__device__ __forceinline__ void load_a_chunk(u32x4 (&dst)[MT][4], const unsigned (&voff)[MT][4], const uint4* base) {
+  const char* b = reinterpret_cast<const char*>(base);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) gload16(dst[mt][i], voff[mt][i], sbase);
+    for (int i = 0; i < 4; ++i) dst[mt][i] = *reinterpret_cast<const u32x4*>(b + voff[mt][i]);
 }
 
+// thread tid takes uint4 #tid of every NTHREADS*16-byte slice of the packed chunk (the last slice may be partial)
 template <int NB, int NTHREADS, int BCH>
-__device__ __forceinline__ void load_b_chunk(u32x4 (&dst)[NB], unsigned voff, const uint4* sbase, int tid) {
-  // thread tid takes uint4 #tid of every NTHREADS*16-byte slice of the packed chunk
+__device__ __forceinline__ void load_b_chunk(u32x4 (&dst)[NB], const uint4* base, int tid) {
+  const u32x4* b = reinterpret_cast<const u32x4*>(base);
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    if ((i + 1) * NTHREADS <= BCH || tid + NTHREADS * i < BCH) gload16(dst[i], voff, sbase + NTHREADS * i);
-  }
+  for (int i = 0; i < NB; ++i)
+    if ((i + 1) * NTHREADS <= BCH || tid + NTHREADS * i < BCH) dst[i] = b[tid + NTHREADS * i];
 }
 
 template <int NB, int NTHREADS, int BCH>
 __device__ __forceinline__ void store_b_chunk(u32x4* sb, const u32x4 (&src)[NB], int tid) {
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
+  for (int i = 0; i < NB; ++i)
     if ((i + 1) * NTHREADS <= BCH || tid + NTHREADS * i < BCH) sb[tid + NTHREADS * i] = src[i];
-  }
 }
 
 // One workgroup = NW waves x MT 32-row tiles (a panel of 32*MT*NW rows) and one
 // contiguous range of reduction chunks (a "split").  Per chunk c:
-//     issue   B(c+1) -> bs,  A(c+1) -> a      (clamped to the split's last chunk)
 //     compute chunk c: A fragments from the wave's LDS tile, B from LDS
-//     wait    vmcnt(0)
+//     load    B(c+1) -> bs,  A(c+1) -> a      (clamped to the segment's last chunk)
 //     write   bs -> LDS (other buffer if BDB, else after a barrier) ; a -> the wave's A tile
 //     barrier
 // BDB = true : B double-buffered in LDS, one barrier per chunk
@@ -276,7 +243,6 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
       const int piece = (lane & 7) ^ ((lr >> 1) & 7);               // source-side swizzle
       avoff[mt][i] = (unsigned)(((int64_t)(wave * (32 * MT) + 32 * mt + lr) * lda16 + piece) * 16);
     }
-  const unsigned bvoff = (unsigned)tid * 16u;
   u32x4* const myA = sA[wave];
 
   while (unit < unit_end) {
@@ -307,9 +273,8 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   u32x4 bs[BPT];
 
   // prologue: B(0), A(0) -> LDS
-  load_b_chunk<BPT, NTHR, BCH>(bs, bvoff, bbase, tid);
+  load_b_chunk<BPT, NTHR, BCH>(bs, bbase, tid);
   load_a_chunk<MT>(a, avoff, abase);
-  wait_all_loads<BPT, MT>(bs, a);
   store_b_chunk<BPT, NTHR, BCH>(sB[0], bs, tid);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -321,10 +286,9 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int cn = min(c + u + 1, last);
-      load_b_chunk<BPT, NTHR, BCH>(bs, bvoff, bbase + (int64_t)cn * BCH, tid);
-      load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
       sweep_compute<BF16, MT, NT>(acc, myA, sB[BDB ? u : 0], lane);
-      wait_all_loads<BPT, MT>(bs, a);
+      load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
+      load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
       if constexpr (!BDB) __syncthreads();          // everyone has finished reading B(c)
       store_b_chunk<BPT, NTHR, BCH>(sB[BDB ? (u ^ 1) : 0], bs, tid);
 #pragma unroll

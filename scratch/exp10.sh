@@ -1,0 +1,6 @@
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python scratch/race_probe.py 2>&1 | grep -E "differs|FPE" | head -4
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('c3', d['value'], d['roofline']['ms_xv'], d['roofline']['ms_xtu'], d['roofline']['frac'])"
+python bench.py --workload c2 --steps 200 --warmup 20 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('c2', d['value'], d['ms_per_step'], d['roofline']['ms_xv'], d['roofline']['ms_xtu'], d['roofline']['frac'])"
