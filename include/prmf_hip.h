@@ -174,6 +174,24 @@ int prmf_phase_post(prmf_ctx* ctx, void* stream);
  * (synchronises `stream`). */
 int prmf_end(prmf_ctx* ctx, int n_steps, double* obj_out, double* gamma_delta_out, void* stream);
 
+/* ------------------------------------------------------------------------
+ * The same multi-rank iteration with the collectives issued by the library itself
+ * (RCCL, resolved with dlopen("librccl.so.1") at prmf_comm_init; enqueued on the
+ * caller's stream between the phases), so that n_steps iterations run without any
+ * host round trip.  Bootstrap: rank 0 calls prmf_comm_unique_id and sends the 128
+ * bytes to the other ranks by any host channel (the Python host broadcasts them with
+ * torch.distributed); every rank then calls prmf_comm_init.  Communication buffers
+ * are allocated by the library unless prmf_set_comm_buffers was called.
+ * ---------------------------------------------------------------------- */
+#define PRMF_COMM_ID_BYTES 128
+int prmf_comm_unique_id(void* id_out /* PRMF_COMM_ID_BYTES */);
+int prmf_comm_init(prmf_ctx* ctx, const void* id /* PRMF_COMM_ID_BYTES */);
+/* multi-rank prmf_step: same arguments and results (every rank gets the same
+ * objective records); requires prmf_comm_init.  Also valid with nranks == 1. */
+int prmf_step_dist(prmf_ctx* ctx, float* dU, float* dV, int n_steps,
+                   double gamma, double delta, double tradeoff,
+                   double* obj_out, double* gamma_delta_out, void* stream);
+
 /*
  * Candidate scoring for `restrict` (prmf_runner.py:129-194 / :115-127):
  * scores_out[kk*P + p] = ||vhat_kk[S_p]||_2 + 1 - vhat_kk^T Lhat_p vhat_kk for

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libprmf_hip.so")
 SOURCES = ["gemm.hip", "update.hip", "capi.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I/opt/rocm/include"]
 
 
 def hipcc():
@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs,
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stderr)

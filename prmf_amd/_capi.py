@@ -14,6 +14,7 @@ PRMF_ABI_VERSION = 1
 PRMF_X_F32, PRMF_X_BF16 = 0, 1
 PRMF_OBJ_STRIDE = 8
 PRMF_FLAG_TIMING = 0x1
+PRMF_COMM_ID_BYTES = 128
 OBJ_KEYS = ("recon", "manifold", "ignore", "fro", "gamma", "delta", "obj")
 
 PRMF_OK = 0
@@ -52,6 +53,9 @@ SIGNATURES = {
     "prmf_phase_v": (_i, [_vp, _vp]),
     "prmf_phase_post": (_i, [_vp, _vp]),
     "prmf_end": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "prmf_comm_unique_id": (_i, [_vp]),
+    "prmf_comm_init": (_i, [_vp, _vp]),
+    "prmf_step_dist": (_i, [_vp, _vp, _vp, _i, _d, _d, _d, _vp, _vp, _vp]),
     "prmf_score_candidates": (_i, [_vp, _vp, _vp, _vp]),
     "prmf_get_sweep_info": (_i, [_vp, C.POINTER(SweepInfo)]),
     "prmf_set_timing": (_i, [_vp, _i]),

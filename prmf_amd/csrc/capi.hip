@@ -3,6 +3,9 @@
 #include "../../include/prmf_hip.h"
 #include "kernels.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -67,7 +70,7 @@ struct prmf_ctx {
   double* colres = nullptr;           // [kc][2]
   double* vpartial = nullptr;         // [v_update_blocks][kc+1]
   int vblocks = 0;
-  bool fused_u = false, fused_v = false;   // MFMA epilogues (k % 4 == 0; V path single-rank only)
+  bool fused_u = false, fused_v = false, gram_v_done = false;   // MFMA epilogues (k % 4 == 0; V path single-rank only)
 
   // hyper-parameters + records
   double* hyper = nullptr;            // device: gamma, delta, tradeoff
@@ -86,6 +89,9 @@ struct prmf_ctx {
   double ms_xv = 0, ms_xtu = 0, ms_total = 0;
   int timed_iters = 0;
 
+  // RCCL (resolved at run time, see prmf_comm_init)
+  ncclComm_t comm = nullptr;
+
   // scoring scratch
   double* colnorm = nullptr;
   double* scores_dev = nullptr;
@@ -93,6 +99,40 @@ struct prmf_ctx {
 };
 
 namespace {
+
+// RCCL entry points, bound with dlopen so that the library itself has no link-time
+// dependency (PyTorch-ROCm ships librccl.so.1; the copy already mapped by torch is reused).
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+RcclApi& rccl() {
+  static RcclApi api = [] {
+    RcclApi a;
+    a.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!a.handle) a.handle = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!a.handle) return a;
+#define PRMF_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.handle, name))
+    PRMF_SYM(GetUniqueId, "ncclGetUniqueId");
+    PRMF_SYM(CommInitRank, "ncclCommInitRank");
+    PRMF_SYM(CommDestroy, "ncclCommDestroy");
+    PRMF_SYM(AllReduce, "ncclAllReduce");
+    PRMF_SYM(ReduceScatter, "ncclReduceScatter");
+    PRMF_SYM(AllGather, "ncclAllGather");
+    PRMF_SYM(GetErrorString, "ncclGetErrorString");
+#undef PRMF_SYM
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.ReduceScatter && a.AllGather && a.GetErrorString;
+    return a;
+  }();
+  return api;
+}
 
 int fail(prmf_ctx* c, int code, const char* fmt, ...) {
   va_list ap;
@@ -155,13 +195,19 @@ int check_ready(prmf_ctx* c) {
 
 int ensure_own_comm(prmf_ctx* c) {
   if (c->gram_buf) return PRMF_OK;
-  if (c->nranks != 1) return fail(c, PRMF_ERR_STATE, "nranks > 1 needs caller-allocated communication buffers");
+  if (c->nranks != 1 && !c->comm)
+    return fail(c, PRMF_ERR_STATE, "nranks > 1 needs prmf_set_comm_buffers (host-driven collectives) or prmf_comm_init");
   int rc;
   if ((rc = dev_alloc(c, &c->gram_buf, (size_t)c->k * c->k))) return rc;
-  if ((rc = dev_alloc(c, &c->q_send, (size_t)c->n * c->kc))) return rc;
+  if ((rc = dev_alloc(c, &c->q_send, (size_t)c->n * c->kc * c->nranks))) return rc;
   if ((rc = dev_alloc(c, &c->v_send, (size_t)c->v_send_floats))) return rc;
-  c->q_recv = c->q_send;
-  c->v_recv = c->v_send;
+  if (c->nranks == 1) {
+    c->q_recv = c->q_send;
+    c->v_recv = c->v_send;
+  } else {
+    if ((rc = dev_alloc(c, &c->q_recv, (size_t)c->n * c->kc))) return rc;
+    if ((rc = dev_alloc(c, &c->v_recv, (size_t)c->v_send_floats * c->nranks))) return rc;
+  }
   c->own_comm = true;
   return PRMF_OK;
 }
@@ -219,8 +265,9 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   const int n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->plan_xv = plan_gemm(x_dtype, m_local > 0 ? m_local : 1, c->Kpad_x, c->NT, n_cus);
   c->plan_xtu = plan_gemm(x_dtype, n, c->Kpad_xt, c->NT, n_cus);
-  c->slab_stride_p = (m_local > 0 ? m_local : 1) * (int64_t)c->KP;
-  c->slab_stride_q = n * (int64_t)c->KP;
+  // slabs are written as whole 32-row tiles of whole panels (fragment order, no row masking)
+  c->slab_stride_p = (int64_t)c->plan_xv.panels * c->plan_xv.panel_rows * c->KP;
+  c->slab_stride_q = (int64_t)c->plan_xtu.panels * c->plan_xtu.panel_rows * c->KP;
   int64_t slab_floats = c->slab_stride_p * c->plan_xv.max_seg;
   if (c->slab_stride_q * c->plan_xtu.max_seg > slab_floats) slab_floats = c->slab_stride_q * c->plan_xtu.max_seg;
   if ((rc = dev_alloc(c, &c->nseg_xv, c->plan_xv.nseg.size(), false))) return bail(rc);
@@ -235,6 +282,7 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, (char**)&c->Up, (size_t)packed_bytes(c, c->Kpad_xt)))) return bail(rc);
   if ((rc = dev_alloc(c, &c->slabs, (size_t)slab_floats, false))) return bail(rc);
   int gb = gram_blocks(m_local > n ? m_local : n);
+  if (gb < 256) gb = 256;                      // the fused epilogues write up to 256 per-workgroup partials
   if ((rc = dev_alloc(c, (float**)&c->gram_partial, (size_t)gb * k * k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->Gv, (size_t)k * k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->active_dev, (size_t)k))) return bail(rc);
@@ -275,7 +323,12 @@ int prmf_destroy(prmf_ctx* c) {
     dev_free(c->gram_buf);
     dev_free(c->q_send);
     dev_free(c->v_send);
+    if (c->nranks > 1) {
+      dev_free(c->q_recv);
+      dev_free(c->v_recv);
+    }
   }
+  if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
   for (void* p : c->lib_allocs) dev_free(p);
   dev_free(c->active_dev);
   dev_free(c->pos);
@@ -431,6 +484,10 @@ int prmf_set_comm_buffers(prmf_ctx* c, double* gram, float* q_send, float* q_rec
     dev_free(c->gram_buf);
     dev_free(c->q_send);
     dev_free(c->v_send);
+    if (c->nranks > 1) {
+      dev_free(c->q_recv);
+      dev_free(c->v_recv);
+    }
     c->own_comm = false;
   }
   c->gram_buf = gram;
@@ -480,8 +537,13 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
     // U <- U * P / (U Gv + U)                              (:421-422)
     FactorView fu{c->U, (int)c->m, c->k, c->k, 0};
     if (c->fused_u) {
+      bool gram_done = false;
       HIP_TRY(c, launch_u_epilogue(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP,
-                                   c->Gv, c->x_dtype, c->Up, c->Kpad_xt, s));
+                                   c->Gv, c->x_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, s));
+      if (gram_done) {
+        HIP_TRY(c, launch_gram_reduce((const float*)c->gram_partial, epilogue_blocks(c->Kpad_xt), c->k, c->gram_buf, s));
+        return PRMF_OK;
+      }
     } else {
       HIP_TRY(c, launch_u_update(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP, c->Gv, s));
       HIP_TRY(c, launch_pack_factor(fu, c->x_dtype, c->NT, c->Kpad_xt, c->Up, s));
@@ -526,7 +588,7 @@ int prmf_phase_v(prmf_ctx* c, void* stream) {
     // single rank: V updated in place straight from the sweep's slabs, packed for the next sweep in the same pass
     HIP_TRY(c, launch_v_epilogue(c->V, c->n, c->k, c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP,
                                  c->gram_buf, c->pos, c->gnum, c->gden, c->lib.max_support, c->x_dtype, c->Vp, c->Kpad_x,
-                                 c->vpartial, s));
+                                 c->vpartial, (float*)c->gram_partial, &c->gram_v_done, s));
     HIP_TRY(c, launch_objective_terms(c->lib, c->active_dev, 0, c->k, c->k, c->n, c->V, c->vpartial, c->vblocks, c->colres,
                                       c->obj_scratch, extras, s));
     return PRMF_OK;
@@ -549,7 +611,10 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
     HIP_TRY(c, launch_assemble_v(c->v_recv, c->nranks, c->v_send_floats, c->kc, c->n, c->k, c->V, s));
     HIP_TRY(c, launch_pack_factor(fv, c->x_dtype, c->NT, c->Kpad_x, c->Vp, s));
   }
-  HIP_TRY(c, launch_gram(fv, c->gram_partial, c->Gv, s));
+  if (c->fused_v && c->gram_v_done)
+    HIP_TRY(c, launch_gram_reduce((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x), c->k, c->Gv, s));
+  else
+    HIP_TRY(c, launch_gram(fv, c->gram_partial, c->Gv, s));
   HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->nranks, c->v_send_floats, c->extras_off,
                              c->norm_x_sq, c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, s));
   c->cursor++;
@@ -613,6 +678,74 @@ int prmf_step(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma, doub
     delta = gd[1];
     done += batch;
     if (n_steps == 0) break;
+  }
+  if (gamma_delta_out) {
+    gamma_delta_out[0] = gamma;
+    gamma_delta_out[1] = delta;
+  }
+  return PRMF_OK;
+}
+
+int prmf_comm_unique_id(void* id_out) {
+  if (!id_out) return fail(nullptr, PRMF_ERR_ARG, "id_out is NULL");
+  if (!rccl().ok) return fail(nullptr, PRMF_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded: %s", dlerror());
+  static_assert(sizeof(ncclUniqueId) == PRMF_COMM_ID_BYTES, "unique id size");
+  ncclUniqueId id;
+  ncclResult_t r = rccl().GetUniqueId(&id);
+  if (r != ncclSuccess) return fail(nullptr, PRMF_ERR_HIP, "ncclGetUniqueId: %s", rccl().GetErrorString(r));
+  std::memcpy(id_out, &id, sizeof id);
+  return PRMF_OK;
+}
+
+int prmf_comm_init(prmf_ctx* c, const void* id_in) {
+  if (!c || !id_in) return PRMF_ERR_ARG;
+  if (!rccl().ok) return fail(c, PRMF_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded");
+  if (c->comm) return fail(c, PRMF_ERR_STATE, "communicator already initialised");
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  ncclUniqueId id;
+  std::memcpy(&id, id_in, sizeof id);
+  ncclResult_t r = rccl().CommInitRank(&c->comm, c->nranks, id, c->rank);
+  if (r != ncclSuccess) {
+    c->comm = nullptr;
+    return fail(c, PRMF_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", c->rank, c->nranks, rccl().GetErrorString(r));
+  }
+  return PRMF_OK;
+}
+
+#define NCCL_TRY(ctx, expr)                                                                          \
+  do {                                                                                               \
+    ncclResult_t _r = (expr);                                                                        \
+    if (_r != ncclSuccess) return fail(ctx, PRMF_ERR_HIP, "%s: %s", #expr, rccl().GetErrorString(_r)); \
+  } while (0)
+
+int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma, double delta, double tradeoff,
+                   double* obj_out, double* gamma_delta_out, void* stream) {
+  if (!c) return PRMF_ERR_ARG;
+  if (!c->comm) return fail(c, PRMF_ERR_STATE, "prmf_comm_init has not been called");
+  if (n_steps < 0) return fail(c, PRMF_ERR_ARG, "n_steps < 0");
+  hipStream_t s = (hipStream_t)stream;
+  const RcclApi& N = rccl();
+  int done = 0, rc;
+  while (done < n_steps) {
+    const int batch = n_steps - done < MAX_RECORDS ? n_steps - done : MAX_RECORDS;
+    if ((rc = prmf_begin(c, dU, dV, gamma, delta, tradeoff, stream))) return rc;
+    for (int i = 0; i < batch; ++i) {
+      if ((rc = prmf_phase_u(c, stream))) return rc;
+      NCCL_TRY(c, N.AllReduce(c->gram_buf, c->gram_buf, (size_t)c->k * c->k, ncclFloat64, ncclSum, c->comm, s));
+      if ((rc = prmf_phase_q(c, stream))) return rc;
+      if (c->nranks > 1 || c->q_recv != c->q_send)
+        NCCL_TRY(c, N.ReduceScatter(c->q_send, c->q_recv, (size_t)c->n * c->kc, ncclFloat32, ncclSum, c->comm, s));
+      if ((rc = prmf_phase_v(c, stream))) return rc;
+      if (c->nranks > 1 || c->v_recv != c->v_send)
+        NCCL_TRY(c, N.AllGather(c->v_send, c->v_recv, (size_t)c->v_send_floats, ncclFloat32, c->comm, s));
+      if ((rc = prmf_phase_post(c, stream))) return rc;
+    }
+    double gd[2] = {gamma, delta};
+    if ((rc = prmf_end(c, batch, obj_out ? obj_out + (size_t)done * PRMF_OBJ_STRIDE : nullptr, gd, stream))) return rc;
+    gamma = gd[0];
+    delta = gd[1];
+    done += batch;
   }
   if (gamma_delta_out) {
     gamma_delta_out[0] = gamma;

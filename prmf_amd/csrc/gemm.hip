@@ -213,7 +213,6 @@ __global__ void __launch_bounds__(64 * NW)
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
              const uint4* __restrict__ Bp, int npanels, int ngroups /* chunk pairs per row */,
              float* __restrict__ slabs, int64_t slab_stride) {
-  constexpr int KP = 32 * NT;
   constexpr int NTHR = 64 * NW;
   constexpr int BCH = BF16 ? 512 * NT : 256 * NT;   // uint4 per packed chunk
   constexpr int BPT = (BCH + NTHR - 1) / NTHR;      // uint4 staged per thread per chunk (last one may be partial)
@@ -221,7 +220,6 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   __shared__ u32x4 sA[NW][MT * 256];                // per wave: MT tiles of 32 rows x 128 B
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
 
   // Balanced persistent decomposition: the launch has one workgroup per resident
   // slot; the npanels x ngroups units (a unit = 2 chunks of one row panel) are cut
@@ -299,18 +297,21 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
     }
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*h
-  float* out = slabs + (int64_t)seg * slab_stride;
+  // epilogue: the accumulators go out in FRAGMENT order -- slab[seg][tile32][t][lane][16 floats],
+  // the 16 registers of a lane contiguous (4 x 16-B stores per tile, fully coalesced); the
+  // consumers read them back the same way.  Element (row, col) of a slab:
+  //   tile = row/32, rr = row%32, lane = col%32 + 32*((rr>>2)&1), i = (rr&3) + 4*(rr>>3), t = col/32
+  float4* out = reinterpret_cast<float4*>(slabs + (int64_t)seg * slab_stride);
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int mt = 0; mt < MT; ++mt) {
+    const int64_t tile = row0 / 32 + mt;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int64_t row = row0 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (row < M_store) {
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) out[row * KP + 32 * t + r] = acc[mt][t][i];
-      }
-    }
+      for (int q4 = 0; q4 < 4; ++q4)
+        out[((tile * NT + t) * 64 + lane) * 4 + q4] =
+            make_float4(acc[mt][t][4 * q4], acc[mt][t][4 * q4 + 1], acc[mt][t][4 * q4 + 2], acc[mt][t][4 * q4 + 3]);
+  }
   }   // segments
 }
 

@@ -77,15 +77,18 @@ struct PathwayLibDev {
 hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const int* nseg, int panel_rows,
                            int64_t slab_stride, int KP, const double* Gv, hipStream_t s);
 // fused U epilogue (k % 4 == 0): slab sum + U (V^T V) on the f32 MFMA + update + fragment packing
+// (*gram_done: the kernel also wrote epilogue_blocks(Kpad) per-workgroup partials of F_new^T F_new)
+int epilogue_blocks(int64_t rows);
 hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const int* nseg, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
-                             hipStream_t s);
+                             float* gram_partial, bool* gram_done, hipStream_t s);
+hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G, hipStream_t s);
 // fused single-rank V epilogue (k % 4 == 0): in place, + packing + per-wave partials [waves][k+1]
 int v_epilogue_waves(int64_t n);
 hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const int* nseg, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gu, const int32_t* pos, const float* gnum,
                              const float* gden, int max_support, int x_dtype, void* packed, int64_t Kpad,
-                             double* partial, hipStream_t s);
+                             double* partial, float* gram_partial, bool* gram_done, hipStream_t s);
 // partial Gram: per-wave partials -> partial[gram_blocks][k*k]; reduce -> G (double)
 int gram_blocks(int64_t rows);
 hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStream_t s);

@@ -15,6 +15,15 @@ namespace prmf {
 // float32 machine epsilon used as the clamp value (prmf_runner.py:23)
 #define PRMF_EPS 1.1920928955078125e-07f
 
+// Element (row, col) of a sweep slab (fragment order, see sweep_kernel's epilogue); NT = KP/32.
+__device__ __forceinline__ int64_t slab_index(int64_t row, int col, int NT) {
+  const int64_t tile = row >> 5;
+  const int rr = (int)(row & 31);
+  const int lane = (col & 31) + 32 * ((rr >> 2) & 1);
+  const int i = (rr & 3) + 4 * (rr >> 3);
+  return (((tile * NT + (col >> 5)) * 64 + lane) << 4) + i;
+}
+
 // deterministic block-wide sum of one double per thread (256 threads)
 __device__ __forceinline__ double block_sum_256(double v, double* red /* [256] shared */) {
   const int tid = threadIdx.x;
@@ -76,7 +85,8 @@ u_update_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict
         if (col < k) {
           float p = 0.f;
           const int ns = nseg[row / panel_rows];
-          for (int s = 0; s < ns; ++s) p += slabs[(int64_t)s * slab_stride + row * KP + col];
+          const int64_t si = slab_index(row, col, KP >> 5);
+          for (int s = 0; s < ns; ++s) p += slabs[(int64_t)s * slab_stride + si];
           const float uu = urow[col];
           const float d = den[j] + uu;
           const float ratio = (d != 0.f) ? p / d : 1.f;
@@ -283,13 +293,12 @@ __device__ __forceinline__ void pack_tile_from_cd(const float (&un)[NT][16], int
   }
 }
 
-// den[t] = (F tile) * G  for one 32-row tile; Gs = G in LDS, [KP][KP] floats (rows/cols >= k are zero)
+// A-layout load of one 32-row tile of F (lane (r,h): F[row0+r][(KP/2)h .. +KP/2), zero outside)
 template <int NT>
-__device__ __forceinline__ void tile_times_gram(const float* __restrict__ F, int64_t rows, int k, int64_t row0, int lane,
-                                                const float* __restrict__ Gs, f32x16 (&den)[NT]) {
-  constexpr int KP = 32 * NT, HALF = KP / 2;
+__device__ __forceinline__ void load_tile_a_layout(const float* __restrict__ F, int64_t rows, int k, int64_t row0, int lane,
+                                                   float (&ua)[16 * NT]) {
+  constexpr int HALF = 16 * NT;
   const int r = lane & 31, h = lane >> 5;
-  float ua[HALF];
   const int64_t row = row0 + r;
 #pragma unroll
   for (int q = 0; q < HALF / 4; ++q) {
@@ -298,6 +307,14 @@ __device__ __forceinline__ void tile_times_gram(const float* __restrict__ F, int
     if (row < rows && col < k) v = *reinterpret_cast<const float4*>(F + row * k + col);
     ua[4 * q] = v.x; ua[4 * q + 1] = v.y; ua[4 * q + 2] = v.z; ua[4 * q + 3] = v.w;
   }
+}
+
+// den[t] = (F tile) * G ; Gs = G in LDS, [KP][KP] floats (rows/cols >= k are zero)
+template <int NT>
+__device__ __forceinline__ void tile_times_gram(const float (&ua)[16 * NT], int lane, const float* __restrict__ Gs,
+                                                f32x16 (&den)[NT]) {
+  constexpr int KP = 32 * NT, HALF = KP / 2;
+  const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -318,51 +335,106 @@ __device__ __forceinline__ void stage_gram(const double* __restrict__ G, int k, 
   }
 }
 
-template <int NT, bool BF16>
+// sum of a tile's slab segments, fragment order: 4 x float4 per (t) per lane, segment-outermost
+// (independent batches; a per-element loop over segments would serialise the round trips)
+template <int NT>
+__device__ __forceinline__ void load_slab_tile(const float* __restrict__ slabs, int64_t slab_stride, int ns, int64_t tile,
+                                               int lane, float (&p)[NT][16]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) p[t][i] = 0.f;
+  for (int sg = 0; sg < ns; ++sg) {
+    const float4* sl = reinterpret_cast<const float4*>(slabs + (int64_t)sg * slab_stride);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 v = sl[((tile * NT + t) * 64 + lane) * 4 + q4];
+        p[t][4 * q4] += v.x; p[t][4 * q4 + 1] += v.y; p[t][4 * q4 + 2] += v.z; p[t][4 * q4 + 3] += v.w;
+      }
+  }
+}
+
+// Gram partial of the tile in C/D layout (see gram_mfma_kernel): g[p] += tile^T tile
+template <int NT>
+__device__ __forceinline__ void gram_accumulate(const float (&un)[NT][16], f32x16 (&g)[NT * (NT + 1) / 2]) {
+  int p = 0;
+#pragma unroll
+  for (int t1 = 0; t1 < NT; ++t1)
+#pragma unroll
+    for (int t2 = t1; t2 < NT; ++t2, ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) g[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(un[t1][i], un[t2][i], g[p], 0, 0, 0);
+}
+
+// sum the block's 4 waves through LDS (one 32x32 block at a time) and write the workgroup's partial
+template <int NT>
+__device__ __forceinline__ void gram_block_store(const f32x16 (&g)[NT * (NT + 1) / 2], int k, float* __restrict__ out,
+                                                 float (*red)[16][64]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  int p = 0;
+#pragma unroll
+  for (int t1 = 0; t1 < NT; ++t1)
+#pragma unroll
+    for (int t2 = t1; t2 < NT; ++t2, ++p) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[wave][i][lane] = g[p][i];
+      __syncthreads();
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = 4 * wave + ii;
+        const float v = ((red[0][i][lane] + red[1][i][lane]) + red[2][i][lane]) + red[3][i][lane];
+        const int a = 32 * t1 + (i & 3) + 8 * (i >> 2) + 4 * h, b = 32 * t2 + c;
+        if (a < k && b < k) {
+          out[a * k + b] = v;
+          if (t1 != t2) out[b * k + a] = v;
+        }
+      }
+    }
+}
+
+// GRAM: also accumulate F_new^T F_new (per-workgroup partial [k*k] floats at gram_partial[blockIdx])
+template <int NT, bool BF16, bool GRAM>
 __global__ void __launch_bounds__(256)
 u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs, const int* __restrict__ nseg,
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gv, void* __restrict__ packed,
-                  int64_t ntiles_pack) {
-  constexpr int KP = 32 * NT;
+                  int64_t ntiles_pack, float* __restrict__ gram_partial) {
+  constexpr int KP = 32 * NT, NP = NT * (NT + 1) / 2;
   __shared__ float Gs[KP * KP];
+  __shared__ float red[GRAM ? 4 : 1][16][64];
   stage_gram<NT>(Gv, k, 0, k, Gs);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
   const int64_t wstride = (int64_t)gridDim.x * 4;
+  f32x16 g[GRAM ? NP : 1];
+  if constexpr (GRAM) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) g[p][i] = 0.f;
+  }
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles_pack; tile += wstride) {
     const int64_t row0 = tile * 32;
-    f32x16 den[NT];
     float un[NT][16];
     if (row0 < m) {
-      tile_times_gram<NT>(U, m, k, row0, lane, Gs, den);
-      const int ns = nseg[row0 / panel_rows];
-      // all loads of the tile are issued as independent batches (segment-outermost): a per-element
-      // loop over the segments would serialise 32 x ns dependent round trips
-      float p[NT][16], uu[NT][16];
-      int64_t off[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        off[i] = row < m ? row : m - 1;
-      }
+      // issue every load of the tile first (A layout, C/D layout, slabs), then the MFMA chain
+      float ua[16 * NT], uu[NT][16], p[NT][16];
+      load_tile_a_layout<NT>(U, m, k, row0, lane, ua);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int col = 32 * t + c;
-        const int colc = col < k ? col : k - 1;
+        const int col = 32 * t + c, colc = col < k ? col : k - 1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          uu[t][i] = U[off[i] * k + colc];
-          p[t][i] = 0.f;
+          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          uu[t][i] = U[(row < m ? row : m - 1) * k + colc];
         }
       }
-      for (int sg = 0; sg < ns; ++sg) {
-        const float* sl = slabs + (int64_t)sg * slab_stride;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) p[t][i] += sl[off[i] * KP + 32 * t + c];
-      }
+      load_slab_tile<NT>(slabs, slab_stride, nseg[row0 / panel_rows], tile, lane, p);
+      f32x16 den[NT];
+      tile_times_gram<NT>(ua, lane, Gs, den);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int col = 32 * t + c;
@@ -371,13 +443,14 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
           const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
           float r2 = 0.f;
           if (row < m && col < k) {
-            const float d = den[t][i] + uu[t][i];            // U (V^T V) + U      (prmf_runner.py:421)
-            r2 = uu[t][i] * ((d != 0.f) ? p[t][i] / d : 1.f); // 0/0 := 1           (:422)
+            const float d = den[t][i] + uu[t][i];             // U (V^T V) + U      (prmf_runner.py:421)
+            r2 = uu[t][i] * ((d != 0.f) ? p[t][i] / d : 1.f);  // 0/0 := 1           (:422)
             U[row * k + col] = r2;
           }
           un[t][i] = r2;
         }
       }
+      if constexpr (GRAM) gram_accumulate<NT>(un, g);
     } else {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -386,22 +459,31 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
     }
     pack_tile_from_cd<NT, BF16>(un, row0, lane, packed);
   }
+  if constexpr (GRAM) gram_block_store<NT>(g, k, gram_partial + (int64_t)blockIdx.x * k * k, red);
+}
+
+int epilogue_blocks(int64_t rows) {
+  int64_t tiles = (rows + 31) / 32;
+  int64_t blocks = (tiles + 3) / 4;
+  if (blocks > 256) blocks = 256;
+  return (int)(blocks < 1 ? 1 : blocks);
 }
 
 hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const int* nseg, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
-                             hipStream_t s) {
+                             float* gram_partial, bool* gram_done, hipStream_t s) {
   const int NT = KP / 32;
   const int64_t ntiles = Kpad / 32;          // every tile of the packed buffer is (re)written, zero beyond m
-  int grid = (int)((ntiles + 3) / 4 < 1024 ? (ntiles + 3) / 4 : 1024);
-#define PRMF_UEP(NTV)                                                                                              \
-  if (x_dtype == 1) u_epilogue_kernel<NTV, true><<<grid, 256, 0, s>>>(U, m, k, slabs, nseg, panel_rows, slab_stride, Gv, packed, ntiles); \
-  else u_epilogue_kernel<NTV, false><<<grid, 256, 0, s>>>(U, m, k, slabs, nseg, panel_rows, slab_stride, Gv, packed, ntiles)
+  const int grid = epilogue_blocks(Kpad);
+  *gram_done = NT <= 2;
+#define PRMF_UEP(NTV, GR)                                                                                          \
+  if (x_dtype == 1) u_epilogue_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, nseg, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial); \
+  else u_epilogue_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, nseg, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial)
   switch (NT) {
-    case 1: PRMF_UEP(1); break;
-    case 2: PRMF_UEP(2); break;
-    case 3: PRMF_UEP(3); break;
-    case 4: PRMF_UEP(4); break;
+    case 1: PRMF_UEP(1, true); break;
+    case 2: PRMF_UEP(2, true); break;
+    case 3: PRMF_UEP(3, false); break;
+    case 4: PRMF_UEP(4, false); break;
     default: return hipErrorInvalidValue;
   }
 #undef PRMF_UEP
@@ -410,15 +492,17 @@ hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, con
 
 // Single-rank V epilogue: V <- V * (Q + g_num) / max(V (U^T U) + g_den, eps), clamp
 // (prmf_runner.py:424-444), in place, + packing + per-wave partial column sums of
-// squares and <Q, V_new> (float64).
-template <int NT, bool BF16>
+// squares and <Q, V_new> (float64) + (GRAM) V_new^T V_new partials.
+template <int NT, bool BF16, bool GRAM>
 __global__ void __launch_bounds__(256)
 v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ slabs, const int* __restrict__ nseg,
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gu, const int32_t* __restrict__ pos,
                   const float* __restrict__ gnum, const float* __restrict__ gden, int max_support,
-                  void* __restrict__ packed, int64_t ntiles_pack, double* __restrict__ partial /*[waves][k+1]*/) {
-  constexpr int KP = 32 * NT;
+                  void* __restrict__ packed, int64_t ntiles_pack, double* __restrict__ partial /*[waves][k+1]*/,
+                  float* __restrict__ gram_partial) {
+  constexpr int KP = 32 * NT, NP = NT * (NT + 1) / 2;
   __shared__ float Gs[KP * KP];
+  __shared__ float red[GRAM ? 4 : 1][16][64];
   stage_gram<NT>(Gu, k, 0, k, Gs);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -427,39 +511,34 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
   double colsq[NT], cross = 0.0;
 #pragma unroll
   for (int t = 0; t < NT; ++t) colsq[t] = 0.0;
+  f32x16 g[GRAM ? NP : 1];
+  if constexpr (GRAM) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) g[p][i] = 0.f;
+  }
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles_pack; tile += wstride) {
     const int64_t row0 = tile * 32;
-    f32x16 den[NT];
     float vn[NT][16];
     if (row0 < n) {
-      tile_times_gram<NT>(V, n, k, row0, lane, Gs, den);
-      const int ns = nseg[row0 / panel_rows];
-      float q[NT][16], vv[NT][16];
+      float ua[16 * NT], vv[NT][16], q[NT][16];
       int ps[NT][16];
-      int64_t off[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        off[i] = row < n ? row : n - 1;
-      }
+      load_tile_a_layout<NT>(V, n, k, row0, lane, ua);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int col = 32 * t + c;
-        const int colc = col < k ? col : k - 1;
+        const int col = 32 * t + c, colc = col < k ? col : k - 1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          vv[t][i] = V[off[i] * k + colc];
-          ps[t][i] = pos[off[i] * k + colc];
-          q[t][i] = 0.f;
+          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const int64_t rc = row < n ? row : n - 1;
+          vv[t][i] = V[rc * k + colc];
+          ps[t][i] = pos[rc * k + colc];
         }
       }
-      for (int sg = 0; sg < ns; ++sg) {
-        const float* sl = slabs + (int64_t)sg * slab_stride;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) q[t][i] += sl[off[i] * KP + 32 * t + c];
-      }
+      load_slab_tile<NT>(slabs, slab_stride, nseg[row0 / panel_rows], tile, lane, q);
+      f32x16 den[NT];
+      tile_times_gram<NT>(ua, lane, Gs, den);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int col = 32 * t + c;
@@ -483,6 +562,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
           vn[t][i] = r2;
         }
       }
+      if constexpr (GRAM) gram_accumulate<NT>(vn, g);
     } else {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -501,34 +581,40 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) cross += __shfl_xor(cross, off);
   if (lane == 0) out[k] = cross;
+  if constexpr (GRAM) gram_block_store<NT>(g, k, gram_partial + (int64_t)blockIdx.x * k * k, red);
 }
 
-int v_epilogue_waves(int64_t n) {
-  int64_t tiles = (n + 31) / 32;
-  int64_t blocks = (tiles + 3) / 4;
-  if (blocks > 512) blocks = 512;
-  return (int)blocks * 4;
-}
+int v_epilogue_waves(int64_t n) { return epilogue_blocks(round_up(n, K_PAD)) * 4; }
 
 hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const int* nseg, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gu, const int32_t* pos, const float* gnum,
                              const float* gden, int max_support, int x_dtype, void* packed, int64_t Kpad,
-                             double* partial, hipStream_t s) {
+                             double* partial, float* gram_partial, bool* gram_done, hipStream_t s) {
   const int NT = KP / 32;
   const int64_t ntiles = Kpad / 32;
   // the grid must match v_epilogue_waves(n): every partial row is written by exactly one wave
-  const int grid = v_epilogue_waves(n) / 4;
-#define PRMF_VEP(NTV)                                                                                               \
-  if (x_dtype == 1) v_epilogue_kernel<NTV, true><<<grid, 256, 0, s>>>(V, n, k, slabs, nseg, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial); \
-  else v_epilogue_kernel<NTV, false><<<grid, 256, 0, s>>>(V, n, k, slabs, nseg, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial)
+  const int grid = epilogue_blocks(Kpad);
+  *gram_done = NT <= 2;
+#define PRMF_VEP(NTV, GR)                                                                                           \
+  if (x_dtype == 1) v_epilogue_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(V, n, k, slabs, nseg, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial); \
+  else v_epilogue_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(V, n, k, slabs, nseg, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial)
   switch (NT) {
-    case 1: PRMF_VEP(1); break;
-    case 2: PRMF_VEP(2); break;
-    case 3: PRMF_VEP(3); break;
-    case 4: PRMF_VEP(4); break;
+    case 1: PRMF_VEP(1, true); break;
+    case 2: PRMF_VEP(2, true); break;
+    case 3: PRMF_VEP(3, false); break;
+    case 4: PRMF_VEP(4, false); break;
     default: return hipErrorInvalidValue;
   }
 #undef PRMF_VEP
+  return hipGetLastError();
+}
+
+// reduce `nparts` per-workgroup Gram partials (written by an epilogue) into G
+hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G, hipStream_t s);
+
+hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G, hipStream_t s) {
+  const int kk2 = k * k;
+  gram_reduce_kernel<<<(kk2 + 31) / 32, 256, 0, s>>>(partial, nparts, kk2, G);
   return hipGetLastError();
 }
 
@@ -544,7 +630,8 @@ slab_sum_blocks_kernel(const float* __restrict__ slabs, const int* __restrict__ 
   int kk = (int)(idx - j * k);
   float v = 0.f;
   const int ns = nseg[j / panel_rows];
-  for (int s = 0; s < ns; ++s) v += slabs[(int64_t)s * slab_stride + j * KP + kk];
+  const int64_t si = slab_index(j, kk, KP >> 5);
+  for (int s = 0; s < ns; ++s) v += slabs[(int64_t)s * slab_stride + si];
   int r = kk / kc, c = kk - r * kc;
   q_send[((int64_t)r * n + j) * kc + c] = v;
 }

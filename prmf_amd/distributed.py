@@ -60,30 +60,59 @@ class Collectives(object):
 
 
 class DistributedPrmf(object):
-    """Drives one engine per rank through the four phases with the collectives in
-    between.  With world size 1 no collective is issued (q_recv / v_recv alias the
-    send buffers)."""
+    """Drives one engine per rank through the iteration.
 
-    def __init__(self, engine, group=None):
+    native=True (default when the process group's backend is "nccl"): the library
+    itself issues the RCCL collectives on the stream between its phases
+    (`prmf_step_dist`), n_steps iterations per host call.  native=False: the four
+    phases are called from here with torch.distributed collectives in between --
+    the form the gloo tests exercise, and the fallback if the in-library
+    communicator cannot be created.  With world size 1 no collective is issued."""
+
+    def __init__(self, engine, group=None, native=None):
         self.engine = engine
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.coll = Collectives(group) if self.world > 1 else None
         if self.world != engine.nranks:
             raise ValueError("engine was created for %d ranks, process group has %d" % (engine.nranks, self.world))
-        self.buf = engine.comm_buffers()
+        if native is None:
+            native = self.world > 1 and dist.get_backend(group) == "nccl" and hasattr(engine, "comm_init")
+        self.native = False
+        if native:
+            try:
+                engine.comm_init(group)
+                self.native = True
+            except Exception as e:      # keep running on the host-driven path, but say so
+                import sys
+                sys.stderr.write("prmf_amd: in-library RCCL communicator unavailable (%s); "
+                                 "using host-driven collectives\n" % e)
+        self.coll = Collectives(group) if (self.world > 1 and not self.native) else None
+        self.buf = None if self.native else engine.comm_buffers()
 
     def step(self, U, V, n_steps, gamma, delta, tradeoff=None):
-        e, b, c = self.engine, self.buf, self.coll
-        e.begin(U, V, gamma, delta, tradeoff)
-        for _ in range(n_steps):
-            e.phase_u()
-            if c:
-                c.all_reduce_sum(b["gram"])
-            e.phase_q()
-            if c:
-                c.reduce_scatter_sum(b["q_recv"], b["q_send"])
-            e.phase_v()
-            if c:
-                c.all_gather(b["v_recv"], b["v_send"])
-            e.phase_post()
-        return e.end(n_steps)
+        e = self.engine
+        if self.native:
+            return e.step_dist(U, V, n_steps, gamma, delta, tradeoff)
+        b, c = self.buf, self.coll
+        objs_all = []
+        gd = (gamma, delta)
+        done = 0
+        while done < n_steps or (n_steps == 0 and done == 0):
+            batch = min(n_steps - done, 128)         # the library keeps <= 256 records between begin and end
+            e.begin(U, V, gd[0], gd[1], tradeoff)
+            for _ in range(batch):
+                e.phase_u()
+                if c:
+                    c.all_reduce_sum(b["gram"])
+                e.phase_q()
+                if c:
+                    c.reduce_scatter_sum(b["q_recv"], b["q_send"])
+                e.phase_v()
+                if c:
+                    c.all_gather(b["v_recv"], b["v_send"])
+                e.phase_post()
+            objs, gd = e.end(batch)
+            objs_all += objs
+            done += batch
+            if n_steps == 0:
+                break
+        return objs_all, gd

@@ -209,6 +209,45 @@ class PrmfEngine(object):
         self._check(rc)
         return self.records_to_dicts(obj[:n_steps]), (float(gd[0]), float(gd[1]))
 
+    # -- collectives inside the library (RCCL on the stream; no per-iteration host work) ----
+    def comm_init(self, group=None):
+        """Create this rank's RCCL communicator inside the library: rank 0 draws the
+        unique id, torch.distributed broadcasts the 128 bytes, every rank joins."""
+        torch = self.torch
+        idbuf = np.zeros(_capi.PRMF_COMM_ID_BYTES, dtype=np.uint8)
+        if self.nranks == 1:
+            self._check_create(self.lib.prmf_comm_unique_id(_ptr(idbuf)))
+        else:
+            import torch.distributed as dist
+            if dist.get_rank(group) == 0:
+                self._check_create(self.lib.prmf_comm_unique_id(_ptr(idbuf)))
+            on_gpu = dist.get_backend(group) == "nccl"
+            t = torch.from_numpy(idbuf)
+            if on_gpu:
+                t = t.to("cuda:%d" % self.device)
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            idbuf = t.cpu().numpy().copy()
+        self._check(self.lib.prmf_comm_init(self.ctx, _ptr(idbuf)))
+        self._native_comm = True
+
+    def _check_create(self, rc):
+        if rc != _capi.PRMF_OK:
+            raise _capi.PrmfError(rc, self.lib.prmf_last_error(None).decode())
+
+    def step_dist(self, U, V, n_steps, gamma, delta, tradeoff=None):
+        """Multi-rank `step`: the library runs phases and collectives on the stream."""
+        self._check_factors(U, V)
+        self._bound = (U, V)
+        obj = np.zeros((max(n_steps, 1), _capi.PRMF_OBJ_STRIDE))
+        gd = np.zeros(2)
+        t = -1.0 if tradeoff is None else float(tradeoff)
+        rc = self.lib.prmf_step_dist(self.ctx, C.c_void_p(U.data_ptr()), C.c_void_p(V.data_ptr()), int(n_steps),
+                                     float(gamma), float(delta), t, _ptr(obj), _ptr(gd), self._stream())
+        if rc == _capi.PRMF_ERR_NUMERIC:
+            raise FloatingPointError(self.lib.prmf_last_error(self.ctx).decode())
+        self._check(rc)
+        return self.records_to_dicts(obj[:n_steps]), (float(gd[0]), float(gd[1]))
+
     def score_candidates(self, V):
         """k x P matrix of restrict's match scores (prmf_runner.py:115-127)."""
         out = np.zeros((self.k, self.library.P))

@@ -77,3 +77,31 @@ def test_two_ranks_match_single_rank(k, x_dtype):
     for a, b in zip(res[0][2], tr):
         for key in ("recon", "manifold", "ignore", "fro", "obj"):
             assert abs(a[key] - b[key]) <= 1e-4 * max(abs(b[key]), 1e-12), key
+
+
+def test_in_library_rccl_step_single_rank():
+    """prmf_step_dist (RCCL collectives issued by the library on the stream) with a
+    one-rank communicator must reproduce prmf_step bit for bit."""
+    import torch
+    from prmf_amd import PathwayLibrary
+    from prmf_amd.distributed import DistributedPrmf
+    from prmf_amd.solver import PrmfEngine
+    case = synth.small_case(seed=17, m=600, n=1100, k=32, P=6, order=70, bf16_x=True)
+    X = case["X"]
+    res = []
+    for native in (False, True):
+        eng = PrmfEngine(X.shape[0], X.shape[1], 32, x_dtype="bf16")
+        eng.set_x(X)
+        eng.set_library(PathwayLibrary.from_edge_lists(X.shape[1], case["pathways"]))
+        eng.set_active(np.arange(32) % 6)
+        U = eng.device_tensor(case["U0"], torch.float32)
+        V = eng.device_tensor(case["V0"], torch.float32)
+        if native:
+            runner = DistributedPrmf(eng, native=True)
+            assert runner.native
+            objs, gd = runner.step(U, V, 4, case["gamma"], case["delta"])
+        else:
+            objs, gd = eng.step(U, V, 4, case["gamma"], case["delta"])
+        res.append((U.cpu().numpy(), V.cpu().numpy(), objs))
+        eng.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
