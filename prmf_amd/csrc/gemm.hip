@@ -172,13 +172,21 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], const u32x4
 // are bit-identical run to run.  The design therefore never relies on the completion
 // order of global loads.
 
+#ifndef PRMF_A_NT
+#define PRMF_A_NT 1
+#endif
+constexpr bool NT_LOADS = PRMF_A_NT != 0;   // A is read exactly once: non-temporal loads keep it from displacing the factor in L2
+
 template <int MT>
 __device__ __forceinline__ void load_a_chunk(u32x4 (&dst)[MT][4], const unsigned (&voff)[MT][4], const uint4* base) {
   const char* b = reinterpret_cast<const char*>(base);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dst[mt][i] = *reinterpret_cast<const u32x4*>(b + voff[mt][i]);
+    for (int i = 0; i < 4; ++i) {
+      const u32x4* src = reinterpret_cast<const u32x4*>(b + voff[mt][i]);
+      dst[mt][i] = NT_LOADS ? __builtin_nontemporal_load(src) : *src;
+    }
 }
 
 // thread tid takes uint4 #tid of every NTHREADS*16-byte slice of the packed chunk (the last slice may be partial)
@@ -211,7 +219,7 @@ __device__ __forceinline__ void store_b_chunk(u32x4* sb, const u32x4 (&src)[NB],
 template <bool BF16, int MT, int NT, int NW, bool BDB>
 __global__ void __launch_bounds__(64 * NW)
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
-             const uint4* __restrict__ Bp, int npanels, int ngroups /* chunk pairs per row */,
+             const uint4* __restrict__ Bp, int npanels, int ngroups /* chunk pairs per row */, int nx, int pmax,
              float* __restrict__ slabs, int64_t slab_stride) {
   constexpr int NTHR = 64 * NW;
   constexpr int BCH = BF16 ? 512 * NT : 256 * NT;   // uint4 per packed chunk
@@ -221,16 +229,26 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  // Balanced persistent decomposition: the launch has one workgroup per resident
-  // slot; the npanels x ngroups units (a unit = 2 chunks of one row panel) are cut
-  // into gridDim.x equal contiguous ranges in panel-major order.  A range that
-  // crosses a panel boundary is processed as separate segments; segment number
-  // `seg` of a panel (counted from the workgroup that holds the panel's first
-  // unit) goes to slab `seg`, and the consumer sums a panel's segments in order.
-  const int64_t T = (int64_t)npanels * ngroups;
-  const int64_t G = gridDim.x, wg = blockIdx.x;
-  int64_t unit = wg * T / G;
-  const int64_t unit_end = (wg + 1) * T / G;
+  // Balanced, XCD-aware persistent decomposition.  The launch has one workgroup per
+  // resident slot.  The reduction range (ngroups chunk pairs) is cut into `nx` slices
+  // (nx = 8: one per XCD; workgroups b, b+8, ... share an XCD and its 4 MiB L2, so
+  // the nx-th of the packed factor they all stream stays L2-resident instead of
+  // being re-fetched through the fabric by every workgroup -- placement is used for
+  // speed only, never for correctness).  Within slice x the npanels x L_x units (a
+  // unit = one chunk pair of one row panel) are cut into gridDim.x/nx equal
+  // contiguous ranges in panel-major order.  A range that crosses a panel boundary is
+  // processed as separate segments; the segment of panel p in slice x that is the
+  // `part`-th to touch it goes to slab x*pmax + part, and the consumer sums the slabs
+  // named by the panel's bit mask in index order.
+  // block b runs on XCD b % 8; slice x = (b % 8) % nx, so XCDs x, x + nx, ... share slice x
+  const int xcd = (int)(blockIdx.x & 7), x = xcd % nx;
+  const int64_t Gx = gridDim.x / nx;                             // workgroups per slice
+  const int wj = (int)(blockIdx.x >> 3) * (8 / nx) + xcd / nx;   // index within the slice
+  const int gs0 = (int)((int64_t)ngroups * x / nx);
+  const int L = (int)((int64_t)ngroups * (x + 1) / nx) - gs0;      // chunk pairs in this slice
+  const int64_t T = (int64_t)npanels * L;
+  int64_t unit = T * wj / Gx;
+  const int64_t unit_end = L > 0 ? T * (wj + 1) / Gx : 0;
 
   unsigned avoff[MT][4];
 #pragma unroll
@@ -244,12 +262,13 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   u32x4* const myA = sA[wave];
 
   while (unit < unit_end) {
-  const int panel = (int)(unit / ngroups);
-  const int g0 = (int)(unit - (int64_t)panel * ngroups);
-  const int g1 = (int)min((int64_t)ngroups, g0 + (unit_end - unit));
-  const int seg = (int)(wg - (((int64_t)panel * ngroups + 1) * G - 1) / T);   // wg minus the first workgroup of this panel
+  const int panel = (int)(unit / L);
+  const int g0 = (int)(unit - (int64_t)panel * L);
+  const int g1 = (int)min((int64_t)L, g0 + (unit_end - unit));
+  const int part = (int)(wj - (((int64_t)panel * L + 1) * Gx - 1) / T);   // wj minus the first workgroup of this (panel, slice)
+  const int seg = x * pmax + part;
   unit += g1 - g0;
-  const int c0 = 2 * g0;
+  const int c0 = 2 * (gs0 + g0);
   const int nch = 2 * (g1 - g0);
   const int last = nch - 1;
   const int64_t prow0 = (int64_t)panel * (32 * MT * NW);            // first row of this panel
@@ -329,8 +348,6 @@ static SweepVariant sweep_variant() {
   return v;
 }
 
-static int64_t first_wg_of_unit(int64_t u, int64_t G, int64_t T) { return ((u + 1) * G - 1) / T; }
-
 GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus) {
   GemmPlan p;
   const SweepVariant v = sweep_variant();
@@ -338,20 +355,62 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus) {
   p.panels = (int)(round_up(M, p.panel_rows) / p.panel_rows);
   p.nchunks = (int)(Kpad / chunk_elems(x_dtype));          // even (K_PAD)
   p.ngroups = p.nchunks / 2;
-  const int64_t T = (int64_t)p.panels * p.ngroups;
-  // one workgroup per resident slot, but at least 4 units (8 chunks) each
+  // one workgroup per resident slot (a multiple of 8: one share per XCD), but at least 4 units (8 chunks) each
   int64_t G = (int64_t)n_cus * v.wgs_per_cu;
   if (NT > 2) G = (int64_t)n_cus * (v.wgs_per_cu > 1 ? v.wgs_per_cu - 1 : 1);   // larger B tiles: fewer resident workgroups
-  if (G > T / 4) G = T / 4;
+  const int64_t total_units = (int64_t)p.panels * p.ngroups;
+  if (G > total_units / 4) G = total_units / 4;
+  G = G / 8 * 8;
+  p.nx = 1;
+  if (G >= 8 && p.ngroups >= 8) {
+    // as many slices as keep >= ~1.5 (panel, slice) pieces per workgroup: shorter segments cost
+    // more in prologues and slab traffic than the L2 residency of the factor slice wins back
+    const double units_per_wg = (double)total_units / (double)G;
+    // Slice only when the packed factor cannot stay in the 4 MiB XCD L2 (with the A stream loaded
+    // non-temporally a slice that fits is served from L2 instead of the fabric).  Measured at
+    // 50000x20000, k=64 (interleaved runs): X^T*U (12.8 MB factor) 0.425 -> 0.36-0.39 ms at 4 slices;
+    // X*V (5.1 MB factor) is fastest unsliced (0.35-0.375 vs 0.40-0.42: the extra segments cost more).
+    const double factor_mb = (double)Kpad * 32.0 * NT * 4.0 / (1024.0 * 1024.0);
+    if (factor_mb > 6.0) {
+      p.nx = 2;
+      while (p.nx < 8 && factor_mb / p.nx > 3.5) p.nx *= 2;
+      while (p.nx > 1 && units_per_wg < 0.5 * ((double)p.ngroups / p.nx)) p.nx /= 2;
+    }
+    if (const char* e = getenv("PRMF_SWEEP_XCD")) {
+      const int f = atoi(e);
+      if (f == 1 || f == 2 || f == 4 || f == 8) p.nx = f;
+    }
+  }
   if (G < 1) G = 1;
-  p.grid = (int)G;
-  p.nseg.assign(p.panels, 0);
-  p.max_seg = 1;
-  for (int q = 0; q < p.panels; ++q) {
-    const int64_t w0 = first_wg_of_unit((int64_t)q * p.ngroups, G, T);
-    const int64_t w1 = first_wg_of_unit((int64_t)(q + 1) * p.ngroups - 1, G, T);
-    p.nseg[q] = (int)(w1 - w0 + 1);
-    if (p.nseg[q] > p.max_seg) p.max_seg = p.nseg[q];
+  for (;;) {
+    // simulate the kernel's decomposition: which slabs does every panel receive?
+    p.grid = (int)G;
+    const int64_t Gx = G / p.nx;
+    std::vector<int> parts((size_t)p.panels * p.nx, 0);
+    p.pmax = 1;
+    for (int x = 0; x < p.nx; ++x) {
+      const int gs0 = (int)((int64_t)p.ngroups * x / p.nx);
+      const int L = (int)((int64_t)p.ngroups * (x + 1) / p.nx) - gs0;
+      if (L <= 0) continue;
+      const int64_t T = (int64_t)p.panels * L;
+      for (int q = 0; q < p.panels; ++q) {
+        const int64_t w0 = (((int64_t)q * L + 1) * Gx - 1) / T;
+        const int64_t w1 = (((int64_t)(q + 1) * L) * Gx - 1) / T;
+        const int n = (int)(w1 - w0 + 1);
+        parts[(size_t)q * p.nx + x] = n;
+        if (n > p.pmax) p.pmax = n;
+      }
+    }
+    if (p.nx * p.pmax <= 32) {
+      p.segmask.assign(p.panels, 0u);
+      for (int q = 0; q < p.panels; ++q)
+        for (int x = 0; x < p.nx; ++x)
+          for (int j = 0; j < parts[(size_t)q * p.nx + x]; ++j) p.segmask[q] |= 1u << (x * p.pmax + j);
+      p.max_seg = p.nx * p.pmax;
+      break;
+    }
+    // too many segments per panel for the 32-bit mask: fewer slices, then fewer workgroups
+    if (p.nx > 1) p.nx = 1; else G = G > 16 ? G / 2 : 1;
   }
   return p;
 }
@@ -362,7 +421,7 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
   dim3 grid(p.grid), block(64 * NW);
 #define PRMF_LAUNCH(NTV)                                                                                          \
   sweep_kernel<BF16, 1, NTV, NW, BDB><<<grid, block, 0, s>>>((const uint4*)A, lda16, M_store, (const uint4*)Bp, \
-                                                             p.panels, p.ngroups, slabs, slab_stride)
+                                                             p.panels, p.ngroups, p.nx, p.pmax, slabs, slab_stride)
   switch (NT) {
     case 1: PRMF_LAUNCH(1); break;
     case 2: PRMF_LAUNCH(2); break;

@@ -46,8 +46,10 @@ struct GemmPlan {
   int nchunks = 0;          // reduction chunks per row (even)
   int ngroups = 0;          // nchunks / 2: the work unit is (panel, chunk pair)
   int grid = 0;             // workgroups launched: one per resident slot, equal contiguous unit ranges
-  int max_seg = 1;          // slabs needed: most segments any panel is cut into
-  std::vector<int> nseg;    // [panels] segments (= slabs to sum) of each panel
+  int nx = 1;               // slices of the reduction range (8 = one per XCD)
+  int pmax = 1;             // most workgroups that touch one (panel, slice)
+  int max_seg = 1;          // slabs allocated: nx * pmax
+  std::vector<uint32_t> segmask;   // [panels] bit s set <=> slab s holds a segment of this panel
 };
 GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus);
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
@@ -74,18 +76,18 @@ struct PathwayLibDev {
 };
 
 // U <- U * (P / (U Gv + U)), P = sum of `splits` slabs     (prmf_runner.py:420-422)
-hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const int* nseg, int panel_rows,
+hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                            int64_t slab_stride, int KP, const double* Gv, hipStream_t s);
 // fused U epilogue (k % 4 == 0): slab sum + U (V^T V) on the f32 MFMA + update + fragment packing
 // (*gram_done: the kernel also wrote epilogue_blocks(Kpad) per-workgroup partials of F_new^T F_new)
 int epilogue_blocks(int64_t rows);
-hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const int* nseg, int panel_rows,
+hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
                              float* gram_partial, bool* gram_done, hipStream_t s);
 hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G, hipStream_t s);
 // fused single-rank V epilogue (k % 4 == 0): in place, + packing + per-wave partials [waves][k+1]
 int v_epilogue_waves(int64_t n);
-hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const int* nseg, int panel_rows,
+hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gu, const int32_t* pos, const float* gnum,
                              const float* gden, int max_support, int x_dtype, void* packed, int64_t Kpad,
                              double* partial, float* gram_partial, bool* gram_done, hipStream_t s);
@@ -93,7 +95,7 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
 int gram_blocks(int64_t rows);
 hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStream_t s);
 // Q slabs -> q_send[nranks][n][kc]
-hipError_t launch_slab_sum_blocks(const float* slabs, const int* nseg, int panel_rows, int64_t slab_stride, int KP,
+hipError_t launch_slab_sum_blocks(const float* slabs, const uint32_t* segmask, int panel_rows, int64_t slab_stride, int KP,
                                   int64_t n, int k, int kc, int nranks, float* q_send, hipStream_t s);
 // pos[n][kc] = index in the active pathway's support of gene j for own column c, or -1
 hipError_t launch_build_pos(const PathwayLibDev& lib, const int32_t* active_dev, int col0, int ncols, int kc,

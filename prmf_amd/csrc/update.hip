@@ -44,7 +44,7 @@ __device__ __forceinline__ double block_sum_256(double v, double* red /* [256] s
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 u_update_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs,
-                const int* __restrict__ nseg, int panel_rows, int64_t slab_stride, int KP,
+                const uint32_t* __restrict__ segmask, int panel_rows, int64_t slab_stride, int KP,
                 const double* __restrict__ Gv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int k4 = (k + 3) & ~3;
@@ -84,9 +84,9 @@ u_update_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict
         const int col = 4 * cg + j;
         if (col < k) {
           float p = 0.f;
-          const int ns = nseg[row / panel_rows];
           const int64_t si = slab_index(row, col, KP >> 5);
-          for (int s = 0; s < ns; ++s) p += slabs[(int64_t)s * slab_stride + si];
+          for (uint32_t mk = segmask[row / panel_rows]; mk; mk &= mk - 1)
+            p += slabs[(int64_t)(__ffs(mk) - 1) * slab_stride + si];
           const float uu = urow[col];
           const float d = den[j] + uu;
           const float ratio = (d != 0.f) ? p / d : 1.f;
@@ -97,14 +97,14 @@ u_update_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict
   }
 }
 
-hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const int* nseg, int panel_rows,
+hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                            int64_t slab_stride, int KP, const double* Gv, hipStream_t s) {
   const int k4 = (k + 3) & ~3;
   const int RT = 256 / (k4 >> 2);
   size_t lds = (size_t)(k * k4 + RT * k4) * sizeof(float);
   int64_t ntiles = (m + RT - 1) / RT;
   int grid = (int)(ntiles < 2048 ? ntiles : 2048);
-  u_update_kernel<<<grid, 256, lds, s>>>(U, m, k, slabs, nseg, panel_rows, slab_stride, KP, Gv);
+  u_update_kernel<<<grid, 256, lds, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, KP, Gv);
   return hipGetLastError();
 }
 
@@ -338,14 +338,14 @@ __device__ __forceinline__ void stage_gram(const double* __restrict__ G, int k, 
 // sum of a tile's slab segments, fragment order: 4 x float4 per (t) per lane, segment-outermost
 // (independent batches; a per-element loop over segments would serialise the round trips)
 template <int NT>
-__device__ __forceinline__ void load_slab_tile(const float* __restrict__ slabs, int64_t slab_stride, int ns, int64_t tile,
+__device__ __forceinline__ void load_slab_tile(const float* __restrict__ slabs, int64_t slab_stride, uint32_t mask, int64_t tile,
                                                int lane, float (&p)[NT][16]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) p[t][i] = 0.f;
-  for (int sg = 0; sg < ns; ++sg) {
-    const float4* sl = reinterpret_cast<const float4*>(slabs + (int64_t)sg * slab_stride);
+  for (; mask; mask &= mask - 1) {
+    const float4* sl = reinterpret_cast<const float4*>(slabs + (int64_t)(__ffs(mask) - 1) * slab_stride);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -398,7 +398,7 @@ __device__ __forceinline__ void gram_block_store(const f32x16 (&g)[NT * (NT + 1)
 // GRAM: also accumulate F_new^T F_new (per-workgroup partial [k*k] floats at gram_partial[blockIdx])
 template <int NT, bool BF16, bool GRAM>
 __global__ void __launch_bounds__(256)
-u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs, const int* __restrict__ nseg,
+u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs, const uint32_t* __restrict__ segmask,
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gv, void* __restrict__ packed,
                   int64_t ntiles_pack, float* __restrict__ gram_partial) {
   constexpr int KP = 32 * NT, NP = NT * (NT + 1) / 2;
@@ -432,7 +432,7 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
           uu[t][i] = U[(row < m ? row : m - 1) * k + colc];
         }
       }
-      load_slab_tile<NT>(slabs, slab_stride, nseg[row0 / panel_rows], tile, lane, p);
+      load_slab_tile<NT>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, p);
       f32x16 den[NT];
       tile_times_gram<NT>(ua, lane, Gs, den);
 #pragma unroll
@@ -469,7 +469,7 @@ int epilogue_blocks(int64_t rows) {
   return (int)(blocks < 1 ? 1 : blocks);
 }
 
-hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const int* nseg, int panel_rows,
+hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
                              float* gram_partial, bool* gram_done, hipStream_t s) {
   const int NT = KP / 32;
@@ -477,8 +477,8 @@ hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, con
   const int grid = epilogue_blocks(Kpad);
   *gram_done = NT <= 2;
 #define PRMF_UEP(NTV, GR)                                                                                          \
-  if (x_dtype == 1) u_epilogue_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, nseg, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial); \
-  else u_epilogue_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, nseg, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial)
+  if (x_dtype == 1) u_epilogue_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial); \
+  else u_epilogue_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial)
   switch (NT) {
     case 1: PRMF_UEP(1, true); break;
     case 2: PRMF_UEP(2, true); break;
@@ -495,7 +495,7 @@ hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, con
 // squares and <Q, V_new> (float64) + (GRAM) V_new^T V_new partials.
 template <int NT, bool BF16, bool GRAM>
 __global__ void __launch_bounds__(256)
-v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ slabs, const int* __restrict__ nseg,
+v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ slabs, const uint32_t* __restrict__ segmask,
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gu, const int32_t* __restrict__ pos,
                   const float* __restrict__ gnum, const float* __restrict__ gden, int max_support,
                   void* __restrict__ packed, int64_t ntiles_pack, double* __restrict__ partial /*[waves][k+1]*/,
@@ -536,7 +536,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
           ps[t][i] = pos[rc * k + colc];
         }
       }
-      load_slab_tile<NT>(slabs, slab_stride, nseg[row0 / panel_rows], tile, lane, q);
+      load_slab_tile<NT>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);
       f32x16 den[NT];
       tile_times_gram<NT>(ua, lane, Gs, den);
 #pragma unroll
@@ -586,7 +586,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
 
 int v_epilogue_waves(int64_t n) { return epilogue_blocks(round_up(n, K_PAD)) * 4; }
 
-hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const int* nseg, int panel_rows,
+hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gu, const int32_t* pos, const float* gnum,
                              const float* gden, int max_support, int x_dtype, void* packed, int64_t Kpad,
                              double* partial, float* gram_partial, bool* gram_done, hipStream_t s) {
@@ -596,8 +596,8 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
   const int grid = epilogue_blocks(Kpad);
   *gram_done = NT <= 2;
 #define PRMF_VEP(NTV, GR)                                                                                           \
-  if (x_dtype == 1) v_epilogue_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(V, n, k, slabs, nseg, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial); \
-  else v_epilogue_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(V, n, k, slabs, nseg, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial)
+  if (x_dtype == 1) v_epilogue_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(V, n, k, slabs, segmask, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial); \
+  else v_epilogue_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(V, n, k, slabs, segmask, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial)
   switch (NT) {
     case 1: PRMF_VEP(1, true); break;
     case 2: PRMF_VEP(2, true); break;
@@ -622,25 +622,24 @@ hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G
 // Q slabs -> per-owner column blocks  q_send[r][j][c],  column kk = r*kc + c
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-slab_sum_blocks_kernel(const float* __restrict__ slabs, const int* __restrict__ nseg, int panel_rows,
+slab_sum_blocks_kernel(const float* __restrict__ slabs, const uint32_t* __restrict__ segmask, int panel_rows,
                        int64_t slab_stride, int KP, int64_t n, int k, int kc, float* __restrict__ q_send) {
   int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n * k) return;
   int64_t j = idx / k;
   int kk = (int)(idx - j * k);
   float v = 0.f;
-  const int ns = nseg[j / panel_rows];
   const int64_t si = slab_index(j, kk, KP >> 5);
-  for (int s = 0; s < ns; ++s) v += slabs[(int64_t)s * slab_stride + si];
+  for (uint32_t mk = segmask[j / panel_rows]; mk; mk &= mk - 1) v += slabs[(int64_t)(__ffs(mk) - 1) * slab_stride + si];
   int r = kk / kc, c = kk - r * kc;
   q_send[((int64_t)r * n + j) * kc + c] = v;
 }
 
-hipError_t launch_slab_sum_blocks(const float* slabs, const int* nseg, int panel_rows, int64_t slab_stride, int KP,
+hipError_t launch_slab_sum_blocks(const float* slabs, const uint32_t* segmask, int panel_rows, int64_t slab_stride, int KP,
                                   int64_t n, int k, int kc, int nranks, float* q_send, hipStream_t s) {
   (void)nranks;
   int64_t total = n * k;
-  slab_sum_blocks_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(slabs, nseg, panel_rows, slab_stride, KP, n, k, kc, q_send);
+  slab_sum_blocks_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(slabs, segmask, panel_rows, slab_stride, KP, n, k, kc, q_send);
   return hipGetLastError();
 }
 
