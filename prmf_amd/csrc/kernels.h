@@ -41,6 +41,8 @@ struct FactorView {
 // ---------------------------------------------------------------------------
 hipError_t launch_pack_factor(const FactorView& f, int x_dtype, int NT, int64_t Kpad, void* packed, hipStream_t s);
 struct GemmPlan {
+  int nw = 8;               // waves per workgroup
+  bool bdb = true;          // packed factor double-buffered in LDS
   int panel_rows = 0;       // rows per panel (= rows of one workgroup tile)
   int panels = 0;           // row panels
   int nchunks = 0;          // reduction chunks per row (even)

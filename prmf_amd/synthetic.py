@@ -8,6 +8,7 @@ CONFIGS = {
     "c2": (5000, 10000, 16, 50, "f32"),
     "c3": (50000, 20000, 64, 300, "bf16"),
     "c5": (200000, 25000, 128, 1000, "bf16"),
+    "c5shard": (25000, 25000, 128, 1000, "bf16"),     # one rank's share of c5 on 8 GPUs
 }
 
 
