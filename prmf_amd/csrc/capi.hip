@@ -70,7 +70,8 @@ struct prmf_ctx {
   double* colres = nullptr;           // [kc][2]
   double* vpartial = nullptr;         // [v_update_blocks][kc+1]
   int vblocks = 0;
-  bool fused_u = false, fused_v = false, gram_v_done = false;   // MFMA epilogues (k % 4 == 0; V path single-rank only)
+  bool fused_u = false, fused_v = false, gram_v_done = false;
+  bool graph_done = false;            // the pathway terms of this iteration were already computed in phase_u (merged launch)   // MFMA epilogues (k % 4 == 0; V path single-rank only)
 
   // hyper-parameters + records
   double* hyper = nullptr;            // device: gamma, delta, tradeoff
@@ -517,6 +518,7 @@ int prmf_begin(prmf_ctx* c, float* dU, float* dV, double gamma, double delta, do
   c->hyper_host[3] = 0.0;
   HIP_TRY(c, hipMemcpyAsync(c->hyper, c->hyper_host, 4 * sizeof(double), hipMemcpyHostToDevice, s));
   c->cursor = 0;
+  c->graph_done = false;
   if (!c->prepared && (rc = prepare(c, s))) return rc;
   return PRMF_OK;
 }
@@ -541,7 +543,14 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
       HIP_TRY(c, launch_u_epilogue(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP,
                                    c->Gv, c->x_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, s));
       if (gram_done) {
-        HIP_TRY(c, launch_gram_reduce((const float*)c->gram_partial, epilogue_blocks(c->Kpad_xt), c->k, c->gram_buf, s));
+        if (c->fused_v) {
+          // one launch: reduce U^T U and compute the pathway terms (they depend on the old V and gamma/delta only)
+          HIP_TRY(c, launch_mid((const float*)c->gram_partial, epilogue_blocks(c->Kpad_xt), c->k, c->gram_buf, c->lib,
+                                c->active_dev, c->V, c->hyper, c->gnum, c->gden, s));
+          c->graph_done = true;
+        } else {
+          HIP_TRY(c, launch_gram_reduce((const float*)c->gram_partial, epilogue_blocks(c->Kpad_xt), c->k, c->gram_buf, s));
+        }
         return PRMF_OK;
       }
     } else {
@@ -581,7 +590,9 @@ int prmf_phase_v(prmf_ctx* c, void* stream) {
   if ((rc = set_device(c))) return rc;
   hipStream_t s = (hipStream_t)stream;
   // sparse pathway terms on the OLD V                    (:431-438)
-  HIP_TRY(c, launch_graph_terms(c->lib, c->active_dev, c->col0, c->ncols, c->V, c->k, c->hyper, c->gnum, c->gden, s));
+  if (!c->graph_done)
+    HIP_TRY(c, launch_graph_terms(c->lib, c->active_dev, c->col0, c->ncols, c->V, c->k, c->hyper, c->gnum, c->gden, s));
+  c->graph_done = false;
   // V_own <- V * (Q + gnum) / max(V Gu + gden, eps)      (:425, :440-444)
   double* extras = reinterpret_cast<double*>(c->v_send + c->extras_off);
   if (c->fused_v) {
@@ -589,8 +600,9 @@ int prmf_phase_v(prmf_ctx* c, void* stream) {
     HIP_TRY(c, launch_v_epilogue(c->V, c->n, c->k, c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP,
                                  c->gram_buf, c->pos, c->gnum, c->gden, c->lib.max_support, c->x_dtype, c->Vp, c->Kpad_x,
                                  c->vpartial, (float*)c->gram_partial, &c->gram_v_done, s));
-    HIP_TRY(c, launch_objective_terms(c->lib, c->active_dev, 0, c->k, c->k, c->n, c->V, c->vpartial, c->vblocks, c->colres,
-                                      c->obj_scratch, extras, s));
+    if (!c->gram_v_done)   // otherwise the objective pieces ride along with the V^T V reduction in phase_post
+      HIP_TRY(c, launch_objective_terms(c->lib, c->active_dev, 0, c->k, c->k, c->n, c->V, c->vpartial, c->vblocks, c->colres,
+                                        c->obj_scratch, extras, s));
     return PRMF_OK;
   }
   HIP_TRY(c, launch_v_update(c->V, c->n, c->k, c->col0, c->ncols, c->kc, c->q_recv, c->gram_buf, c->pos, c->gnum, c->gden,
@@ -611,12 +623,17 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
     HIP_TRY(c, launch_assemble_v(c->v_recv, c->nranks, c->v_send_floats, c->kc, c->n, c->k, c->V, s));
     HIP_TRY(c, launch_pack_factor(fv, c->x_dtype, c->NT, c->Kpad_x, c->Vp, s));
   }
-  if (c->fused_v && c->gram_v_done)
-    HIP_TRY(c, launch_gram_reduce((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x), c->k, c->Gv, s));
-  else
-    HIP_TRY(c, launch_gram(fv, c->gram_partial, c->Gv, s));
+  if (c->fused_v && c->gram_v_done) {
+    HIP_TRY(c, launch_post((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x), c->k, c->Gv, c->lib, c->active_dev, c->V,
+                           c->vpartial, c->vblocks, c->colres, c->obj_scratch, s));
+    HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->nranks, c->v_send_floats, c->extras_off, c->norm_x_sq,
+                               c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, c->vpartial, c->vblocks, c->colres, s));
+    c->cursor++;
+    return PRMF_OK;
+  }
+  HIP_TRY(c, launch_gram(fv, c->gram_partial, c->Gv, s));
   HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->nranks, c->v_send_floats, c->extras_off,
-                             c->norm_x_sq, c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, s));
+                             c->norm_x_sq, c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, nullptr, 0, nullptr, s));
   c->cursor++;
   return PRMF_OK;
 }
@@ -773,6 +790,9 @@ int prmf_score_candidates(prmf_ctx* c, const float* dV, double* scores_out, void
   HIP_TRY(c, hipStreamSynchronize(s));
   return PRMF_OK;
 }
+
+/* debug (not in the public header): device buffer of 2*grid uint64 start/end stamps of the next sweep launches */
+extern "C" int prmf_debug_set_stamps(void* dev_buf) { prmf::g_sweep_stamps = (unsigned long long*)dev_buf; return 0; }
 
 int prmf_get_sweep_info(const prmf_ctx* c, prmf_sweep_info* out) {
   if (!c || !out) return PRMF_ERR_ARG;

@@ -220,7 +220,8 @@ template <bool BF16, int MT, int NT, int NW, bool BDB>
 __global__ void __launch_bounds__(64 * NW)
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
              const uint4* __restrict__ Bp, int npanels, int ngroups /* chunk pairs per row */, int nx, int pmax,
-             float* __restrict__ slabs, int64_t slab_stride) {
+             float* __restrict__ slabs, int64_t slab_stride, unsigned long long* __restrict__ stamps /* debug, may be null */) {
+  if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x] = wall_clock64();
   constexpr int NTHR = 64 * NW;
   constexpr int BCH = BF16 ? 512 * NT : 256 * NT;   // uint4 per packed chunk
   constexpr int BPT = (BCH + NTHR - 1) / NTHR;      // uint4 staged per thread per chunk (last one may be partial)
@@ -332,6 +333,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
             make_float4(acc[mt][t][4 * q4], acc[mt][t][4 * q4 + 1], acc[mt][t][4 * q4 + 2], acc[mt][t][4 * q4 + 3]);
   }
   }   // segments
+  if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x + 1] = wall_clock64();
 }
 
 struct SweepVariant { int nw; bool bdb; int wgs_per_cu; };
@@ -418,13 +420,15 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus) {
   return p;
 }
 
+unsigned long long* g_sweep_stamps = nullptr;   // debug: per-workgroup start/end stamps (tools/wg_spread.py)
+
 template <bool BF16, int NW, bool BDB>
 static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda16, int64_t M_store, const void* Bp,
                                   int NT, float* slabs, int64_t slab_stride, hipStream_t s) {
   dim3 grid(p.grid), block(64 * NW);
 #define PRMF_LAUNCH(NTV)                                                                                          \
   sweep_kernel<BF16, 1, NTV, NW, BDB><<<grid, block, 0, s>>>((const uint4*)A, lda16, M_store, (const uint4*)Bp, \
-                                                             p.panels, p.ngroups, p.nx, p.pmax, slabs, slab_stride)
+                                                             p.panels, p.ngroups, p.nx, p.pmax, slabs, slab_stride, g_sweep_stamps)
   switch (NT) {
     case 1: PRMF_LAUNCH(1); break;
     case 2: PRMF_LAUNCH(2); break;

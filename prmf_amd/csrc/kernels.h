@@ -54,6 +54,7 @@ struct GemmPlan {
   std::vector<uint32_t> segmask;   // [panels] bit s set <=> slab s holds a segment of this panel
 };
 GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus);
+extern unsigned long long* g_sweep_stamps;   // debug only
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
                        const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s);
 hipError_t launch_copy_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols,
@@ -121,7 +122,15 @@ hipError_t launch_assemble_v(const float* v_recv, int nranks, int64_t blk_stride
 // objective record + tradeoff feedback
 hipError_t launch_finalize(const double* Gu, const double* Gv, int k, const float* v_recv, int nranks,
                            int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* hyper /*gamma,delta,tradeoff*/,
-                           double* record /*8 doubles*/, hipStream_t s);
+                           double* record /*8 doubles*/, const double* loc_partial, int loc_nblocks,
+                           const double* loc_colres, hipStream_t s);
+// merged small launches of the single-rank path
+hipError_t launch_mid(const float* gram_partial, int nparts, int k, double* Gu, const PathwayLibDev& lib,
+                      const int32_t* active_dev, const float* V, const double* hyper, float* gnum, float* gden,
+                      hipStream_t s);
+hipError_t launch_post(const float* gram_partial, int nparts, int k, double* Gv, const PathwayLibDev& lib,
+                       const int32_t* active_dev, const float* V, const double* partial, int nblocks, double* colres,
+                       double* scratch, hipStream_t s);
 // candidate scores k x P
 hipError_t launch_score_candidates(const PathwayLibDev& lib, const float* V, int64_t n, int k,
                                    double* colnorm_scratch, double* scores, hipStream_t s);

@@ -190,11 +190,10 @@ __global__ void __launch_bounds__(256) gram_mfma_kernel(FactorView f, float* __r
 // G[e] = sum over the workgroup partials in float64, fixed order: 8 threads per entry,
 // thread `sub` sums partials sub, sub+8, ... with 4 independent loads in flight, the 8
 // sub-sums are then combined in order.
-__global__ void __launch_bounds__(256) gram_reduce_kernel(const float* __restrict__ partial, int nparts, int kk2,
-                                                          double* __restrict__ G) {
-  __shared__ double red[8][32];
+__device__ __forceinline__ void gram_reduce_body(const float* __restrict__ partial, int nparts, int kk2,
+                                                 double* __restrict__ G, int vblock, double (*red)[32]) {
   const int el = threadIdx.x & 31, sub = threadIdx.x >> 5;
-  const int e = blockIdx.x * 32 + el;
+  const int e = vblock * 32 + el;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   if (e < kk2) {
     int b = sub;
@@ -213,6 +212,12 @@ __global__ void __launch_bounds__(256) gram_reduce_kernel(const float* __restric
     for (int j = 1; j < 8; ++j) t += red[j][el];
     G[e] = t;
   }
+}
+
+__global__ void __launch_bounds__(256) gram_reduce_kernel(const float* __restrict__ partial, int nparts, int kk2,
+                                                          double* __restrict__ G) {
+  __shared__ double red[8][32];
+  gram_reduce_body(partial, nparts, kk2, G, blockIdx.x, red);
 }
 
 hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStream_t s) {
@@ -671,11 +676,10 @@ hipError_t launch_build_pos(const PathwayLibDev& lib, const int32_t* active_dev,
 // once into LDS, the CSR rows (support-local column indices) then read LDS only.
 // ---------------------------------------------------------------------------
 template <bool USE_LDS>
-__global__ void __launch_bounds__(256)
-graph_terms_kernel(PathwayLibDev lib, const int32_t* __restrict__ active, int col0, const float* __restrict__ V, int k,
-                   const double* __restrict__ hyper, float* __restrict__ gnum, float* __restrict__ gden) {
-  extern __shared__ __attribute__((aligned(16))) float vs[];
-  const int c = blockIdx.x, kk = col0 + c;
+__device__ __forceinline__ void graph_terms_body(const PathwayLibDev& lib, const int32_t* __restrict__ active, int col0, int c,
+                                                 const float* __restrict__ V, int k, const double* __restrict__ hyper,
+                                                 float* __restrict__ gnum, float* __restrict__ gden, float* vs) {
+  const int kk = col0 + c;
   const int p = active[kk];
   const int64_t s0 = lib.sup_ptr[p];
   const int ns = (int)(lib.sup_ptr[p + 1] - s0);
@@ -696,6 +700,37 @@ graph_terms_kernel(PathwayLibDev lib, const int32_t* __restrict__ active, int co
     gnum[(int64_t)c * lib.max_support + s] = (float)(gamma * wv + delta / (vp1 * vp1));
     gden[(int64_t)c * lib.max_support + s] = (float)(gamma * (lib.sup_deg[s0 + s] * v));
   }
+}
+
+template <bool USE_LDS>
+__global__ void __launch_bounds__(256)
+graph_terms_kernel(PathwayLibDev lib, const int32_t* __restrict__ active, int col0, const float* __restrict__ V, int k,
+                   const double* __restrict__ hyper, float* __restrict__ gnum, float* __restrict__ gden) {
+  extern __shared__ __attribute__((aligned(16))) float vs[];
+  graph_terms_body<USE_LDS>(lib, active, col0, blockIdx.x, V, k, hyper, gnum, gden, vs);
+}
+
+// One launch for the two small jobs between the U epilogue and the second sweep (single-rank path):
+// blocks [0, nred): reduce the U^T U partials; blocks [nred, nred + k): pathway terms of column b - nred.
+template <bool USE_LDS>
+__global__ void __launch_bounds__(256)
+mid_kernel(const float* __restrict__ gram_partial, int nparts, int k, double* __restrict__ Gu, int nred, PathwayLibDev lib,
+           const int32_t* __restrict__ active, const float* __restrict__ V, const double* __restrict__ hyper,
+           float* __restrict__ gnum, float* __restrict__ gden) {
+  extern __shared__ __attribute__((aligned(16))) float vs[];
+  __shared__ double red[8][32];
+  if ((int)blockIdx.x < nred) gram_reduce_body(gram_partial, nparts, k * k, Gu, blockIdx.x, red);
+  else graph_terms_body<USE_LDS>(lib, active, 0, blockIdx.x - nred, V, k, hyper, gnum, gden, vs);
+}
+
+hipError_t launch_mid(const float* gram_partial, int nparts, int k, double* Gu, const PathwayLibDev& lib,
+                      const int32_t* active_dev, const float* V, const double* hyper, float* gnum, float* gden,
+                      hipStream_t s) {
+  const int nred = (k * k + 31) / 32;
+  const size_t lds = (size_t)lib.max_support * sizeof(float);
+  if (lds <= 64 * 1024) mid_kernel<true><<<nred + k, 256, lds, s>>>(gram_partial, nparts, k, Gu, nred, lib, active_dev, V, hyper, gnum, gden);
+  else mid_kernel<false><<<nred + k, 256, 0, s>>>(gram_partial, nparts, k, Gu, nred, lib, active_dev, V, hyper, gnum, gden);
+  return hipGetLastError();
 }
 
 hipError_t launch_graph_terms(const PathwayLibDev& lib, const int32_t* active_dev, int col0, int ncols, const float* V,
@@ -831,12 +866,10 @@ hipError_t launch_v_update(const float* V, int64_t n, int k, int col0, int ncols
 //   vhat = v / ||v|| ; y = D^-1/2 vhat on the support
 //   manifold_k = y^T (D y - W y) ; ignore_k = sum_{i in S} 1 / (vhat_i + 1)
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-objective_col_kernel(PathwayLibDev lib, const int32_t* __restrict__ active, int col0, int kc,
-                     const float* __restrict__ v_send, const double* __restrict__ partial, int nblocks,
-                     double* __restrict__ colres, double* __restrict__ scratch) {
-  __shared__ double red[256];
-  const int c = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void objective_col_body(const PathwayLibDev& lib, const int32_t* __restrict__ active, int col0, int kc, int c,
+                                                   const float* __restrict__ v_send, const double* __restrict__ partial, int nblocks,
+                                                   double* __restrict__ colres, double* __restrict__ scratch, double* red) {
+  const int tid = threadIdx.x;
   double sq = 0.0;
   for (int b = tid; b < nblocks; b += 256) sq += partial[(int64_t)b * (kc + 1) + c];
   sq = block_sum_256(sq, red);
@@ -866,6 +899,33 @@ objective_col_kernel(PathwayLibDev lib, const int32_t* __restrict__ active, int 
     colres[2 * c] = man;
     colres[2 * c + 1] = ign;
   }
+}
+
+__global__ void __launch_bounds__(256)
+objective_col_kernel(PathwayLibDev lib, const int32_t* __restrict__ active, int col0, int kc,
+                     const float* __restrict__ v_send, const double* __restrict__ partial, int nblocks,
+                     double* __restrict__ colres, double* __restrict__ scratch) {
+  __shared__ double red[256];
+  objective_col_body(lib, active, col0, kc, blockIdx.x, v_send, partial, nblocks, colres, scratch, red);
+}
+
+// One launch after the V epilogue (single-rank path): blocks [0, nred): reduce the V^T V partials;
+// blocks [nred, nred + k): objective pieces of column b - nred.
+__global__ void __launch_bounds__(256)
+post_kernel(const float* __restrict__ gram_partial, int nparts, int k, double* __restrict__ Gv, int nred, PathwayLibDev lib,
+            const int32_t* __restrict__ active, const float* __restrict__ V, const double* __restrict__ partial, int nblocks,
+            double* __restrict__ colres, double* __restrict__ scratch) {
+  __shared__ double red[256];
+  if ((int)blockIdx.x < nred) gram_reduce_body(gram_partial, nparts, k * k, Gv, blockIdx.x, reinterpret_cast<double (*)[32]>(red));
+  else objective_col_body(lib, active, 0, k, blockIdx.x - nred, V, partial, nblocks, colres, scratch, red);
+}
+
+hipError_t launch_post(const float* gram_partial, int nparts, int k, double* Gv, const PathwayLibDev& lib,
+                       const int32_t* active_dev, const float* V, const double* partial, int nblocks, double* colres,
+                       double* scratch, hipStream_t s) {
+  const int nred = (k * k + 31) / 32;
+  post_kernel<<<nred + k, 256, 0, s>>>(gram_partial, nparts, k, Gv, nred, lib, active_dev, V, partial, nblocks, colres, scratch);
+  return hipGetLastError();
 }
 
 __global__ void __launch_bounds__(256)
@@ -926,10 +986,13 @@ hipError_t launch_assemble_v(const float* v_recv, int nranks, int64_t blk_stride
 // objective record (:362-371) + tradeoff feedback (:542-548)
 //   recon^2 = ||X||^2 - 2 <X^T U, V> + <U^T U, V^T V>
 // ---------------------------------------------------------------------------
+// `loc_partial` != nullptr (single rank): cross / manifold / ignore are summed here from the V epilogue's
+// per-wave partials and the per-column results instead of being read from the gathered rank extras.
 __global__ void __launch_bounds__(256)
 finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, int k, const float* __restrict__ v_recv,
                 int nranks, int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* __restrict__ hyper,
-                double* __restrict__ record) {
+                double* __restrict__ record, const double* __restrict__ loc_partial, int loc_nblocks,
+                const double* __restrict__ loc_colres) {
   __shared__ double red[256];
   const int tid = threadIdx.x;
   double gg = 0.0, fro = 0.0;
@@ -937,14 +1000,26 @@ finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, in
   for (int a = tid; a < k; a += 256) fro += Gu[a * k + a];
   gg = block_sum_256(gg, red);
   fro = block_sum_256(fro, red);
-  if (tid == 0) {
-    double cross = 0.0, man = 0.0, ign = 0.0;
-    for (int r = 0; r < nranks; ++r) {
-      const double* ex = reinterpret_cast<const double*>(v_recv + (int64_t)r * blk_stride + extras_off);
-      cross += ex[0];
-      man += ex[1];
-      ign += ex[2];
+  double lcross = 0.0, lman = 0.0, lign = 0.0;
+  if (loc_partial) {
+    for (int b = tid; b < loc_nblocks; b += 256) lcross += loc_partial[(int64_t)b * (k + 1) + k];
+    for (int c = tid; c < k; c += 256) {
+      lman += loc_colres[2 * c];
+      lign += loc_colres[2 * c + 1];
     }
+    lcross = block_sum_256(lcross, red);
+    lman = block_sum_256(lman, red);
+    lign = block_sum_256(lign, red);
+  }
+  if (tid == 0) {
+    double cross = lcross, man = lman, ign = lign;
+    if (!loc_partial)
+      for (int r = 0; r < nranks; ++r) {
+        const double* ex = reinterpret_cast<const double*>(v_recv + (int64_t)r * blk_stride + extras_off);
+        cross += ex[0];
+        man += ex[1];
+        ign += ex[2];
+      }
     const double gamma = hyper[0], delta = hyper[1], t = hyper[2];
     const double recon_sq = norm_x_sq - 2.0 * cross + gg;
     const double recon = sqrt(recon_sq > 0.0 ? recon_sq : 0.0);
@@ -967,8 +1042,9 @@ finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, in
 
 hipError_t launch_finalize(const double* Gu, const double* Gv, int k, const float* v_recv, int nranks,
                            int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* hyper, double* record,
-                           hipStream_t s) {
-  finalize_kernel<<<1, 256, 0, s>>>(Gu, Gv, k, v_recv, nranks, blk_stride, extras_off, norm_x_sq, hyper, record);
+                           const double* loc_partial, int loc_nblocks, const double* loc_colres, hipStream_t s) {
+  finalize_kernel<<<1, 256, 0, s>>>(Gu, Gv, k, v_recv, nranks, blk_stride, extras_off, norm_x_sq, hyper, record,
+                                    loc_partial, loc_nblocks, loc_colres);
   return hipGetLastError();
 }
 
