@@ -543,14 +543,11 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
       HIP_TRY(c, launch_u_epilogue(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP,
                                    c->Gv, c->x_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, s));
       if (gram_done) {
-        if (c->fused_v) {
-          // one launch: reduce U^T U and compute the pathway terms (they depend on the old V and gamma/delta only)
-          HIP_TRY(c, launch_mid((const float*)c->gram_partial, epilogue_blocks(c->Kpad_xt), c->k, c->gram_buf, c->lib,
-                                c->active_dev, c->V, c->hyper, c->gnum, c->gden, s));
-          c->graph_done = true;
-        } else {
-          HIP_TRY(c, launch_gram_reduce((const float*)c->gram_partial, epilogue_blocks(c->Kpad_xt), c->k, c->gram_buf, s));
-        }
+        // one launch: reduce (this rank's) U^T U and compute the pathway terms of the own columns
+        // (they depend on the old V and gamma/delta only)
+        HIP_TRY(c, launch_mid((const float*)c->gram_partial, epilogue_blocks(c->Kpad_xt), c->k, c->gram_buf, c->lib,
+                              c->active_dev, c->col0, c->ncols, c->V, c->hyper, c->gnum, c->gden, s));
+        c->graph_done = true;
         return PRMF_OK;
       }
     } else {
@@ -620,8 +617,21 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   FactorView fv{c->V, (int)c->n, c->k, c->k, 0};
   if (!c->fused_v) {
-    HIP_TRY(c, launch_assemble_v(c->v_recv, c->nranks, c->v_send_floats, c->kc, c->n, c->k, c->V, s));
-    HIP_TRY(c, launch_pack_factor(fv, c->x_dtype, c->NT, c->Kpad_x, c->Vp, s));
+    if (c->fused_u) {
+      bool gram_done = false;
+      HIP_TRY(c, launch_v_post(c->V, c->n, c->k, c->v_recv, c->v_send_floats, c->kc, c->KP, c->x_dtype, c->Vp, c->Kpad_x,
+                               (float*)c->gram_partial, &gram_done, s));
+      if (gram_done) {
+        HIP_TRY(c, launch_gram_reduce((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x), c->k, c->Gv, s));
+        HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->nranks, c->v_send_floats, c->extras_off,
+                                   c->norm_x_sq, c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, nullptr, 0, nullptr, s));
+        c->cursor++;
+        return PRMF_OK;
+      }
+    } else {
+      HIP_TRY(c, launch_assemble_v(c->v_recv, c->nranks, c->v_send_floats, c->kc, c->n, c->k, c->V, s));
+      HIP_TRY(c, launch_pack_factor(fv, c->x_dtype, c->NT, c->Kpad_x, c->Vp, s));
+    }
   }
   if (c->fused_v && c->gram_v_done) {
     HIP_TRY(c, launch_post((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x), c->k, c->Gv, c->lib, c->active_dev, c->V,

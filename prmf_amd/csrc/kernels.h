@@ -126,8 +126,11 @@ hipError_t launch_finalize(const double* Gu, const double* Gv, int k, const floa
                            const double* loc_colres, hipStream_t s);
 // merged small launches of the single-rank path
 hipError_t launch_mid(const float* gram_partial, int nparts, int k, double* Gu, const PathwayLibDev& lib,
-                      const int32_t* active_dev, const float* V, const double* hyper, float* gnum, float* gden,
-                      hipStream_t s);
+                      const int32_t* active_dev, int col0, int ncols, const float* V, const double* hyper, float* gnum,
+                      float* gden, hipStream_t s);
+// multi-rank phase_post in one pass: gathered blocks -> V, packed fragments, V^T V partials
+hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_t blk_stride, int kc, int KP, int x_dtype,
+                         void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, hipStream_t s);
 hipError_t launch_post(const float* gram_partial, int nparts, int k, double* Gv, const PathwayLibDev& lib,
                        const int32_t* active_dev, const float* V, const double* partial, int nblocks, double* colres,
                        double* scratch, hipStream_t s);

@@ -614,6 +614,71 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
   return hipGetLastError();
 }
 
+// Multi-rank phase_post in one pass: the gathered per-rank column blocks -> row-major V (caller's buffer),
+// packed fragments for the next sweep, V^T V partials (GRAM).  Same tile machinery as the epilogues.
+template <int NT, bool BF16, bool GRAM>
+__global__ void __launch_bounds__(256)
+v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ v_recv, int64_t blk_stride, int kc,
+              void* __restrict__ packed, int64_t ntiles_pack, float* __restrict__ gram_partial) {
+  constexpr int NP = NT * (NT + 1) / 2;
+  __shared__ float red[GRAM ? 4 : 1][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t wstride = (int64_t)gridDim.x * 4;
+  f32x16 g[GRAM ? NP : 1];
+  if constexpr (GRAM) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) g[p][i] = 0.f;
+  }
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles_pack; tile += wstride) {
+    const int64_t row0 = tile * 32;
+    float vn[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = 32 * t + c;
+      const int colc = col < k ? col : k - 1;
+      const int64_t cb = (int64_t)(colc / kc) * blk_stride + (colc % kc);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        float v = 0.f;
+        if (row < n && col < k) {
+          v = v_recv[cb + row * kc];
+          V[row * k + col] = v;
+        }
+        vn[t][i] = v;
+      }
+    }
+    if constexpr (GRAM) {
+      if (row0 < n) gram_accumulate<NT>(vn, g);
+    }
+    pack_tile_from_cd<NT, BF16>(vn, row0, lane, packed);
+  }
+  if constexpr (GRAM) gram_block_store<NT>(g, k, gram_partial + (int64_t)blockIdx.x * k * k, red);
+}
+
+hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_t blk_stride, int kc, int KP, int x_dtype,
+                         void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, hipStream_t s) {
+  const int NT = KP / 32;
+  const int64_t ntiles = Kpad / 32;
+  const int grid = epilogue_blocks(Kpad);
+  *gram_done = NT <= 2;
+#define PRMF_VPOST(NTV, GR)                                                                                      \
+  if (x_dtype == 1) v_post_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial); \
+  else v_post_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial)
+  switch (NT) {
+    case 1: PRMF_VPOST(1, true); break;
+    case 2: PRMF_VPOST(2, true); break;
+    case 3: PRMF_VPOST(3, false); break;
+    case 4: PRMF_VPOST(4, false); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef PRMF_VPOST
+  return hipGetLastError();
+}
+
 // reduce `nparts` per-workgroup Gram partials (written by an epilogue) into G
 hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G, hipStream_t s);
 
@@ -715,21 +780,22 @@ graph_terms_kernel(PathwayLibDev lib, const int32_t* __restrict__ active, int co
 template <bool USE_LDS>
 __global__ void __launch_bounds__(256)
 mid_kernel(const float* __restrict__ gram_partial, int nparts, int k, double* __restrict__ Gu, int nred, PathwayLibDev lib,
-           const int32_t* __restrict__ active, const float* __restrict__ V, const double* __restrict__ hyper,
+           const int32_t* __restrict__ active, int col0, const float* __restrict__ V, const double* __restrict__ hyper,
            float* __restrict__ gnum, float* __restrict__ gden) {
   extern __shared__ __attribute__((aligned(16))) float vs[];
   __shared__ double red[8][32];
   if ((int)blockIdx.x < nred) gram_reduce_body(gram_partial, nparts, k * k, Gu, blockIdx.x, red);
-  else graph_terms_body<USE_LDS>(lib, active, 0, blockIdx.x - nred, V, k, hyper, gnum, gden, vs);
+  else graph_terms_body<USE_LDS>(lib, active, col0, blockIdx.x - nred, V, k, hyper, gnum, gden, vs);
 }
 
+// (col0, ncols): the latent columns this rank owns (all k with one rank)
 hipError_t launch_mid(const float* gram_partial, int nparts, int k, double* Gu, const PathwayLibDev& lib,
-                      const int32_t* active_dev, const float* V, const double* hyper, float* gnum, float* gden,
-                      hipStream_t s) {
+                      const int32_t* active_dev, int col0, int ncols, const float* V, const double* hyper, float* gnum,
+                      float* gden, hipStream_t s) {
   const int nred = (k * k + 31) / 32;
   const size_t lds = (size_t)lib.max_support * sizeof(float);
-  if (lds <= 64 * 1024) mid_kernel<true><<<nred + k, 256, lds, s>>>(gram_partial, nparts, k, Gu, nred, lib, active_dev, V, hyper, gnum, gden);
-  else mid_kernel<false><<<nred + k, 256, 0, s>>>(gram_partial, nparts, k, Gu, nred, lib, active_dev, V, hyper, gnum, gden);
+  if (lds <= 64 * 1024) mid_kernel<true><<<nred + ncols, 256, lds, s>>>(gram_partial, nparts, k, Gu, nred, lib, active_dev, col0, V, hyper, gnum, gden);
+  else mid_kernel<false><<<nred + ncols, 256, 0, s>>>(gram_partial, nparts, k, Gu, nred, lib, active_dev, col0, V, hyper, gnum, gden);
   return hipGetLastError();
 }
 
