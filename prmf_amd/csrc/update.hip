@@ -691,25 +691,45 @@ hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G
 // ---------------------------------------------------------------------------
 // Q slabs -> per-owner column blocks  q_send[r][j][c],  column kk = r*kc + c
 // ---------------------------------------------------------------------------
+template <int NT>
 __global__ void __launch_bounds__(256)
 slab_sum_blocks_kernel(const float* __restrict__ slabs, const uint32_t* __restrict__ segmask, int panel_rows,
-                       int64_t slab_stride, int KP, int64_t n, int k, int kc, float* __restrict__ q_send) {
-  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n * k) return;
-  int64_t j = idx / k;
-  int kk = (int)(idx - j * k);
-  float v = 0.f;
-  const int64_t si = slab_index(j, kk, KP >> 5);
-  for (uint32_t mk = segmask[j / panel_rows]; mk; mk &= mk - 1) v += slabs[(int64_t)(__ffs(mk) - 1) * slab_stride + si];
-  int r = kk / kc, c = kk - r * kc;
-  q_send[((int64_t)r * n + j) * kc + c] = v;
+                       int64_t slab_stride, int64_t n, int k, int kc, float* __restrict__ q_send) {
+  // one wave per 32-row tile: fragment-order 16-B loads, summed over the tile's segments, written by owner block
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t ntiles = (n + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = tile * 32;
+    float q[NT][16];
+    load_slab_tile<NT>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = 32 * t + c;
+      if (col < k) {
+        const int r = col / kc, cc = col - r * kc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (row < n) q_send[((int64_t)r * n + row) * kc + cc] = q[t][i];
+        }
+      }
+    }
+  }
 }
 
 hipError_t launch_slab_sum_blocks(const float* slabs, const uint32_t* segmask, int panel_rows, int64_t slab_stride, int KP,
                                   int64_t n, int k, int kc, int nranks, float* q_send, hipStream_t s) {
   (void)nranks;
-  int64_t total = n * k;
-  slab_sum_blocks_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(slabs, segmask, panel_rows, slab_stride, KP, n, k, kc, q_send);
+  const int64_t tiles = (n + 31) / 32;
+  const int grid = (int)((tiles + 3) / 4 < 2048 ? (tiles + 3) / 4 : 2048);
+  switch (KP / 32) {
+    case 1: slab_sum_blocks_kernel<1><<<grid, 256, 0, s>>>(slabs, segmask, panel_rows, slab_stride, n, k, kc, q_send); break;
+    case 2: slab_sum_blocks_kernel<2><<<grid, 256, 0, s>>>(slabs, segmask, panel_rows, slab_stride, n, k, kc, q_send); break;
+    case 3: slab_sum_blocks_kernel<3><<<grid, 256, 0, s>>>(slabs, segmask, panel_rows, slab_stride, n, k, kc, q_send); break;
+    case 4: slab_sum_blocks_kernel<4><<<grid, 256, 0, s>>>(slabs, segmask, panel_rows, slab_stride, n, k, kc, q_send); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

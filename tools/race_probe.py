@@ -1,5 +1,5 @@
 import os, sys, math
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from prmf_amd import PathwayLibrary, synthetic as syn
 from prmf_amd.solver import PrmfEngine

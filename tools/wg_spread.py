@@ -1,6 +1,6 @@
 """Finish-time spread of the sweep's persistent workgroups (debug stamps, 100 MHz real-time counter)."""
 import os, sys, ctypes as C
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from prmf_amd import PathwayLibrary, synthetic as syn
 from prmf_amd.solver import PrmfEngine
