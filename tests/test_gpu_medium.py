@@ -59,3 +59,60 @@ def test_medium_vs_oracle_and_deterministic(m, n, k, x_dtype):
     for U, V, objs in outs[1:]:
         assert np.array_equal(U, outs[0][0]) and np.array_equal(V, outs[0][1]), "run-to-run difference"
         assert objs == outs[0][2]
+
+
+@pytest.mark.parametrize("xcd", ["4", "8"])
+def test_xcd_sliced_decomposition_matches_unsliced(xcd, monkeypatch):
+    """The XCD-aware slicing of the reduction only changes which workgroup sums which chunks and in
+    which slab: results must stay within float32 summation-order noise of the unsliced run and be
+    deterministic themselves."""
+    case = synth.small_case(seed=9, m=1500, n=6000, k=64, P=8, order=120, bf16_x=True)
+    monkeypatch.setenv("PRMF_SWEEP_XCD", "1")
+    base = run_gpu(case, "bf16", 4)[0]
+    monkeypatch.setenv("PRMF_SWEEP_XCD", xcd)
+    a, b = run_gpu(case, "bf16", 4, repeats=2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert rel(a[0], base[0]) < 1e-5 and rel(a[1], base[1]) < 1e-5
+    for x, y in zip(a[2], base[2]):
+        assert abs(x["obj"] - y["obj"]) <= 1e-5 * abs(y["obj"])
+
+
+def test_full_size_c3_properties():
+    """BASELINE.json's headline size (50000 x 20000, k = 64, 300 pathways, bf16 X): size-independent
+    properties instead of an oracle run -- the Gram-identity reconstruction error equals the directly
+    computed ||X - U V^T||_F, fro = sum U^2, V >= eps, finite, and two runs are bit-identical."""
+    import math
+    import torch
+    from prmf_amd import PathwayLibrary, synthetic as syn
+    from prmf_amd.solver import PrmfEngine
+    m, n, k, P = syn.CONFIGS["c3"][:4]
+    dev = "cuda:0"
+    Xd = syn.x_rows_torch(torch, dev, 3, n, k, 0, m, torch.bfloat16)
+    eng = PrmfEngine(m, n, k, x_dtype="bf16")
+    nsq = eng.set_x(Xd)
+    eng.set_library(PathwayLibrary.from_edge_lists(n, syn.tree_pathways(n, P, 300, 3)))
+    eng.set_active([kk % P for kk in range(k)])
+    normx = math.sqrt(nsq)
+    outs = []
+    for rep in range(2):
+        U = syn.init_factor_torch(torch, dev, 4, m, k)
+        V = syn.init_factor_torch(torch, dev, 5, n, k)
+        eng.invalidate_factors()
+        objs, _ = eng.step(U, V, 3, normx / k, 10.0 / normx)
+        outs.append((U, V, objs))
+    U, V, objs = outs[0]
+    assert torch.equal(U, outs[1][0]) and torch.equal(V, outs[1][1]) and objs == outs[1][2]
+    assert torch.isfinite(U).all() and torch.isfinite(V).all() and float(V.min()) >= np.finfo(np.float32).eps
+    # direct residual in float64, row-chunked
+    acc = 0.0
+    Vd = V.double()
+    for r0 in range(0, m, 5000):
+        R = Xd[r0:r0 + 5000].double() - U[r0:r0 + 5000].double() @ Vd.T
+        acc += float((R * R).sum())
+    recon = math.sqrt(acc)
+    assert abs(objs[-1]["recon"] - recon) <= 1e-4 * recon, (objs[-1]["recon"], recon)
+    fro = float((U.double() ** 2).sum())
+    assert abs(objs[-1]["fro"] - fro) <= 1e-5 * fro
+    assert objs[-1]["obj"] == pytest.approx(objs[-1]["recon"] + objs[-1]["gamma"] * objs[-1]["manifold"]
+                                            + objs[-1]["delta"] * objs[-1]["ignore"] + objs[-1]["fro"], rel=1e-12)
+    eng.close()
