@@ -90,6 +90,8 @@ struct prmf_ctx {
   double ms_xv = 0, ms_xtu = 0, ms_total = 0;
   int timed_iters = 0;
 
+  SweepSide side{};                   // side stream for the sweeps' tail launches
+
   // RCCL (resolved at run time, see prmf_comm_init)
   ncclComm_t comm = nullptr;
 
@@ -302,6 +304,12 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
     fail(c, PRMF_ERR_HIP, "hipHostMalloc failed");
     return bail(PRMF_ERR_HIP);
   }
+  if (hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming) != hipSuccess) {
+    fail(c, PRMF_ERR_HIP, "side stream / events could not be created");
+    return bail(PRMF_ERR_HIP);
+  }
   if ((flags & PRMF_FLAG_TIMING) && (rc = prmf_set_timing(c, 1))) return bail(rc);
   *out = c;
   return PRMF_OK;
@@ -330,6 +338,9 @@ int prmf_destroy(prmf_ctx* c) {
     }
   }
   if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+  if (c->side.fork) (void)hipEventDestroy(c->side.fork);
+  if (c->side.join) (void)hipEventDestroy(c->side.join);
+  if (c->side.stream) (void)hipStreamDestroy(c->side.stream);
   for (void* p : c->lib_allocs) dev_free(p);
   dev_free(c->active_dev);
   dev_free(c->pos);
@@ -534,7 +545,7 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
     const bool timing = (c->flags & PRMF_FLAG_TIMING) != 0;
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 0], s));
     // P = X V                                             (prmf_runner.py:420)
-    HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xv, c->X, c->ldx, c->m, c->Vp, c->NT, c->slabs, c->slab_stride_p, s));
+    HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xv, c->X, c->ldx, c->m, c->Vp, c->NT, c->slabs, c->slab_stride_p, s, c->side));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 1], s));
     // U <- U * P / (U Gv + U)                              (:421-422)
     FactorView fu{c->U, (int)c->m, c->k, c->k, 0};
@@ -570,7 +581,7 @@ int prmf_phase_q(prmf_ctx* c, void* stream) {
   if (c->m > 0) {
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 2], s));
     // Q = X^T U_new                                       (:424)
-    HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xtu, c->XT, c->ldxt, c->n, c->Up, c->NT, c->slabs, c->slab_stride_q, s));
+    HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xtu, c->XT, c->ldxt, c->n, c->Up, c->NT, c->slabs, c->slab_stride_q, s, c->side));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 3], s));
     if (!c->fused_v)
       HIP_TRY(c, launch_slab_sum_blocks(c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP, c->n, c->k, c->kc,

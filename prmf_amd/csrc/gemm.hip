@@ -219,8 +219,9 @@ __device__ __forceinline__ void store_b_chunk(u32x4* sb, const u32x4 (&src)[NB],
 template <bool BF16, int MT, int NT, int NW, bool BDB>
 __global__ void __launch_bounds__(64 * NW)
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
-             const uint4* __restrict__ Bp, int npanels, int ngroups /* chunk pairs per row */, int nx, int pmax,
-             float* __restrict__ slabs, int64_t slab_stride, unsigned long long* __restrict__ stamps /* debug, may be null */) {
+             const uint4* __restrict__ Bp, int npanels, int g_begin, int ngroups /* chunk pairs [g_begin, g_begin+ngroups) of every row */,
+             int nx, int pmax, int seg_base, float* __restrict__ slabs, int64_t slab_stride,
+             unsigned long long* __restrict__ stamps /* debug, may be null */) {
   if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x] = wall_clock64();
   constexpr int NTHR = 64 * NW;
   constexpr int BCH = BF16 ? 512 * NT : 256 * NT;   // uint4 per packed chunk
@@ -245,8 +246,8 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   const int xcd = (int)(blockIdx.x & 7), x = xcd % nx;
   const int64_t Gx = gridDim.x / nx;                             // workgroups per slice
   const int wj = (int)(blockIdx.x >> 3) * (8 / nx) + xcd / nx;   // index within the slice
-  const int gs0 = (int)((int64_t)ngroups * x / nx);
-  const int L = (int)((int64_t)ngroups * (x + 1) / nx) - gs0;      // chunk pairs in this slice
+  const int gs0 = g_begin + (int)((int64_t)ngroups * x / nx);
+  const int L = g_begin + (int)((int64_t)ngroups * (x + 1) / nx) - gs0;      // chunk pairs in this slice
   const int64_t T = (int64_t)npanels * L;
   int64_t unit = T * wj / Gx;
   const int64_t unit_end = L > 0 ? T * (wj + 1) / Gx : 0;
@@ -267,7 +268,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   const int g0 = (int)(unit - (int64_t)panel * L);
   const int g1 = (int)min((int64_t)L, g0 + (unit_end - unit));
   const int part = (int)(wj - (((int64_t)panel * L + 1) * Gx - 1) / T);   // wj minus the first workgroup of this (panel, slice)
-  const int seg = x * pmax + part;
+  const int seg = seg_base + x * pmax + part;
   unit += g1 - g0;
   const int c0 = 2 * (gs0 + g0);
   const int nch = 2 * (g1 - g0);
@@ -387,35 +388,63 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus) {
     }
   }
   if (G < 1) G = 1;
-  for (;;) {
-    // simulate the kernel's decomposition: which slabs does every panel receive?
-    p.grid = (int)G;
-    const int64_t Gx = G / p.nx;
-    std::vector<int> parts((size_t)p.panels * p.nx, 0);
-    p.pmax = 1;
-    for (int x = 0; x < p.nx; ++x) {
-      const int gs0 = (int)((int64_t)p.ngroups * x / p.nx);
-      const int L = (int)((int64_t)p.ngroups * (x + 1) / p.nx) - gs0;
+  // Optional tail launch (PRMF_SWEEP_TAIL=<percent>, default off): the last chunk pairs of every panel go
+  // to a second, small launch on a side stream, in the hope that the dispatcher starts its short workgroups
+  // as main workgroups finish (their finish times spread by +-7%).  Measured at 50000x20000: slower
+  // (X*V 0.355 -> 0.38 ms, X^T*U 0.37-0.39 -> 0.39-0.43 ms at 6-12%): the two queues do not interleave
+  // that way.  Kept as an experiment knob only.
+  int tail_pct = 0;
+  if (const char* e = getenv("PRMF_SWEEP_TAIL")) tail_pct = atoi(e);
+  p.tail_groups = 0;
+  if (tail_pct > 0 && G >= 64 && p.ngroups >= 32) {
+    p.tail_groups = (int)((int64_t)p.ngroups * tail_pct / 100);
+    if (p.tail_groups < 2) p.tail_groups = 0;
+  }
+  p.main_groups = p.ngroups - p.tail_groups;
+  p.tail_pieces = p.tail_groups > 12 ? 2 : 1;
+  p.tail_grid = p.tail_groups > 0 ? p.panels * p.tail_pieces : 0;
+
+  // which slabs does every panel receive?  simulate the kernel's decomposition for one launch
+  auto simulate = [&](int ngroups_sub, int nx, int64_t Gl, int seg_base, int* pmax_out, std::vector<uint32_t>* mask) -> bool {
+    const int64_t Gx = Gl / nx;
+    std::vector<int> parts((size_t)p.panels * nx, 0);
+    int pmax = 1;
+    for (int x = 0; x < nx; ++x) {
+      const int gs0 = (int)((int64_t)ngroups_sub * x / nx);
+      const int L = (int)((int64_t)ngroups_sub * (x + 1) / nx) - gs0;
       if (L <= 0) continue;
       const int64_t T = (int64_t)p.panels * L;
       for (int q = 0; q < p.panels; ++q) {
         const int64_t w0 = (((int64_t)q * L + 1) * Gx - 1) / T;
         const int64_t w1 = (((int64_t)(q + 1) * L) * Gx - 1) / T;
         const int n = (int)(w1 - w0 + 1);
-        parts[(size_t)q * p.nx + x] = n;
-        if (n > p.pmax) p.pmax = n;
+        parts[(size_t)q * nx + x] = n;
+        if (n > pmax) pmax = n;
       }
     }
-    if (p.nx * p.pmax <= 32) {
-      p.segmask.assign(p.panels, 0u);
+    *pmax_out = pmax;
+    if (seg_base + nx * pmax > 32) return false;
+    if (mask)
       for (int q = 0; q < p.panels; ++q)
-        for (int x = 0; x < p.nx; ++x)
-          for (int j = 0; j < parts[(size_t)q * p.nx + x]; ++j) p.segmask[q] |= 1u << (x * p.pmax + j);
-      p.max_seg = p.nx * p.pmax;
+        for (int x = 0; x < nx; ++x)
+          for (int j = 0; j < parts[(size_t)q * nx + x]; ++j) (*mask)[q] |= 1u << (seg_base + x * pmax + j);
+    return true;
+  };
+  for (;;) {
+    p.grid = (int)G;
+    p.segmask.assign(p.panels, 0u);
+    bool ok = simulate(p.main_groups, p.nx, G, 0, &p.pmax, &p.segmask);
+    p.tail_seg_base = p.nx * p.pmax;
+    p.tail_pmax = 1;
+    if (ok && p.tail_grid > 0) ok = simulate(p.tail_groups, 1, p.tail_grid, p.tail_seg_base, &p.tail_pmax, &p.segmask);
+    if (ok) {
+      p.max_seg = p.tail_seg_base + (p.tail_grid > 0 ? p.tail_pmax : 0);
       break;
     }
-    // too many segments per panel for the 32-bit mask: fewer slices, then fewer workgroups
-    if (p.nx > 1) p.nx = 1; else G = G > 16 ? G / 2 : 1;
+    // too many segments per panel for the 32-bit mask: drop the tail launch, then the slices, then workgroups
+    if (p.tail_grid > 0) { p.tail_grid = 0; p.tail_groups = 0; p.main_groups = p.ngroups; }
+    else if (p.nx > 1) p.nx = 1;
+    else G = G > 16 ? G / 2 : 1;
   }
   return p;
 }
@@ -424,11 +453,21 @@ unsigned long long* g_sweep_stamps = nullptr;   // debug: per-workgroup start/en
 
 template <bool BF16, int NW, bool BDB>
 static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda16, int64_t M_store, const void* Bp,
-                                  int NT, float* slabs, int64_t slab_stride, hipStream_t s) {
-  dim3 grid(p.grid), block(64 * NW);
-#define PRMF_LAUNCH(NTV)                                                                                          \
-  sweep_kernel<BF16, 1, NTV, NW, BDB><<<grid, block, 0, s>>>((const uint4*)A, lda16, M_store, (const uint4*)Bp, \
-                                                             p.panels, p.ngroups, p.nx, p.pmax, slabs, slab_stride, g_sweep_stamps)
+                                  int NT, float* slabs, int64_t slab_stride, hipStream_t s, const SweepSide& side) {
+  const bool tail = p.tail_grid > 0 && side.stream;
+  if (tail) {
+    hipError_t e = hipEventRecord(side.fork, s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side.stream, side.fork, 0);
+    if (e != hipSuccess) return e;
+  }
+#define PRMF_LAUNCH(NTV)                                                                                              \
+  sweep_kernel<BF16, 1, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), 0, s>>>(                                         \
+      (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, 0, tail ? p.main_groups : p.ngroups, p.nx, p.pmax, \
+      0, slabs, slab_stride, g_sweep_stamps);                                                                         \
+  if (tail)                                                                                                           \
+    sweep_kernel<BF16, 1, NTV, NW, BDB><<<dim3(p.tail_grid), dim3(64 * NW), 0, side.stream>>>(                        \
+        (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, p.main_groups, p.tail_groups, 1, p.tail_pmax,    \
+        p.tail_seg_base, slabs, slab_stride, nullptr)
   switch (NT) {
     case 1: PRMF_LAUNCH(1); break;
     case 2: PRMF_LAUNCH(2); break;
@@ -437,18 +476,24 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
     default: return hipErrorInvalidValue;
   }
 #undef PRMF_LAUNCH
-  return hipGetLastError();
+  hipError_t e = hipGetLastError();
+  if (tail && e == hipSuccess) {
+    e = hipEventRecord(side.join, side.stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, side.join, 0);
+  }
+  return e;
 }
 
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
-                       const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s) {
+                       const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s,
+                       const SweepSide& side) {
   const int64_t lda16 = lda * elem_bytes(x_dtype) / 16;
   const struct { int nw; bool bdb; } v{p.nw, p.bdb};
-#define PRMF_DISPATCH(BF)                                                                                              \
-  (v.nw == 8 ? (v.bdb ? launch_sweep_nt<BF, 8, true>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)         \
-                      : launch_sweep_nt<BF, 8, false>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s))       \
-              : (v.bdb ? launch_sweep_nt<BF, 4, true>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)        \
-                      : launch_sweep_nt<BF, 4, false>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)))
+#define PRMF_DISPATCH(BF)                                                                                                 \
+  (v.nw == 8 ? (v.bdb ? launch_sweep_nt<BF, 8, true>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)      \
+                      : launch_sweep_nt<BF, 8, false>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side))    \
+              : (v.bdb ? launch_sweep_nt<BF, 4, true>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)     \
+                      : launch_sweep_nt<BF, 4, false>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)))
   return x_dtype == 1 ? PRMF_DISPATCH(true) : PRMF_DISPATCH(false);
 #undef PRMF_DISPATCH
 }
