@@ -285,7 +285,7 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, (char**)&c->Up, (size_t)packed_bytes(c, c->Kpad_xt)))) return bail(rc);
   if ((rc = dev_alloc(c, &c->slabs, (size_t)slab_floats, false))) return bail(rc);
   int gb = gram_blocks(m_local > n ? m_local : n);
-  if (gb < 256) gb = 256;                      // the fused epilogues write up to 256 per-workgroup partials
+  if (gb < 512) gb = 512;                      // the fused epilogues write up to 512 per-workgroup partials
   if ((rc = dev_alloc(c, (float**)&c->gram_partial, (size_t)gb * k * k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->Gv, (size_t)k * k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->active_dev, (size_t)k))) return bail(rc);

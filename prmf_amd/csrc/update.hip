@@ -340,8 +340,10 @@ __device__ __forceinline__ void stage_gram(const double* __restrict__ G, int k, 
   }
 }
 
-// sum of a tile's slab segments, fragment order: 4 x float4 per (t) per lane, segment-outermost
-// (independent batches; a per-element loop over segments would serialise the round trips)
+// sum of a tile's slab segments (fragment order: 4 x float4 per t per lane), in slab-index order.
+// The loads of two segments are issued together (a data-dependent one-segment-per-iteration
+// loop costs a full memory round trip per segment: up to 8 per tile); missing slots of the last
+// batch re-read the first slab and are masked out of the sum.
 template <int NT>
 __device__ __forceinline__ void load_slab_tile(const float* __restrict__ slabs, int64_t slab_stride, uint32_t mask, int64_t tile,
                                                int lane, float (&p)[NT][16]) {
@@ -349,15 +351,38 @@ __device__ __forceinline__ void load_slab_tile(const float* __restrict__ slabs, 
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) p[t][i] = 0.f;
-  for (; mask; mask &= mask - 1) {
-    const float4* sl = reinterpret_cast<const float4*>(slabs + (int64_t)(__ffs(mask) - 1) * slab_stride);
+  const int64_t base = (tile * NT * 64 + lane) * 4;          // float4 index of (tile, t = 0, lane, q4 = 0)
+  while (mask) {
+    constexpr int NB = 2;
+    int sg[NB];
+    float on[NB];
+    const int first = __ffs(mask) - 1;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int j = 0; j < NB; ++j) {
+      sg[j] = mask ? __ffs(mask) - 1 : first;
+      on[j] = mask ? 1.f : 0.f;
+      mask &= mask - 1;
+    }
+    float4 v[NB][NT][4];
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const float4 v = sl[((tile * NT + t) * 64 + lane) * 4 + q4];
-        p[t][4 * q4] += v.x; p[t][4 * q4 + 1] += v.y; p[t][4 * q4 + 2] += v.z; p[t][4 * q4 + 3] += v.w;
-      }
+    for (int j = 0; j < NB; ++j) {
+      const float4* sl = reinterpret_cast<const float4*>(slabs + (int64_t)sg[j] * slab_stride) + base;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) v[j][t][q4] = sl[t * 256 + q4];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          p[t][4 * q4] += on[j] * v[j][t][q4].x;
+          p[t][4 * q4 + 1] += on[j] * v[j][t][q4].y;
+          p[t][4 * q4 + 2] += on[j] * v[j][t][q4].z;
+          p[t][4 * q4 + 3] += on[j] * v[j][t][q4].w;
+        }
   }
 }
 
@@ -402,7 +427,7 @@ __device__ __forceinline__ void gram_block_store(const f32x16 (&g)[NT * (NT + 1)
 
 // GRAM: also accumulate F_new^T F_new (per-workgroup partial [k*k] floats at gram_partial[blockIdx])
 template <int NT, bool BF16, bool GRAM>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, NT <= 2 ? 2 : 1)
 u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs, const uint32_t* __restrict__ segmask,
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gv, void* __restrict__ packed,
                   int64_t ntiles_pack, float* __restrict__ gram_partial) {
@@ -427,6 +452,7 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
     if (row0 < m) {
       // issue every load of the tile first (A layout, C/D layout, slabs), then the MFMA chain
       float ua[16 * NT], uu[NT][16], p[NT][16];
+      load_slab_tile<NT>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, p);
       load_tile_a_layout<NT>(U, m, k, row0, lane, ua);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -437,7 +463,6 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
           uu[t][i] = U[(row < m ? row : m - 1) * k + colc];
         }
       }
-      load_slab_tile<NT>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, p);
       f32x16 den[NT];
       tile_times_gram<NT>(ua, lane, Gs, den);
 #pragma unroll
@@ -470,7 +495,7 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
 int epilogue_blocks(int64_t rows) {
   int64_t tiles = (rows + 31) / 32;
   int64_t blocks = (tiles + 3) / 4;
-  if (blocks > 256) blocks = 256;
+  if (blocks > 512) blocks = 512;
   return (int)(blocks < 1 ? 1 : blocks);
 }
 
@@ -529,6 +554,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
     if (row0 < n) {
       float ua[16 * NT], vv[NT][16], q[NT][16];
       int ps[NT][16];
+      load_slab_tile<NT>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);
       load_tile_a_layout<NT>(V, n, k, row0, lane, ua);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -538,12 +564,20 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
           const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
           const int64_t rc = row < n ? row : n - 1;
           vv[t][i] = V[rc * k + colc];
-          ps[t][i] = pos[rc * k + colc];
         }
       }
-      load_slab_tile<NT>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);
       f32x16 den[NT];
       tile_times_gram<NT>(ua, lane, Gs, den);
+      // the position map is loaded after the MFMA chain, into the registers the A-layout tile has freed
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = 32 * t + c, colc = col < k ? col : k - 1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          ps[t][i] = pos[(row < n ? row : n - 1) * k + colc];
+        }
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int col = 32 * t + c;
