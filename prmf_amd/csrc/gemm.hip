@@ -337,17 +337,18 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x + 1] = wall_clock64();
 }
 
-struct SweepVariant { int nw; bool bdb; int wgs_per_cu; };
+struct SweepVariant { int nw; bool bdb; int wgs_per_cu; int mt; };
 // 8 waves per workgroup; B double-buffered (one barrier per chunk) while two workgroups still fit
 // the 160 KiB LDS (k <= 64: 32 KiB A tiles + 2 x 16 KiB B), single-buffered beyond (k = 128:
 // 32 + 32 KiB, measured 0.368 vs 0.396 ms against double-buffered at 1 workgroup per CU).
 static SweepVariant sweep_variant(int NT) {
-  SweepVariant r{8, NT <= 2, 2};
+  SweepVariant r{8, NT <= 2, 2, 1};
+  if (const char* e = getenv("PRMF_SWEEP_MT")) r.mt = (atoi(e) == 2 && NT <= 2) ? 2 : 1;
   if (const char* e = getenv("PRMF_SWEEP_NW")) r.nw = atoi(e) == 4 ? 4 : 8;
   if (const char* e = getenv("PRMF_SWEEP_BDB")) r.bdb = atoi(e) != 0;
-  const int lds_kib = r.nw * 4 + (r.bdb ? 2 : 1) * 8 * NT;
+  const int lds_kib = r.nw * 4 * r.mt + (r.bdb ? 2 : 1) * 8 * NT;
   r.wgs_per_cu = 160 / lds_kib;
-  if (r.wgs_per_cu * r.nw > 16) r.wgs_per_cu = 16 / r.nw;          // register-limited to 4 waves per SIMD
+  if (r.wgs_per_cu * r.nw > 16 / r.mt) r.wgs_per_cu = 16 / r.mt / r.nw;   // register-limited: 4 (MT=1) or 2 (MT=2) waves per SIMD
   if (r.wgs_per_cu < 1) r.wgs_per_cu = 1;
   if (const char* e = getenv("PRMF_SWEEP_WGS_PER_CU")) r.wgs_per_cu = atoi(e) > 0 ? atoi(e) : r.wgs_per_cu;
   return r;
@@ -358,7 +359,8 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus) {
   const SweepVariant v = sweep_variant(NT);
   p.nw = v.nw;
   p.bdb = v.bdb;
-  p.panel_rows = v.nw * 32;
+  p.mt = v.mt;
+  p.panel_rows = v.nw * 32 * v.mt;
   p.panels = (int)(round_up(M, p.panel_rows) / p.panel_rows);
   p.nchunks = (int)(Kpad / chunk_elems(x_dtype));          // even (K_PAD)
   p.ngroups = p.nchunks / 2;
@@ -451,7 +453,7 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus) {
 
 unsigned long long* g_sweep_stamps = nullptr;   // debug: per-workgroup start/end stamps (tools/wg_spread.py)
 
-template <bool BF16, int NW, bool BDB>
+template <bool BF16, int NW, bool BDB, int MTV>
 static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda16, int64_t M_store, const void* Bp,
                                   int NT, float* slabs, int64_t slab_stride, hipStream_t s, const SweepSide& side) {
   const bool tail = p.tail_grid > 0 && side.stream;
@@ -461,11 +463,11 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
     if (e != hipSuccess) return e;
   }
 #define PRMF_LAUNCH(NTV)                                                                                              \
-  sweep_kernel<BF16, 1, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), 0, s>>>(                                         \
+  sweep_kernel<BF16, MTV, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), 0, s>>>(                                         \
       (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, 0, tail ? p.main_groups : p.ngroups, p.nx, p.pmax, \
       0, slabs, slab_stride, g_sweep_stamps);                                                                         \
   if (tail)                                                                                                           \
-    sweep_kernel<BF16, 1, NTV, NW, BDB><<<dim3(p.tail_grid), dim3(64 * NW), 0, side.stream>>>(                        \
+    sweep_kernel<BF16, MTV, NTV, NW, BDB><<<dim3(p.tail_grid), dim3(64 * NW), 0, side.stream>>>(                        \
         (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, p.main_groups, p.tail_groups, 1, p.tail_pmax,    \
         p.tail_seg_base, slabs, slab_stride, nullptr)
   switch (NT) {
@@ -489,11 +491,18 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
                        const SweepSide& side) {
   const int64_t lda16 = lda * elem_bytes(x_dtype) / 16;
   const struct { int nw; bool bdb; } v{p.nw, p.bdb};
-#define PRMF_DISPATCH(BF)                                                                                                 \
-  (v.nw == 8 ? (v.bdb ? launch_sweep_nt<BF, 8, true>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)      \
-                      : launch_sweep_nt<BF, 8, false>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side))    \
-              : (v.bdb ? launch_sweep_nt<BF, 4, true>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)     \
-                      : launch_sweep_nt<BF, 4, false>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)))
+  if (p.mt == 2 && NT <= 2) {   // experiment: 64 rows per wave (B fragments reused twice), 4 or 8 waves
+    if (x_dtype == 1)
+      return v.nw == 8 ? launch_sweep_nt<true, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)
+                       : launch_sweep_nt<true, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side);
+    return v.nw == 8 ? launch_sweep_nt<false, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)
+                     : launch_sweep_nt<false, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side);
+  }
+#define PRMF_DISPATCH(BF)                                                                                                    \
+  (v.nw == 8 ? (v.bdb ? launch_sweep_nt<BF, 8, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)      \
+                      : launch_sweep_nt<BF, 8, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side))    \
+              : (v.bdb ? launch_sweep_nt<BF, 4, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)     \
+                      : launch_sweep_nt<BF, 4, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)))
   return x_dtype == 1 ? PRMF_DISPATCH(true) : PRMF_DISPATCH(false);
 #undef PRMF_DISPATCH
 }

@@ -16,7 +16,7 @@ namespace prmf {
 // and B a factor (V resp. U) pre-packed into MFMA B-fragment order.
 constexpr int ROW_BYTES_PER_CHUNK = 128;   // one reduction chunk = 128 B of every A row
 constexpr int K_PAD = 128;                 // reduction length padded to 128 elements: an even number of chunks (both dtypes)
-constexpr int M_PAD = 256;                 // rows padded to the largest workgroup panel
+constexpr int M_PAD = 512;                 // rows padded to the largest workgroup panel (8 waves x 64 rows)
 constexpr int MAX_KP = 128;                // latent columns padded to 32*NT, NT <= 4
 
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
@@ -42,6 +42,7 @@ struct FactorView {
 hipError_t launch_pack_factor(const FactorView& f, int x_dtype, int NT, int64_t Kpad, void* packed, hipStream_t s);
 struct GemmPlan {
   int nw = 8;               // waves per workgroup
+  int mt = 1;               // 32-row tiles per wave
   bool bdb = true;          // packed factor double-buffered in LDS
   int panel_rows = 0;       // rows per panel (= rows of one workgroup tile)
   int panels = 0;           // row panels

@@ -29,3 +29,36 @@ for name, ph in (("X*V", eng.phase_u), ("X^T*U", eng.phase_q)):
     if name == "X*V":
         eng.phase_v() if False else None
 eng.lib.prmf_debug_set_stamps(None)
+
+# --- are the slow workgroups the same ones every launch? (systematic => a weighted static split would fix it)
+import numpy as np
+durs = []
+eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()))
+for rep in range(4):
+    st.zero_(); torch.cuda.synchronize()
+    eng.phase_u(); torch.cuda.synchronize()
+    a = st.cpu().numpy().reshape(-1, 2)[:512]
+    durs.append((a[:, 1] - a[:, 0]) / 100.0)
+    eng.phase_q(); eng.phase_v(); eng.phase_post(); torch.cuda.synchronize()
+eng.lib.prmf_debug_set_stamps(None)
+durs = np.array(durs)
+print("X*V duration per WG: mean %.1f std %.1f us" % (durs.mean(), durs.std()))
+print("corr(launch0, launch1) = %.3f, corr(launch0, launch3) = %.3f" % (np.corrcoef(durs[0], durs[1])[0, 1], np.corrcoef(durs[0], durs[3])[0, 1]))
+m = durs.mean(axis=0)
+print("per-XCD mean duration (block id %% 8):", np.round([m[x::8].mean() for x in range(8)], 1))
+print("by position in XCD (block id // 8) deciles:", np.round([m[np.arange(512) // 8 // 8 == d].mean() for d in range(8)], 1))
+
+eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()))
+durs = []
+for rep in range(3):
+    eng.phase_u(); torch.cuda.synchronize()
+    st.zero_(); torch.cuda.synchronize()
+    eng.phase_q(); torch.cuda.synchronize()
+    a = st.cpu().numpy().reshape(-1, 2)[:512]
+    durs.append((a[:, 1] - a[:, 0]) / 100.0)
+    eng.phase_v(); eng.phase_post(); torch.cuda.synchronize()
+eng.lib.prmf_debug_set_stamps(None)
+durs = np.array(durs); m = durs.mean(axis=0)
+print("X^T*U duration per WG: mean %.1f std %.1f us; corr %.3f" % (durs.mean(), durs.std(), np.corrcoef(durs[0], durs[2])[0, 1]))
+print("per-XCD mean (block id %% 8):", np.round([m[x::8].mean() for x in range(8)], 1))
+print("per-XCD, first/second WG per CU:", [(round(m[x::8][:32].mean(), 1), round(m[x::8][32:].mean(), 1)) for x in range(8)])
