@@ -303,6 +303,46 @@ def gen_solver_api(ref):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def gen_more_cli(ref):
+    """G10: --manifolds-init (all 6 given in permuted order -> NNLS-based U/V initialisation, :1040-1059); G11: fewer pathways
+    than latent factors (3 manifolds, k = 6: only 3 latents get a final pathway, prmf_runner.py
+    Appendix-B4 behaviour); G12: weighted edges read from graphml."""
+    import networkx as nx
+    import pandas as pd
+    tmp = tempfile.mkdtemp(prefix="prmf_gold_")
+    try:
+        d = os.path.join(tmp, "g10")
+        c = synth.cli_case(d, variant=1)
+        runs = {
+            # all k given, permuted: the < k branch draws with random.sample from a set() of file names, whose
+            # order depends on PYTHONHASHSEED, so only the == k branch is reproducible across processes
+            "g10_init": ["--manifolds"] + c["manifolds"] + ["--manifolds-init"] + [c["manifolds"][i] for i in (0, 1, 3, 2, 5, 4)],
+            "g11_fewer_pathways": ["--manifolds"] + c["manifolds"][:3],
+        }
+        # weighted copies of the graphs (weights in (0,1], 3 decimals)
+        wdir = os.path.join(d, "weighted")
+        os.makedirs(wdir)
+        wfps = synth.weighted_copies(c["manifolds"], wdir)
+        runs["g12_weighted"] = ["--manifolds"] + wfps
+        for tag, margs in runs.items():
+            out = os.path.join(d, "out_" + tag)
+            os.makedirs(out)
+            argv = ["--data", c["data"]] + margs + ["--node-attribute", "name", "--nodelist", c["nodelist"],
+                                                    "--outdir", out, "--delimiter", "\t", "--seed", "1", "--no-normalize"]
+            stdout = run_ref_cli(ref, argv, d)
+            vals, mapping = read_obj_txt(os.path.join(out, "obj.txt"))
+            U = pd.read_csv(os.path.join(out, "U.csv")).to_numpy()
+            V = pd.read_csv(os.path.join(out, "V.csv"), index_col=0).to_numpy()
+            extra = {}
+            ip = os.path.join(out, "init_pathways.txt")
+            if os.path.exists(ip):
+                extra["init_pathways"] = np.array(json.dumps([os.path.basename(x) for x in open(ip).read().split("\n")]))
+            save(tag + ".npz", x_sha=np.array(synth.sha16(c["X"])), trace=parse_trace(stdout),
+                 obj_txt=np.array(json.dumps(vals)), mapping=np.array(json.dumps(mapping)), U=U, V=V, **extra)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     if not ref_harness.reference_available():
         sys.exit("reference not mounted; golden vectors can only be generated in the build container")
@@ -312,6 +352,7 @@ def main():
     gen_restrict(ref)
     gen_solver_api(ref)
     gen_cli(ref)
+    gen_more_cli(ref)
 
 
 if __name__ == "__main__":

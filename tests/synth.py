@@ -121,6 +121,21 @@ def cli_case(outdir, variant=1, m_samples=100, n_genes=1000, k_latent=6, shape_p
             "nodelist_ids": nodelist}
 
 
+def weighted_copies(manifold_fps, outdir):
+    """Copies of the graphml files with a deterministic 'weight' attribute in (0,1] on every edge."""
+    import networkx as nx
+    out = []
+    for gi, fp in enumerate(manifold_fps):
+        G = nx.read_graphml(fp)
+        rs = np.random.RandomState(100 + gi)
+        for a, b in G.edges():
+            G[a][b]["weight"] = float(np.round(0.2 + 0.8 * rs.rand(), 3))
+        ofp = os.path.join(outdir, os.path.basename(fp))
+        nx.write_graphml(G, ofp)
+        out.append(ofp)
+    return out
+
+
 # ---------------------------------------------------------------------------
 # benchmark-shaped inputs (SURVEY.md 8d), generated in row chunks
 # ---------------------------------------------------------------------------

@@ -155,6 +155,48 @@ def test_cli_outputs_vs_reference(golden_dir, tmp_path, variant, tag):
         assert np.allclose(V.to_numpy()[1000:], np.finfo(np.float32).eps)
 
 
+@pytest.mark.parametrize("tag", ["g10_init", "g11_fewer_pathways", "g12_weighted"])
+def test_cli_more_variants_vs_reference(golden_dir, tmp_path, tag):
+    """--manifolds-init (NNLS-based U/V start, init_pathways.txt), fewer pathways than latent factors,
+    weighted graphml edges: obj.txt, the latent->pathway mapping, U.csv and V.csv against reference runs."""
+    import pandas as pd
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    c = synth.cli_case(str(tmp_path), variant=1)
+    man = c["manifolds"]
+    extra = []
+    if tag == "g10_init":
+        extra = ["--manifolds-init"] + [man[i] for i in (0, 1, 3, 2, 5, 4)]
+    elif tag == "g11_fewer_pathways":
+        man = man[:3]
+    else:
+        wdir = str(tmp_path / "weighted")
+        os.makedirs(wdir)
+        man = synth.weighted_copies(man, wdir)
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    stdout = _cli(["--data", c["data"], "--manifolds"] + man + extra +
+                  ["--node-attribute", "name", "--nodelist", c["nodelist"], "--outdir", out, "--delimiter", "\t",
+                   "--seed", "1", "--no-normalize"], str(tmp_path))
+    trace = np.array([float(l.split()[1]) for l in stdout.splitlines()
+                      if len(l.split()) == 2 and l.split()[0].isdigit()])
+    ref_trace = g["trace"]
+    assert len(trace) == len(ref_trace)
+    assert np.allclose(trace, ref_trace, rtol=2e-4)
+    vals, mapping = _read_obj(os.path.join(out, "obj.txt"))
+    ref = json.loads(str(g["obj_txt"]))
+    assert list(vals) == list(ref)
+    for key in ref:
+        assert abs(vals[key] - ref[key]) <= 2e-4 * max(abs(ref[key]), 1e-3), key
+    assert mapping == json.loads(str(g["mapping"]))
+    U = pd.read_csv(os.path.join(out, "U.csv")).to_numpy()
+    V = pd.read_csv(os.path.join(out, "V.csv"), index_col=0).to_numpy()
+    assert rel(U, g["U"]) < 2e-3 and rel(V, g["V"]) < 2e-3
+    if tag == "g10_init":
+        got = [os.path.basename(x) for x in open(os.path.join(out, "init_pathways.txt")).read().split("\n")]
+        assert got == json.loads(str(g["init_pathways"]))
+        assert "Using the following manifolds for initialization:" in stdout
+
+
 def test_cli_config1_plumbing(golden_dir, tmp_path):
     """BASELINE.json configs[0]: header-inferred nodelist, -k 4, 2 manifolds, --cross-validation 0.2
     (quantile-normalised)."""

@@ -121,6 +121,34 @@ def test_outer_solver_trace_matches_reference(golden_dir, tmp_path, name, tradeo
     assert rel(U, g["U"]) < 1e-9 and rel(V, g["V"]) < 1e-9
 
 
+@pytest.mark.parametrize("tag", ["g11_fewer_pathways", "g12_weighted"])
+def test_outer_solver_cli_variants(golden_dir, tmp_path, tag):
+    """Reference CLI runs (--seed 1 --no-normalize) with fewer pathways than latent factors (3 graphs,
+    k = 6: prmf_runner.py:196-258 leaves the spare latents on a repeated pathway) and with weighted
+    edges (adjacency weights enter W, D and the normalised Laplacian)."""
+    g = load(golden_dir, tag + ".npz")
+    c = synth.cli_case(str(tmp_path), variant=1)
+    assert synth.sha16(c["X"]) == str(g["x_sha"])
+    if tag == "g12_weighted":
+        wdir = str(tmp_path / "weighted")
+        os.makedirs(wdir)
+        c["manifolds"] = synth.weighted_copies(c["manifolds"], wdir)
+    else:
+        c["manifolds"] = c["manifolds"][:3]
+    pws = _graphs_to_pathways(c)
+    if tag == "g12_weighted":
+        assert any(np.any(np.abs(p.W.data - 1.0) > 1e-6) for p in pws)
+    trace = []
+    np.random.seed(1)
+    norm_x = np.linalg.norm(c["X"])
+    U, V, od = orc.nmf_pathway(c["X"], pws, gamma=1.0, k_latent=6, trace=trace)
+    assert np.allclose([t["obj"] for t in trace], g["trace"], rtol=1e-9)
+    l2p = od["latent_to_pathway_data"]
+    names = [os.path.basename(c["manifolds"][int(l2p[k][0][0])]) for k in sorted(l2p)]
+    assert [[k, nm] for k, nm in enumerate(names)] == json.loads(str(g["mapping"]))
+    assert rel(U, g["U"]) < 1e-6 and rel(V, g["V"]) < 1e-6          # CSV round trip of the reference
+
+
 def test_reference_stale_golden_gamma_delta(golden_dir):
     """The only golden file the reference ships
     (test_inferred_nodelist_1_expected_obj.txt) is stale except for its
