@@ -200,6 +200,20 @@ int prmf_step_dist(prmf_ctx* ctx, float* dU, float* dV, int n_steps,
  */
 int prmf_score_candidates(prmf_ctx* ctx, const float* dV, double* scores_out, void* stream);
 
+/*
+ * Held-out reconstruction error, replaces measure_cv_performance
+ * (prmf/__init__.py:768-798; called at script/prmf_runner.py:1084-1089): for every
+ * row x of this context's X (the held-out samples, prmf_set_x)
+ *     err_out[s] = min_{u >= 0} || x_s - u V^T ||_2 / || x_s ||_2
+ * (scipy.optimize.nnls per sample in the reference; here X*V and V^T V accumulated in
+ * float64 and a batched active-set solve on the normal equations, one wavefront per sample).  dV: n x k float32
+ * device buffer; err_out: host buffer, m_local doubles; an all-zero sample gives
+ * NaN (0/0) as in the reference.  No pathway library is needed.  Synchronises
+ * `stream`.  PRMF_ERR_NUMERIC if a sample did not converge in 3k iterations (the
+ * reference raises RuntimeError).
+ */
+int prmf_cv_error(prmf_ctx* ctx, const float* dV, double* err_out, void* stream);
+
 /* Introspection used by bench.py for the roofline block: launch geometry and
  * per-launch algorithmic bytes of the dominant kernel (the X / X^T sweep). */
 typedef struct prmf_sweep_info {

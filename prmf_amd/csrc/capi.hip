@@ -812,6 +812,41 @@ int prmf_score_candidates(prmf_ctx* c, const float* dV, double* scores_out, void
   return PRMF_OK;
 }
 
+int prmf_cv_error(prmf_ctx* c, const float* dV, double* err_out, void* stream) {
+  if (!c || !dV || !err_out) return PRMF_ERR_ARG;
+  if (!c->have_x) return fail(c, PRMF_ERR_STATE, "prmf_set_x has not been called");
+  if (c->m <= 0) return PRMF_OK;
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  // one scratch block: H [m][k] | row norms^2 [m] | errors [m] | G [k][k] | Gram partials | failure counter
+  const size_t kk2 = (size_t)c->k * c->k;
+  const size_t nb = (size_t)gram_f64_blocks(c->n);
+  double* buf = nullptr;
+  struct Guard {
+    double*& p;
+    ~Guard() { dev_free(p); }
+  } guard{buf};
+  if ((rc = dev_alloc(c, &buf, (size_t)c->m * c->k + 2 * (size_t)c->m + kk2 + nb * kk2 + 1, false))) return rc;
+  double* H = buf;
+  double* xx = H + (size_t)c->m * c->k;
+  double* err_dev = xx + c->m;
+  double* G = err_dev + c->m;
+  double* partial = G + kk2;
+  int* fail_dev = reinterpret_cast<int*>(partial + nb * kk2);
+  HIP_TRY(c, hipMemsetAsync(fail_dev, 0, sizeof(double), s));
+  HIP_TRY(c, launch_gram_f64(dV, c->n, c->k, partial, G, s));
+  HIP_TRY(c, launch_xv_f64(c->x_dtype, c->X, c->ldx, c->m, c->n, dV, c->k, H, s));
+  HIP_TRY(c, launch_row_normsq(c->x_dtype, c->X, c->ldx, c->m, c->n, xx, s));
+  HIP_TRY(c, launch_nnls(G, H, xx, c->m, c->k, c->n, err_dev, fail_dev, s));
+  int nfail = 0;
+  HIP_TRY(c, hipMemcpyAsync(err_out, err_dev, (size_t)c->m * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(&nfail, fail_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (nfail > 0) return fail(c, PRMF_ERR_NUMERIC, "nnls: %d of %lld samples did not converge in %d iterations", nfail, (long long)c->m, 3 * c->k);
+  return PRMF_OK;
+}
+
 /* debug (not in the public header): device buffer of 2*grid uint64 start/end stamps of the next sweep launches */
 extern "C" int prmf_debug_set_stamps(void* dev_buf) { prmf::g_sweep_stamps = (unsigned long long*)dev_buf; return 0; }
 

@@ -147,4 +147,18 @@ hipError_t launch_post(const float* gram_partial, int nparts, int k, double* Gv,
 hipError_t launch_score_candidates(const PathwayLibDev& lib, const float* V, int64_t n, int k,
                                    double* colnorm_scratch, double* scores, hipStream_t s);
 
+// ---------------------------------------------------------------------------
+// nnls.hip
+// ---------------------------------------------------------------------------
+// out[row] = sum_j X[row][j]^2 (float64) over the stored copy of X
+hipError_t launch_row_normsq(int x_dtype, const void* X, int64_t ld, int64_t m, int64_t n, double* out, hipStream_t s);
+// H = X V and G = V^T V accumulated in float64 (partial: gram_f64_blocks(n) * k * k doubles)
+hipError_t launch_xv_f64(int x_dtype, const void* X, int64_t ld, int64_t m, int64_t n, const float* V, int k, double* H,
+                         hipStream_t s);
+int gram_f64_blocks(int64_t n);
+hipError_t launch_gram_f64(const float* V, int64_t n, int k, double* partial, double* G, hipStream_t s);
+// err[s] = min_{c>=0} ||x_s - V c|| / ||x_s|| from G = V^T V, H = X V, xx = row norms^2   (prmf/__init__.py:768-798)
+hipError_t launch_nnls(const double* G, const double* H, const double* xx, int64_t m, int k, int64_t n, double* err,
+                       int* n_not_converged, hipStream_t s);
+
 }  // namespace prmf

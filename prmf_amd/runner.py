@@ -113,17 +113,6 @@ def embed_arr(all_col_names, some_col_names, arr):
     return rv
 
 
-def measure_cv_performance(V, X_test):
-    """prmf/__init__.py:768-798: per held-out sample, nnls reconstruction error / ||x||."""
-    import scipy.optimize
-    V = np.asarray(V)
-    err = np.zeros(X_test.shape[0])
-    for s in range(X_test.shape[0]):
-        _u, e = scipy.optimize.nnls(V, X_test[s, :])
-        err[s] = e / np.linalg.norm(X_test[s, :])
-    return err
-
-
 def pathway_to_vec(X, G, nodelist, rel_weight=5):
     """prmf_runner.py:272-306."""
     n = len(nodelist)
@@ -300,7 +289,8 @@ Solve an optimization problem of the form
     V.to_csv(V_fp, sep=",", index=True, quoting=csv.QUOTE_NONNUMERIC)
 
     if args.cross_validation is not None:               # :1073-1079
-        errs = measure_cv_performance(V, X_test)
+        from .solver import measure_cv_performance     # GPU: one sweep + batched NNLS (prmf/__init__.py:768-798)
+        errs = measure_cv_performance(V.to_numpy(), X_test, x_dtype=args.x_dtype)
         np.savetxt(os.path.join(args.outdir, 'test_error.csv'), errs, delimiter=",")
         obj_data['average_normalized_test_error'] = np.mean(errs)
 

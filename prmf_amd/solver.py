@@ -254,6 +254,18 @@ class PrmfEngine(object):
         self._check(self.lib.prmf_score_candidates(self.ctx, C.c_void_p(V.data_ptr()), _ptr(out), self._stream()))
         return out
 
+    def cv_error(self, V):
+        """Per-row NNLS reconstruction error of this engine's X (the held-out samples) against V
+        (measure_cv_performance, prmf/__init__.py:768-798)."""
+        if tuple(V.shape) != (self.n, self.k) or V.dtype != self.torch.float32 or not V.is_contiguous():
+            raise ValueError("V must be a contiguous float32 tensor of shape {}".format((self.n, self.k)))
+        out = np.zeros(self.m)
+        rc = self.lib.prmf_cv_error(self.ctx, C.c_void_p(V.data_ptr()), _ptr(out), self._stream())
+        if rc == _capi.PRMF_ERR_NUMERIC:
+            raise RuntimeError(self.lib.prmf_last_error(self.ctx).decode())
+        self._check(rc)
+        return out
+
     def sweep_info(self):
         info = _capi.SweepInfo()
         self._check(self.lib.prmf_get_sweep_info(self.ctx, C.byref(info)))
@@ -452,3 +464,24 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
         return U_out, V_out, obj_data
     finally:
         engine.close()
+
+
+def measure_cv_performance(gene_by_latent_train, data_test, x_dtype="f32", device=0):
+    """Drop-in for prmf.measure_cv_performance (prmf/__init__.py:768-798): normalised NNLS
+    reconstruction error of every held-out sample, computed on the GPU (float64 X_test V and
+    V^T V, batched active-set solve; `prmf_cv_error`)."""
+    import torch
+    V = np.asarray(gene_by_latent_train)
+    Xt = np.asarray(data_test)
+    m, n = Xt.shape
+    if V.shape[0] != n:
+        raise ValueError("gene_by_latent_train has {} rows, data_test has {} columns".format(V.shape[0], n))
+    if m == 0:
+        return np.zeros(0)
+    eng = PrmfEngine(m, n, V.shape[1], x_dtype=x_dtype, device=device)
+    try:
+        eng.set_x(Xt)
+        return eng.cv_error(eng.device_tensor(V, torch.float32))
+    finally:
+        eng.close()
+

@@ -215,3 +215,38 @@ def test_cli_config1_plumbing(golden_dir, tmp_path):
     assert mapping == json.loads(str(g["mapping"]))
     err = np.loadtxt(os.path.join(out, "test_error.csv"), delimiter=",")
     assert err.shape == (20,) and np.allclose(err, g["test_error"], rtol=5e-3)
+
+
+@pytest.mark.parametrize("m,n,k,x_dtype", [(37, 500, 8, "f32"), (64, 1000, 13, "f32"), (50, 2000, 64, "f32"),
+                                            (20, 900, 128, "f32"), (40, 700, 16, "bf16")])
+def test_cv_error_vs_scipy_nnls(m, n, k, x_dtype):
+    """prmf_cv_error (float64 X V and V^T V + batched active-set NNLS on the normal equations) against
+    scipy.optimize.nnls per sample (the oracle's measure_cv_performance = prmf/__init__.py:768-798).
+    V has strongly correlated columns and the samples use few of them, so the active set both grows
+    and shrinks.  Tolerance 1e-7 relative: the residual comes from ||x||^2 - 2c.h + c^T G c in float64,
+    cancellation factor ||x||^2 / err^2 ~ 1e3 here."""
+    from oracle import prmf_oracle as orc
+    from prmf_amd.solver import measure_cv_performance
+    rs = np.random.RandomState(m + k)
+    base = rs.rand(n, max(2, k // 3))
+    V = np.abs(base[:, rs.randint(0, base.shape[1], k)] + 0.15 * rs.rand(n, k)).astype(np.float32).astype(np.float64)
+    C = rs.rand(m, k) * (rs.rand(m, k) < 0.3)
+    Xt = C.dot(V.T) + 0.2 * rs.rand(m, n)
+    Xt[3] = 0.0                                           # all-zero sample: 0/0 -> nan in the reference
+    Xt[5] = 2.0 * V[:, 1]                                 # exactly representable sample: error ~ 0
+    if x_dtype == "bf16":
+        Xt = synth.round_to_bf16(Xt)
+    else:
+        Xt = Xt.astype(np.float32).astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want = orc.measure_cv_performance(V, Xt)
+    got = measure_cv_performance(V, Xt, x_dtype=x_dtype)
+    assert got.shape == want.shape
+    assert np.isnan(got[3]) and np.isnan(want[3])
+    mask = np.ones(m, dtype=bool)
+    mask[[3, 5]] = False
+    assert np.allclose(got[mask], want[mask], rtol=1e-7, atol=0)
+    if x_dtype == "bf16":                                  # 2 V[:,1] rounded to bf16 is no longer in the cone
+        assert abs(got[5] - want[5]) < 1e-6 * want[5]
+    else:                                                  # near-zero residual: sqrt of the float64 cancellation noise
+        assert got[5] < 1e-6 and want[5] < 1e-6

@@ -103,10 +103,6 @@ def test_cli_front_end_helpers(tmp_path):
         assert runner.parse_nodelist(fh) == c["nodelist_ids"]
     arr = np.arange(6.0).reshape(2, 3)
     assert np.array_equal(runner.embed_arr(list("abcde"), list("eca"), arr), orc.embed_arr(list("abcde"), list("eca"), arr))
-    rs = np.random.RandomState(0)
-    V = rs.rand(40, 3)
-    Xt = rs.rand(4, 40)
-    assert np.allclose(runner.measure_cv_performance(V, Xt), orc.measure_cv_performance(V, Xt))
 
 
 def _run_cli(args, cwd):
