@@ -380,8 +380,10 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus) {
     // X*V (5.1 MB factor) is fastest unsliced (0.35-0.375 vs 0.40-0.42: the extra segments cost more).
     const double factor_mb = (double)Kpad * 32.0 * NT * 4.0 / (1024.0 * 1024.0);
     if (factor_mb > 6.0) {
+      double slice_mb = 3.5;
+      if (const char* e = getenv("PRMF_SWEEP_SLICE_MB")) slice_mb = atof(e) > 0 ? atof(e) : slice_mb;
       p.nx = 2;
-      while (p.nx < 8 && factor_mb / p.nx > 3.5) p.nx *= 2;
+      while (p.nx < 8 && factor_mb / p.nx > slice_mb) p.nx *= 2;
       while (p.nx > 1 && units_per_wg < 0.5 * ((double)p.ngroups / p.nx)) p.nx /= 2;
     }
     if (const char* e = getenv("PRMF_SWEEP_XCD")) {
