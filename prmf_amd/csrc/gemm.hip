@@ -176,6 +176,15 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], const u32x4
 #define PRMF_A_NT 1
 #endif
 constexpr bool NT_LOADS = PRMF_A_NT != 0;   // A is read exactly once: non-temporal loads keep it from displacing the factor in L2
+#ifndef PRMF_SLAB_NT
+#define PRMF_SLAB_NT 1
+#endif
+constexpr bool SLAB_NT = PRMF_SLAB_NT != 0; // slabs leave as full-line streaming writes (see the sweep's epilogue)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef PRMF_LOADS_FIRST
+#define PRMF_LOADS_FIRST 0
+#endif
+constexpr bool LOADS_FIRST = PRMF_LOADS_FIRST != 0;
 
 template <int MT>
 __device__ __forceinline__ void load_a_chunk(u32x4 (&dst)[MT][4], const unsigned (&voff)[MT][4], const uint4* base) {
@@ -305,9 +314,19 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int cn = min(c + u + 1, last);
+      if constexpr (LOADS_FIRST) {
+        // the next chunk's loads are in flight while this chunk is computed from LDS
+        load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
+        load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       sweep_compute<BF16, MT, NT>(acc, myA, sB[BDB ? u : 0], lane);
-      load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
-      load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
+      if constexpr (!LOADS_FIRST) {
+        load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
+        load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
+      } else {
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if constexpr (!BDB) __syncthreads();          // everyone has finished reading B(c)
       store_b_chunk<BPT, NTHR, BCH>(sB[BDB ? (u ^ 1) : 0], bs, tid);
 #pragma unroll
@@ -318,31 +337,38 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
     }
   }
 
-  // epilogue: the accumulators go out in FRAGMENT order -- slab[seg][tile32][t][lane][16 floats],
-  // the 16 registers of a lane contiguous (4 x 16-B stores per tile, fully coalesced); the
-  // consumers read them back the same way.  Element (row, col) of a slab:
-  //   tile = row/32, rr = row%32, lane = col%32 + 32*((rr>>2)&1), i = (rr&3) + 4*(rr>>3), t = col/32
-  float4* out = reinterpret_cast<float4*>(slabs + (int64_t)seg * slab_stride);
+  // epilogue: the accumulators go out in FRAGMENT order -- slab[seg][tile32][t][q4][lane][4 floats]: every
+  // store instruction writes 1 KiB contiguous (whole 128-B lines), non-temporal (the slab is read next by
+  // another kernel on other XCDs: it has to reach memory anyway, and as full-line streaming writes it does
+  // so during the sweep instead of as an L2 write-back at the end: -16 us per launch at 50000x20000,
+  // tools/stream_ladder2.hip).  Element (row, col) of a slab:
+  //   tile = row/32, rr = row%32, lane = col%32 + 32*((rr>>2)&1), q4 = rr>>3, j = rr&3, t = col/32
+  f32x4* out = reinterpret_cast<f32x4*>(slabs + (int64_t)seg * slab_stride);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int64_t tile = row0 / 32 + mt;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4)
-        out[((tile * NT + t) * 64 + lane) * 4 + q4] =
-            make_float4(acc[mt][t][4 * q4], acc[mt][t][4 * q4 + 1], acc[mt][t][4 * q4 + 2], acc[mt][t][4 * q4 + 3]);
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 v = {acc[mt][t][4 * q4], acc[mt][t][4 * q4 + 1], acc[mt][t][4 * q4 + 2], acc[mt][t][4 * q4 + 3]};
+        f32x4* dst = out + ((tile * NT + t) * 4 + q4) * 64 + lane;
+        if constexpr (SLAB_NT) __builtin_nontemporal_store(v, dst);
+        else *dst = v;
+      }
   }
   }   // segments
   if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x + 1] = wall_clock64();
 }
 
 struct SweepVariant { int nw; bool bdb; int wgs_per_cu; int mt; };
-// 8 waves per workgroup; B double-buffered (one barrier per chunk) while two workgroups still fit
-// the 160 KiB LDS (k <= 64: 32 KiB A tiles + 2 x 16 KiB B), single-buffered beyond (k = 128:
-// 32 + 32 KiB, measured 0.368 vs 0.396 ms against double-buffered at 1 workgroup per CU).
+// k <= 64 (NT <= 2): 4 waves x 64 rows per workgroup (two 32-row MFMA tiles per wave share every B fragment
+// read: half the LDS traffic per byte of X of the 8 x 32 shape; measured at 50000x20000 k=64 0.336/0.343 ms
+// against 0.347/0.352, at 5000x10000 k=16 f32 +5%), B double-buffered, 2 workgroups per CU.
+// k > 64: 8 waves x 32 rows (the 64-row tile would need > 256 registers), B double-buffered only while two
+// workgroups still fit the 160 KiB LDS (k = 128: 32 + 32 KiB single-buffered, 0.368 vs 0.396 ms).
 static SweepVariant sweep_variant(int NT) {
-  SweepVariant r{8, NT <= 2, 2, 1};
+  SweepVariant r{NT <= 2 ? 4 : 8, NT <= 2, 2, NT <= 2 ? 2 : 1};
   if (const char* e = getenv("PRMF_SWEEP_MT")) r.mt = (atoi(e) == 2 && NT <= 2) ? 2 : 1;
   if (const char* e = getenv("PRMF_SWEEP_NW")) r.nw = atoi(e) == 4 ? 4 : 8;
   if (const char* e = getenv("PRMF_SWEEP_BDB")) r.bdb = atoi(e) != 0;

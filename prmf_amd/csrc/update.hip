@@ -20,8 +20,7 @@ __device__ __forceinline__ int64_t slab_index(int64_t row, int col, int NT) {
   const int64_t tile = row >> 5;
   const int rr = (int)(row & 31);
   const int lane = (col & 31) + 32 * ((rr >> 2) & 1);
-  const int i = (rr & 3) + 4 * (rr >> 3);
-  return (((tile * NT + (col >> 5)) * 64 + lane) << 4) + i;
+  return ((((tile * NT + (col >> 5)) * 4 + (rr >> 3)) * 64 + lane) << 2) + (rr & 3);
 }
 
 // deterministic block-wide sum of one double per thread (256 threads)
@@ -340,7 +339,7 @@ __device__ __forceinline__ void stage_gram(const double* __restrict__ G, int k, 
   }
 }
 
-// sum of a tile's slab segments (fragment order: 4 x float4 per t per lane), in slab-index order.
+// sum of a tile's slab segments (fragment order: [t][q4][lane] float4, 1 KiB per load instruction), in slab-index order.
 // The loads of two segments are issued together (a data-dependent one-segment-per-iteration
 // loop costs a full memory round trip per segment: up to 8 per tile); missing slots of the last
 // batch re-read the first slab and are masked out of the sum.
@@ -351,7 +350,7 @@ __device__ __forceinline__ void load_slab_tile(const float* __restrict__ slabs, 
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) p[t][i] = 0.f;
-  const int64_t base = (tile * NT * 64 + lane) * 4;          // float4 index of (tile, t = 0, lane, q4 = 0)
+  const int64_t base = tile * NT * 256 + lane;               // float4 index of (tile, t = 0, q4 = 0, lane)
   while (mask) {
     constexpr int NB = 2;
     int sg[NB];
@@ -370,7 +369,7 @@ __device__ __forceinline__ void load_slab_tile(const float* __restrict__ slabs, 
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) v[j][t][q4] = sl[t * 256 + q4];
+        for (int q4 = 0; q4 < 4; ++q4) v[j][t][q4] = sl[(t * 4 + q4) * 64];
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j)
