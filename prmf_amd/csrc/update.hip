@@ -343,7 +343,7 @@ __device__ __forceinline__ void stage_gram(const double* __restrict__ G, int k, 
 // The loads of two segments are issued together (a data-dependent one-segment-per-iteration
 // loop costs a full memory round trip per segment: up to 8 per tile); missing slots of the last
 // batch re-read the first slab and are masked out of the sum.
-template <int NT>
+template <int NT, int NB = 2>
 __device__ __forceinline__ void load_slab_tile(const float* __restrict__ slabs, int64_t slab_stride, uint32_t mask, int64_t tile,
                                                int lane, float (&p)[NT][16]) {
 #pragma unroll
@@ -352,7 +352,6 @@ __device__ __forceinline__ void load_slab_tile(const float* __restrict__ slabs, 
     for (int i = 0; i < 16; ++i) p[t][i] = 0.f;
   const int64_t base = tile * NT * 256 + lane;               // float4 index of (tile, t = 0, q4 = 0, lane)
   while (mask) {
-    constexpr int NB = 2;
     int sg[NB];
     float on[NB];
     const int first = __ffs(mask) - 1;
@@ -553,7 +552,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
     if (row0 < n) {
       float ua[16 * NT], vv[NT][16], q[NT][16];
       int ps[NT][16];
-      load_slab_tile<NT>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);
+      load_slab_tile<NT>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);   // 4 segments per round trip: no faster
       load_tile_a_layout<NT>(V, n, k, row0, lane, ua);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
