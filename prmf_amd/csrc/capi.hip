@@ -33,11 +33,9 @@ struct prmf_ctx {
   char err[512] = "";
 
   // X (m x n) and X^T (n x m), zero padded, resident
-  void* X = nullptr;                  // = X_base + off_x (see placement notes in prmf_set_x)
+  void* X = nullptr;
   void* XT = nullptr;
-  char* X_base = nullptr;
-  char* XT_base = nullptr;
-  size_t x_bytes = 0, xt_bytes = 0, slack = 0, off_x = 0, off_xt = 0;
+  size_t x_bytes = 0, xt_bytes = 0;
   int64_t ldx = 0, ldxt = 0;          // elements
   int64_t Kpad_x = 0, Kpad_xt = 0;    // reduction lengths (n resp. m, padded to 64)
   double norm_x_sq = 0.0;
@@ -323,8 +321,8 @@ int prmf_destroy(prmf_ctx* c) {
   if (!c) return PRMF_OK;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  dev_free(c->X_base);
-  dev_free(c->XT_base);
+  dev_free(c->X);
+  dev_free(c->XT);
   dev_free(c->Vp);
   dev_free(c->Up);
   dev_free(c->slabs);
@@ -380,15 +378,12 @@ int prmf_set_x(prmf_ctx* c, const void* dX, int64_t ld, double norm_x_sq, void* 
   const int64_t ld_pad = getenv("PRMF_LD_PAD") ? atoll(getenv("PRMF_LD_PAD")) : 0;
   c->ldx = c->Kpad_x + ld_pad;
   c->ldxt = c->Kpad_xt + ld_pad;
-  if (!c->X_base) {
+  if (!c->X) {
     c->x_bytes = (size_t)(rows_x * c->ldx * eb);
     c->xt_bytes = (size_t)(rows_xt * c->ldxt * eb);
-    c->slack = getenv("PRMF_PLACEMENT_SLACK_MB") ? (size_t)atoll(getenv("PRMF_PLACEMENT_SLACK_MB")) << 20 : 0;
-    if ((rc = dev_alloc(c, &c->X_base, c->x_bytes + c->slack, false))) return rc;
-    if ((rc = dev_alloc(c, &c->XT_base, c->xt_bytes + c->slack, false))) return rc;
+    if ((rc = dev_alloc(c, (char**)&c->X, c->x_bytes, false))) return rc;
+    if ((rc = dev_alloc(c, (char**)&c->XT, c->xt_bytes, false))) return rc;
   }
-  c->X = c->X_base + c->off_x;
-  c->XT = c->XT_base + c->off_xt;
   HIP_TRY(c, hipMemsetAsync(c->X, 0, c->x_bytes, s));       // the padding (rows >= m, columns >= n) must read as zero
   HIP_TRY(c, hipMemsetAsync(c->XT, 0, c->xt_bytes, s));
   HIP_TRY(c, launch_copy_pad(c->x_dtype, dX, ld, c->m, c->n, c->X, c->ldx, s));
@@ -860,16 +855,6 @@ int prmf_cv_error(prmf_ctx* c, const float* dV, double* err_out, void* stream) {
 
 /* debug (not in the public header): device buffer of 2*grid uint64 start/end stamps of the next sweep launches */
 extern "C" int prmf_debug_set_stamps(void* dev_buf) { prmf::g_sweep_stamps = (unsigned long long*)dev_buf; return 0; }
-
-/* debug (not in the public header): byte offsets of the X / X^T copies inside their allocations for the next
- * prmf_set_x (needs PRMF_PLACEMENT_SLACK_MB at the first prmf_set_x) */
-extern "C" int prmf_debug_set_offsets(prmf_ctx* c, size_t off_x, size_t off_xt) {
-  if (!c || off_x % 256 || off_xt % 256) return PRMF_ERR_ARG;
-  if (c->X_base && (off_x > c->slack || off_xt > c->slack)) return PRMF_ERR_ARG;
-  c->off_x = off_x;
-  c->off_xt = off_xt;
-  return PRMF_OK;
-}
 
 /* debug (not in the public header): swap one device buffer between two contexts of identical geometry
  * (tools/placement_probe.py): 0 X, 1 XT, 2 slabs, 3 Vp, 4 Up */
