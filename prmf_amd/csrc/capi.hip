@@ -856,6 +856,14 @@ int prmf_cv_error(prmf_ctx* c, const float* dV, double* err_out, void* stream) {
 /* debug (not in the public header): device buffer of 2*grid uint64 start/end stamps of the next sweep launches */
 extern "C" int prmf_debug_set_stamps(void* dev_buf) { prmf::g_sweep_stamps = (unsigned long long*)dev_buf; return 0; }
 
+/* debug (not in the public header): advance the iteration cursor without running phase_post, so that partial
+ * iterations can be timed (tools/sweep_context.py) */
+extern "C" int prmf_debug_bump_cursor(prmf_ctx* c) {
+  if (!c || c->cursor + 1 >= MAX_RECORDS) return PRMF_ERR_ARG;
+  c->cursor++;
+  return PRMF_OK;
+}
+
 /* debug (not in the public header): swap one device buffer between two contexts of identical geometry
  * (tools/placement_probe.py): 0 X, 1 XT, 2 slabs, 3 Vp, 4 Up */
 extern "C" int prmf_debug_swap(prmf_ctx* a, prmf_ctx* b, int which) {
