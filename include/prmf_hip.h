@@ -61,9 +61,11 @@ const char* prmf_last_error(const prmf_ctx* ctx);
 
 /*
  * One context per GPU / rank.  X is row-sharded over `nranks` ranks: this rank
- * holds `m_local` of the samples; n (genes) and k (latent) are global.  The k
- * latent columns (and their active pathway Laplacians) are sharded for the
- * V-update: rank r owns columns [r*kc, min(k,(r+1)*kc)), kc = ceil(k/nranks).
+ * holds `m_local` of the samples; n (genes) and k (latent) are global.  With
+ * nranks > 1 every rank updates all of V from the all-reduced X^T U (default), or,
+ * with PRMF_FLAG_COLUMN_SHARDED in `flags`, the k latent columns (and their active
+ * pathway Laplacians) are sharded for the V-update: rank r owns columns
+ * [r*kc, min(k,(r+1)*kc)), kc = ceil(k/nranks) -- see prmf_comm_sizes.
  * Replaces: the shapes implied by X/U/V at prmf_runner.py:417-418.
  */
 int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k,
@@ -128,12 +130,21 @@ int prmf_step(prmf_ctx* ctx, float* dU, float* dV, int n_steps,
               double* obj_out, double* gamma_delta_out, void* stream);
 
 /* ------------------------------------------------------------------------
- * Multi-rank form of one iteration: four device phases with a collective
- * between them, driven by the host over torch.distributed (RCCL):
+ * Multi-rank form of one iteration: four device phases with collectives
+ * between them, driven by the host over torch.distributed (RCCL), or issued by
+ * the library itself (prmf_step_dist).  Replicated mode (default):
  *
  *   prmf_phase_u    P = X_g V ; U_g update ; partial U_g^T U_g      -> gram buffer
  *        all_reduce(gram, SUM)                       k*k doubles
- *   prmf_phase_q    Q_g = X_g^T U_g, laid out by owner column block -> q_send
+ *   prmf_phase_q    Q_g = X_g^T U_g (n x k)                         -> q_send
+ *        all_reduce(q_send, SUM, in place)           n*k floats
+ *   prmf_phase_v    V update (all columns) from the reduced Q, objective pieces
+ *   prmf_phase_post V^T V, objective record
+ *
+ * Column-sharded mode (PRMF_FLAG_COLUMN_SHARDED):
+ *
+ *   prmf_phase_u    as above;  all_reduce(gram, SUM)
+ *   prmf_phase_q    Q_g laid out by owner column block              -> q_send
  *        reduce_scatter(q_send -> q_recv, SUM)       n*kc floats per rank
  *   prmf_phase_v    graph terms + divide + clamps for the OWN columns,
  *                   own-column objective pieces                     -> v_send
@@ -150,9 +161,20 @@ typedef struct prmf_comm_sizes {
   int64_t q_recv_floats;    /* n * kc                                         */
   int64_t v_send_floats;    /* n * kc + 8 (objective partials in the tail)    */
   int64_t v_recv_floats;    /* nranks * v_send_floats                         */
-  int32_t kc;               /* latent columns owned per rank                  */
-  int32_t reserved;
+  int32_t kc;               /* latent columns updated per rank                */
+  int32_t mode;             /* PRMF_DIST_*: which exchanges the caller performs */
 } prmf_comm_sizes;
+
+/* Exchanges between the phases (host-driven form; prmf_step_dist issues the same ones itself):
+ *   PRMF_DIST_REPLICATED (default for nranks > 1): every rank updates all of V.
+ *       phase_u; all_reduce(gram, float64 sum); phase_q; all_reduce(q_send, float32 sum, in place;
+ *       q_recv aliases q_send, n*k floats); phase_v; phase_post.  v_send / v_recv are not exchanged.
+ *   PRMF_DIST_COLUMN_SHARDED (PRMF_FLAG_COLUMN_SHARDED at creation, or PRMF_DIST_MODE=colshard): rank r
+ *       updates latent columns [r*kc, (r+1)*kc) and their pathway Laplacians.
+ *       phase_u; all_reduce(gram); phase_q; reduce_scatter(q_send -> q_recv, sum); phase_v;
+ *       all_gather(v_send -> v_recv); phase_post. */
+#define PRMF_DIST_COLUMN_SHARDED 0
+#define PRMF_DIST_REPLICATED 1
 
 int prmf_get_comm_sizes(const prmf_ctx* ctx, prmf_comm_sizes* out);
 
@@ -229,6 +251,7 @@ int prmf_get_sweep_info(const prmf_ctx* ctx, prmf_sweep_info* out);
  * prmf_begin..prmf_end span (prmf_step = one span per <=256 iterations); needs
  * timing enabled (PRMF_FLAG_TIMING at creation or prmf_set_timing). */
 #define PRMF_FLAG_TIMING 0x1u
+#define PRMF_FLAG_COLUMN_SHARDED 0x2u   /* nranks > 1: shard the V update by latent columns (see prmf_comm_sizes) */
 /* Switch the per-launch event timing on or off after creation (bench.py times its
  * throughput run without events and a second short run with them). */
 int prmf_set_timing(prmf_ctx* ctx, int enabled);

@@ -14,6 +14,8 @@ PRMF_ABI_VERSION = 1
 PRMF_X_F32, PRMF_X_BF16 = 0, 1
 PRMF_OBJ_STRIDE = 8
 PRMF_FLAG_TIMING = 0x1
+PRMF_FLAG_COLUMN_SHARDED = 0x2
+PRMF_DIST_COLUMN_SHARDED, PRMF_DIST_REPLICATED = 0, 1
 PRMF_COMM_ID_BYTES = 128
 OBJ_KEYS = ("recon", "manifold", "ignore", "fro", "gamma", "delta", "obj")
 
@@ -24,7 +26,7 @@ PRMF_ERR_ARG, PRMF_ERR_HIP, PRMF_ERR_STATE, PRMF_ERR_NUMERIC, PRMF_ERR_UNSUPPORT
 class CommSizes(C.Structure):
     _fields_ = [("gram_doubles", C.c_int64), ("q_send_floats", C.c_int64), ("q_recv_floats", C.c_int64),
                 ("v_send_floats", C.c_int64), ("v_recv_floats", C.c_int64), ("kc", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("mode", C.c_int32)]
 
 
 class SweepInfo(C.Structure):

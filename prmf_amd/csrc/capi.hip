@@ -28,6 +28,12 @@ struct prmf_ctx {
   int k = 0, KP = 0, NT = 0;
   int x_dtype = 0;
   int nranks = 1, rank = 0;
+  // Layout ranks: how many column blocks the V update is split into.  Column-sharded mode: lr = nranks (each rank
+  // updates kc = ceil(k / nranks) columns; reduce-scatter of Q, all-gather of V).  Replicated mode (default for
+  // nranks > 1): lr = 1 -- every rank updates all of V from the all-reduced Q with the single-rank fused kernels;
+  // exchanges: all-reduce of U^T U (k x k float64) and all-reduce of Q (n x k float32).
+  int lr = 1;
+  bool replicated = false;
   int kc = 0, col0 = 0, ncols = 0;
   unsigned flags = 0;
   char err[512] = "";
@@ -204,14 +210,14 @@ int ensure_own_comm(prmf_ctx* c) {
     return fail(c, PRMF_ERR_STATE, "nranks > 1 needs prmf_set_comm_buffers (host-driven collectives) or prmf_comm_init");
   int rc;
   if ((rc = dev_alloc(c, &c->gram_buf, (size_t)c->k * c->k))) return rc;
-  if ((rc = dev_alloc(c, &c->q_send, (size_t)c->n * c->kc * c->nranks))) return rc;
+  if ((rc = dev_alloc(c, &c->q_send, (size_t)c->n * c->kc * c->lr))) return rc;
   if ((rc = dev_alloc(c, &c->v_send, (size_t)c->v_send_floats))) return rc;
-  if (c->nranks == 1) {
+  if (c->lr == 1) {
     c->q_recv = c->q_send;
     c->v_recv = c->v_send;
   } else {
     if ((rc = dev_alloc(c, &c->q_recv, (size_t)c->n * c->kc))) return rc;
-    if ((rc = dev_alloc(c, &c->v_recv, (size_t)c->v_send_floats * c->nranks))) return rc;
+    if ((rc = dev_alloc(c, &c->v_recv, (size_t)c->v_send_floats * c->lr))) return rc;
   }
   c->own_comm = true;
   return PRMF_OK;
@@ -250,8 +256,14 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   c->nranks = nranks;
   c->rank = rank;
   c->flags = flags;
-  c->kc = (k + nranks - 1) / nranks;
-  c->col0 = rank * c->kc;
+  c->replicated = nranks > 1 && !(flags & PRMF_FLAG_COLUMN_SHARDED);
+  if (const char* e = getenv("PRMF_DIST_MODE")) {
+    if (!std::strcmp(e, "colshard")) c->replicated = false;
+    else if (!std::strcmp(e, "replicated")) c->replicated = nranks > 1;
+  }
+  c->lr = c->replicated ? 1 : nranks;
+  c->kc = (k + c->lr - 1) / c->lr;
+  c->col0 = (c->replicated ? 0 : rank) * c->kc;
   c->ncols = c->col0 >= k ? 0 : (c->col0 + c->kc <= k ? c->kc : k - c->col0);
   c->extras_off = round_up(n * c->kc, 2);
   c->v_send_floats = c->extras_off + 8;
@@ -293,7 +305,7 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, &c->active_dev, (size_t)k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->pos, (size_t)n * c->kc, false))) return bail(rc);
   c->fused_u = (k % 4 == 0) && !getenv("PRMF_NO_FUSED_EPILOGUE");
-  c->fused_v = c->fused_u && nranks == 1;
+  c->fused_v = c->fused_u && c->lr == 1;
   c->vblocks = c->fused_v ? v_epilogue_waves(n) : v_update_blocks(n);
   if ((rc = dev_alloc(c, &c->vpartial, (size_t)c->vblocks * (c->kc + 1)))) return bail(rc);
   if ((rc = dev_alloc(c, &c->colres, (size_t)c->kc * 2))) return bail(rc);
@@ -334,7 +346,7 @@ int prmf_destroy(prmf_ctx* c) {
     dev_free(c->gram_buf);
     dev_free(c->q_send);
     dev_free(c->v_send);
-    if (c->nranks > 1) {
+    if (c->lr > 1) {
       dev_free(c->q_recv);
       dev_free(c->v_recv);
     }
@@ -487,11 +499,11 @@ int prmf_get_comm_sizes(const prmf_ctx* c, prmf_comm_sizes* out) {
   if (!c || !out) return PRMF_ERR_ARG;
   out->gram_doubles = (int64_t)c->k * c->k;
   out->q_recv_floats = c->n * c->kc;
-  out->q_send_floats = out->q_recv_floats * c->nranks;
+  out->q_send_floats = out->q_recv_floats * c->lr;
   out->v_send_floats = c->v_send_floats;
-  out->v_recv_floats = c->v_send_floats * c->nranks;
+  out->v_recv_floats = c->v_send_floats * c->lr;
   out->kc = c->kc;
-  out->reserved = 0;
+  out->mode = c->replicated ? PRMF_DIST_REPLICATED : PRMF_DIST_COLUMN_SHARDED;
   return PRMF_OK;
 }
 
@@ -502,12 +514,14 @@ int prmf_set_comm_buffers(prmf_ctx* c, double* gram, float* q_send, float* q_rec
     dev_free(c->gram_buf);
     dev_free(c->q_send);
     dev_free(c->v_send);
-    if (c->nranks > 1) {
+    if (c->lr > 1) {
       dev_free(c->q_recv);
       dev_free(c->v_recv);
     }
     c->own_comm = false;
   }
+  if (c->lr == 1 && (q_recv != q_send || v_recv != v_send))
+    return fail(c, PRMF_ERR_ARG, "with one column block (single rank or replicated mode) q_recv / v_recv must alias q_send / v_send");
   c->gram_buf = gram;
   c->q_send = q_send;
   c->q_recv = q_recv;
@@ -589,11 +603,12 @@ int prmf_phase_q(prmf_ctx* c, void* stream) {
     // Q = X^T U_new                                       (:424)
     HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xtu, c->XT, c->ldxt, c->n, c->Up, c->NT, c->slabs, c->slab_stride_q, s, c->side));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 3], s));
-    if (!c->fused_v)
+    // the replicated multi-rank mode all-reduces Q, so it needs the summed dense form even on the fused path
+    if (!c->fused_v || c->replicated)
       HIP_TRY(c, launch_slab_sum_blocks(c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP, c->n, c->k, c->kc,
-                                        c->nranks, c->q_send, s));
+                                        c->lr, c->q_send, s));
   } else {
-    HIP_TRY(c, hipMemsetAsync(c->q_send, 0, (size_t)c->n * c->kc * c->nranks * sizeof(float), s));
+    HIP_TRY(c, hipMemsetAsync(c->q_send, 0, (size_t)c->n * c->kc * c->lr * sizeof(float), s));
   }
   return PRMF_OK;
 }
@@ -613,7 +628,8 @@ int prmf_phase_v(prmf_ctx* c, void* stream) {
     // single rank: V updated in place straight from the sweep's slabs, packed for the next sweep in the same pass
     HIP_TRY(c, launch_v_epilogue(c->V, c->n, c->k, c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP,
                                  c->gram_buf, c->pos, c->gnum, c->gden, c->lib.max_support, c->x_dtype, c->Vp, c->Kpad_x,
-                                 c->vpartial, (float*)c->gram_partial, &c->gram_v_done, s));
+                                 c->vpartial, (float*)c->gram_partial, &c->gram_v_done,
+                                 c->replicated ? c->q_recv : nullptr, s));
     if (!c->gram_v_done)   // otherwise the objective pieces ride along with the V^T V reduction in phase_post
       HIP_TRY(c, launch_objective_terms(c->lib, c->active_dev, 0, c->k, c->k, c->n, c->V, c->vpartial, c->vblocks, c->colres,
                                         c->obj_scratch, extras, s));
@@ -640,26 +656,26 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
                                (float*)c->gram_partial, &gram_done, s));
       if (gram_done) {
         HIP_TRY(c, launch_gram_reduce((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x), c->k, c->Gv, s));
-        HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->nranks, c->v_send_floats, c->extras_off,
+        HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->lr, c->v_send_floats, c->extras_off,
                                    c->norm_x_sq, c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, nullptr, 0, nullptr, s));
         c->cursor++;
         return PRMF_OK;
       }
     } else {
-      HIP_TRY(c, launch_assemble_v(c->v_recv, c->nranks, c->v_send_floats, c->kc, c->n, c->k, c->V, s));
+      HIP_TRY(c, launch_assemble_v(c->v_recv, c->lr, c->v_send_floats, c->kc, c->n, c->k, c->V, s));
       HIP_TRY(c, launch_pack_factor(fv, c->x_dtype, c->NT, c->Kpad_x, c->Vp, s));
     }
   }
   if (c->fused_v && c->gram_v_done) {
     HIP_TRY(c, launch_post((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x), c->k, c->Gv, c->lib, c->active_dev, c->V,
                            c->vpartial, c->vblocks, c->colres, c->obj_scratch, s));
-    HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->nranks, c->v_send_floats, c->extras_off, c->norm_x_sq,
+    HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->lr, c->v_send_floats, c->extras_off, c->norm_x_sq,
                                c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, c->vpartial, c->vblocks, c->colres, s));
     c->cursor++;
     return PRMF_OK;
   }
   HIP_TRY(c, launch_gram(fv, c->gram_partial, c->Gv, s));
-  HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->nranks, c->v_send_floats, c->extras_off,
+  HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->lr, c->v_send_floats, c->extras_off,
                              c->norm_x_sq, c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, nullptr, 0, nullptr, s));
   c->cursor++;
   return PRMF_OK;
@@ -778,11 +794,17 @@ int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma,
       if ((rc = prmf_phase_u(c, stream))) return rc;
       NCCL_TRY(c, N.AllReduce(c->gram_buf, c->gram_buf, (size_t)c->k * c->k, ncclFloat64, ncclSum, c->comm, s));
       if ((rc = prmf_phase_q(c, stream))) return rc;
-      if (c->nranks > 1 || c->q_recv != c->q_send)
-        NCCL_TRY(c, N.ReduceScatter(c->q_send, c->q_recv, (size_t)c->n * c->kc, ncclFloat32, ncclSum, c->comm, s));
-      if ((rc = prmf_phase_v(c, stream))) return rc;
-      if (c->nranks > 1 || c->v_recv != c->v_send)
-        NCCL_TRY(c, N.AllGather(c->v_send, c->v_recv, (size_t)c->v_send_floats, ncclFloat32, c->comm, s));
+      if (c->replicated) {
+        // every rank gets the full Q and runs the fused single-rank V update on it: no third exchange
+        NCCL_TRY(c, N.AllReduce(c->q_send, c->q_send, (size_t)c->n * c->k, ncclFloat32, ncclSum, c->comm, s));
+        if ((rc = prmf_phase_v(c, stream))) return rc;
+      } else {
+        if (c->nranks > 1 || c->q_recv != c->q_send)
+          NCCL_TRY(c, N.ReduceScatter(c->q_send, c->q_recv, (size_t)c->n * c->kc, ncclFloat32, ncclSum, c->comm, s));
+        if ((rc = prmf_phase_v(c, stream))) return rc;
+        if (c->nranks > 1 || c->v_recv != c->v_send)
+          NCCL_TRY(c, N.AllGather(c->v_send, c->v_recv, (size_t)c->v_send_floats, ncclFloat32, c->comm, s));
+      }
       if ((rc = prmf_phase_post(c, stream))) return rc;
     }
     double gd[2] = {gamma, delta};

@@ -102,7 +102,8 @@ int v_epilogue_waves(int64_t n);
 hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gu, const int32_t* pos, const float* gnum,
                              const float* gden, int max_support, int x_dtype, void* packed, int64_t Kpad,
-                             double* partial, float* gram_partial, bool* gram_done, hipStream_t s);
+                             double* partial, float* gram_partial, bool* gram_done,
+                             const float* qdense /* null: sum the slabs; else Q [n][k], already summed */, hipStream_t s);
 // partial Gram: per-wave partials -> partial[gram_blocks][k*k]; reduce -> G (double)
 int gram_blocks(int64_t rows);
 hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStream_t s);

@@ -521,9 +521,9 @@ hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, con
 // Single-rank V epilogue: V <- V * (Q + g_num) / max(V (U^T U) + g_den, eps), clamp
 // (prmf_runner.py:424-444), in place, + packing + per-wave partial column sums of
 // squares and <Q, V_new> (float64) + (GRAM) V_new^T V_new partials.
-template <int NT, bool BF16, bool GRAM>
+template <int NT, bool BF16, bool GRAM, bool DENSE>
 __global__ void __launch_bounds__(256)
-v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ slabs, const uint32_t* __restrict__ segmask,
+v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ slabs /* DENSE: Q [n][k] */, const uint32_t* __restrict__ segmask,
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gu, const int32_t* __restrict__ pos,
                   const float* __restrict__ gnum, const float* __restrict__ gden, int max_support,
                   void* __restrict__ packed, int64_t ntiles_pack, double* __restrict__ partial /*[waves][k+1]*/,
@@ -552,7 +552,20 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
     if (row0 < n) {
       float ua[16 * NT], vv[NT][16], q[NT][16];
       int ps[NT][16];
-      load_slab_tile<NT>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);   // 4 segments per round trip: no faster
+      if constexpr (DENSE) {
+        // Q already summed over segments and ranks (replicated multi-rank V update): row-major [n][k]
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int col = 32 * t + c, colc = col < k ? col : k - 1;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            q[t][i] = slabs[(row < n ? row : n - 1) * k + colc];
+          }
+        }
+      } else {
+        load_slab_tile<NT>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);   // 4 segments per round trip: no faster
+      }
       load_tile_a_layout<NT>(V, n, k, row0, lane, ua);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -626,15 +639,18 @@ int v_epilogue_waves(int64_t n) { return epilogue_blocks(round_up(n, K_PAD)) * 4
 hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gu, const int32_t* pos, const float* gnum,
                              const float* gden, int max_support, int x_dtype, void* packed, int64_t Kpad,
-                             double* partial, float* gram_partial, bool* gram_done, hipStream_t s) {
+                             double* partial, float* gram_partial, bool* gram_done, const float* qdense, hipStream_t s) {
   const int NT = KP / 32;
   const int64_t ntiles = Kpad / 32;
   // the grid must match v_epilogue_waves(n): every partial row is written by exactly one wave
   const int grid = epilogue_blocks(Kpad);
   *gram_done = NT <= 2;
+  const float* qsrc = qdense ? qdense : slabs;
+#define PRMF_VEP2(NTV, GR, BF, DN)                                                                                  \
+  v_epilogue_kernel<NTV, BF, GR, DN><<<grid, 256, 0, s>>>(V, n, k, qsrc, segmask, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial)
 #define PRMF_VEP(NTV, GR)                                                                                           \
-  if (x_dtype == 1) v_epilogue_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(V, n, k, slabs, segmask, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial); \
-  else v_epilogue_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(V, n, k, slabs, segmask, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial)
+  if (x_dtype == 1) { if (qdense) PRMF_VEP2(NTV, GR, true, true); else PRMF_VEP2(NTV, GR, true, false); }           \
+  else { if (qdense) PRMF_VEP2(NTV, GR, false, true); else PRMF_VEP2(NTV, GR, false, false); }
   switch (NT) {
     case 1: PRMF_VEP(1, true); break;
     case 2: PRMF_VEP(2, true); break;
@@ -643,6 +659,7 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
     default: return hipErrorInvalidValue;
   }
 #undef PRMF_VEP
+#undef PRMF_VEP2
   return hipGetLastError();
 }
 

@@ -1,9 +1,20 @@
-"""Multi-GPU form of the PRMF iteration: one process per GPU, X row-sharded, the
-k latent columns (and their pathway Laplacians) sharded for the V-update, three
-collectives per iteration over torch.distributed (backend "nccl" = RCCL over
-xGMI on ROCm):
+"""Multi-GPU form of the PRMF iteration: one process per GPU, X row-sharded,
+collectives over torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
+
+Replicated mode (default): every rank updates all of V with the fused single-rank
+kernels, two exchanges per iteration
 
     phase_u   P = X_g V, U_g update, partial U_g^T U_g
+        all_reduce(gram)                  k*k float64
+    phase_q   Q_g = X_g^T U_g  (n x k, this rank's rows of X only)
+        all_reduce(q_send)                n*k float32, in place
+    phase_v   V update (all columns) + objective pieces
+    phase_post  V^T V, objective record
+
+Column-sharded mode (engine created with dist_mode="colshard"): the k latent
+columns and their pathway Laplacians are sharded for the V-update, three exchanges
+
+    phase_u   as above
         all_reduce(gram)                  k*k float64
     phase_q   Q_g = X_g^T U_g by owner column block
         reduce_scatter(q_send -> q_recv)  n*kc float32 per rank
@@ -93,6 +104,7 @@ class DistributedPrmf(object):
         if self.native:
             return e.step_dist(U, V, n_steps, gamma, delta, tradeoff)
         b, c = self.buf, self.coll
+        replicated = getattr(e, "dist_mode", "colshard") == "replicated"
         objs_all = []
         gd = (gamma, delta)
         done = 0
@@ -104,10 +116,12 @@ class DistributedPrmf(object):
                 if c:
                     c.all_reduce_sum(b["gram"])
                 e.phase_q()
-                if c:
+                if c and replicated:
+                    c.all_reduce_sum(b["q_send"])
+                elif c:
                     c.reduce_scatter_sum(b["q_recv"], b["q_send"])
                 e.phase_v()
-                if c:
+                if c and not replicated:
                     c.all_gather(b["v_recv"], b["v_send"])
                 e.phase_post()
             objs, gd = e.end(batch)

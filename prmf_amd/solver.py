@@ -40,9 +40,11 @@ class PrmfEngine(object):
 
     nranks > 1: X is row-sharded (this rank holds m_local samples) and the
     phase_* methods are driven by prmf_amd.distributed with collectives between
-    them; see include/prmf_hip.h."""
+    them; see include/prmf_hip.h.  dist_mode: "replicated" (default: every rank
+    updates all of V from the all-reduced X^T U) or "colshard" (the V update is
+    sharded by latent columns: reduce-scatter + all-gather)."""
 
-    def __init__(self, m_local, n, k, x_dtype="f32", device=None, nranks=1, rank=0, timing=False):
+    def __init__(self, m_local, n, k, x_dtype="f32", device=None, nranks=1, rank=0, timing=False, dist_mode=None):
         self.torch = _torch()
         self.lib = _capi.load()
         torch = self.torch
@@ -54,6 +56,10 @@ class PrmfEngine(object):
         self.nranks, self.rank = int(nranks), int(rank)
         self.ctx = C.c_void_p()
         flags = _capi.PRMF_FLAG_TIMING if timing else 0
+        if dist_mode not in (None, "replicated", "colshard"):
+            raise ValueError("dist_mode must be 'replicated' or 'colshard'")
+        if dist_mode == "colshard":
+            flags |= _capi.PRMF_FLAG_COLUMN_SHARDED
         rc = self.lib.prmf_create(C.byref(self.ctx), self.device, self.m, self.n, self.k, self.x_dtype,
                                   self.nranks, self.rank, flags)
         if rc != _capi.PRMF_OK:
@@ -62,6 +68,7 @@ class PrmfEngine(object):
         self._comm = None
         self.sizes = _capi.CommSizes()
         self._check(self.lib.prmf_get_comm_sizes(self.ctx, C.byref(self.sizes)))
+        self.dist_mode = "replicated" if self.sizes.mode == _capi.PRMF_DIST_REPLICATED else "colshard"
 
     # -- plumbing -------------------------------------------------------------
     def _check(self, rc):
@@ -162,15 +169,15 @@ class PrmfEngine(object):
     # -- phase interface (multi-rank; driven by prmf_amd.distributed) -------------
     def comm_buffers(self):
         """Allocate the collective buffers as torch tensors on this GPU and hand
-        their pointers to the library.  With one rank q_recv / v_recv alias the
-        send buffers."""
+        their pointers to the library.  With one rank, and in the replicated
+        multi-rank mode (Q all-reduced in place), q_recv / v_recv alias the send buffers."""
         if self._comm is None:
             torch, s = self.torch, self.sizes
             dev = "cuda:%d" % self.device
             b = {"gram": torch.zeros(s.gram_doubles, dtype=torch.float64, device=dev),
                  "q_send": torch.zeros(s.q_send_floats, dtype=torch.float32, device=dev),
                  "v_send": torch.zeros(s.v_send_floats, dtype=torch.float32, device=dev)}
-            if self.nranks == 1:
+            if self.nranks == 1 or self.dist_mode == "replicated":
                 b["q_recv"], b["v_recv"] = b["q_send"], b["v_send"]
             else:
                 b["q_recv"] = torch.zeros(s.q_recv_floats, dtype=torch.float32, device=dev)

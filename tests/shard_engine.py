@@ -10,12 +10,15 @@ from oracle import prmf_oracle as orc
 
 
 class OracleShardEngine(object):
-    def __init__(self, X_local, n, k, pathways, active, norm_x_sq, nranks, rank):
+    def __init__(self, X_local, n, k, pathways, active, norm_x_sq, nranks, rank, dist_mode="replicated"):
         self.X = np.asarray(X_local, dtype=np.float64)
         self.m, self.n, self.k = self.X.shape[0], n, k
         self.nranks, self.rank = nranks, rank
-        self.kc = (k + nranks - 1) // nranks
-        self.col0 = rank * self.kc
+        self.dist_mode = dist_mode if nranks > 1 else "colshard"
+        # layout ranks: column blocks of the V update (1 in the replicated mode, include/prmf_hip.h)
+        self.lr = 1 if self.dist_mode == "replicated" else nranks
+        self.kc = (k + self.lr - 1) // self.lr
+        self.col0 = (0 if self.lr == 1 else rank) * self.kc
         self.ncols = max(0, min(self.kc, k - self.col0))
         self.pathways, self.active = pathways, list(active)
         self.norm_x_sq = norm_x_sq
@@ -28,13 +31,13 @@ class OracleShardEngine(object):
             nq = self.n * self.kc
             vs = self.extras_off + 8
             b = {"gram": torch.zeros(self.k * self.k, dtype=torch.float64),
-                 "q_send": torch.zeros(nq * self.nranks, dtype=torch.float32),
+                 "q_send": torch.zeros(nq * self.lr, dtype=torch.float32),
                  "v_send": torch.zeros(vs, dtype=torch.float32)}
-            if self.nranks == 1:
+            if self.lr == 1:
                 b["q_recv"], b["v_recv"] = b["q_send"], b["v_send"]
             else:
                 b["q_recv"] = torch.zeros(nq, dtype=torch.float32)
-                b["v_recv"] = torch.zeros(vs * self.nranks, dtype=torch.float32)
+                b["v_recv"] = torch.zeros(vs * self.lr, dtype=torch.float32)
             self._buf = b
         return self._buf
 
@@ -57,9 +60,9 @@ class OracleShardEngine(object):
 
     def phase_q(self):                   # :424, laid out by owner column block
         Q = self.X.T @ self.U.double().numpy()
-        qs = self._buf["q_send"].view(self.nranks, self.n, self.kc)
+        qs = self._buf["q_send"].view(self.lr, self.n, self.kc)
         qs.zero_()
-        for r in range(self.nranks):
+        for r in range(self.lr):
             c0 = r * self.kc
             nc = max(0, min(self.kc, self.k - c0))
             if nc:
@@ -96,7 +99,7 @@ class OracleShardEngine(object):
         vr = self._buf["v_recv"]
         stride = self.extras_off + 8
         cross = man = ign = 0.0
-        for r in range(self.nranks):
+        for r in range(self.lr):
             blk = vr[r * stride:(r + 1) * stride]
             c0 = r * self.kc
             nc = max(0, min(self.kc, self.k - c0))

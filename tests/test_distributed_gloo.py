@@ -1,6 +1,7 @@
 """world_size-2 test of the multi-rank iteration (prmf_amd/distributed.py) over
-gloo on CPU: row-sharded X, column-sharded V-update, all_reduce / reduce_scatter /
-all_gather between the phases -- against the single-process oracle."""
+gloo on CPU: row-sharded X; replicated mode (all_reduce of U^T U and of Q) and
+column-sharded mode (all_reduce / reduce_scatter / all_gather) between the phases
+-- against the single-process oracle."""
 import os
 import socket
 
@@ -21,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, k, tradeoff, q):
+def _worker(rank, world, port, k, tradeoff, mode, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -35,7 +36,7 @@ def _worker(rank, world, port, k, tradeoff, q):
         pws = [orc.pathway_from_edges(X.shape[1], e, nodes, w) for (e, w, nodes) in case["pathways"]]
         active = [i % len(pws) for i in range(k)]
         lo, hi = shard_rows(X.shape[0], world, rank)
-        eng = OracleShardEngine(X[lo:hi], X.shape[1], k, pws, active, float(np.sum(X * X)), world, rank)
+        eng = OracleShardEngine(X[lo:hi], X.shape[1], k, pws, active, float(np.sum(X * X)), world, rank, dist_mode=mode)
         U = torch.from_numpy(case["U0"][lo:hi]).float().contiguous()
         V = torch.from_numpy(case["V0"]).float().contiguous()
         runner = DistributedPrmf(eng)
@@ -52,13 +53,14 @@ def _worker(rank, world, port, k, tradeoff, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k,tradeoff", [(6, None), (5, None), (6, 0.6)])
-def test_two_rank_iteration_matches_oracle(k, tradeoff):
+@pytest.mark.parametrize("k,tradeoff,mode", [(6, None, "replicated"), (5, None, "replicated"), (6, 0.6, "replicated"),
+                                             (6, None, "colshard"), (5, None, "colshard"), (6, 0.6, "colshard")])
+def test_two_rank_iteration_matches_oracle(k, tradeoff, mode):
     from oracle import prmf_oracle as orc
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, tradeoff, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, tradeoff, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

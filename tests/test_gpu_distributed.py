@@ -1,6 +1,7 @@
 """Two ranks sharing the one GPU of the test box (gloo between the processes):
-the real HIP phases with row-sharded X and column-sharded V-update must reproduce
-the single-rank result."""
+the real HIP phases with row-sharded X, in the replicated mode (all-reduce of U^T U
+and of Q, fused single-rank V update on every rank) and in the column-sharded mode
+(reduce-scatter / all-gather), must reproduce the single-rank result."""
 import os
 import socket
 
@@ -20,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, k, x_dtype, q):
+def _worker(rank, world, port, k, x_dtype, mode, q):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,7 +35,8 @@ def _worker(rank, world, port, k, x_dtype, q):
         case = synth.small_case(seed=13, m=700, n=1500, k=k, P=6, order=80, bf16_x=(x_dtype == "bf16"))
         X = case["X"]
         lo, hi = shard_rows(X.shape[0], world, rank)
-        eng = PrmfEngine(hi - lo, X.shape[1], k, x_dtype=x_dtype, device=0, nranks=world, rank=rank)
+        eng = PrmfEngine(hi - lo, X.shape[1], k, x_dtype=x_dtype, device=0, nranks=world, rank=rank, dist_mode=mode)
+        assert eng.dist_mode == mode
         eng.set_x(X[lo:hi], norm_x_sq=float(np.sum(X * X)))
         eng.set_library(PathwayLibrary.from_edge_lists(X.shape[1], case["pathways"]))
         eng.set_active(np.arange(k) % 6)
@@ -47,15 +49,16 @@ def _worker(rank, world, port, k, x_dtype, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k,x_dtype", [(16, "f32"), (13, "bf16")])
-def test_two_ranks_match_single_rank(k, x_dtype):
+@pytest.mark.parametrize("k,x_dtype,mode", [(16, "f32", "replicated"), (13, "bf16", "replicated"), (64, "bf16", "replicated"),
+                                             (16, "f32", "colshard"), (13, "bf16", "colshard")])
+def test_two_ranks_match_single_rank(k, x_dtype, mode):
     import torch
     import torch.multiprocessing as mp
     from oracle import prmf_oracle as orc
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, x_dtype, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, x_dtype, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}

@@ -31,8 +31,8 @@ __global__ void __launch_bounds__(512) k(const u32x4* __restrict__ A, long ld16,
   if (acc == 0x12345678u) out[0] = acc;
 }
 
-int main() {
-  const long rows = 50176, rowbytes = 40192;   // X of C3 (padded): 196 panels x 314 chunks
+int main(int argc, char** argv) {
+  const long rows = argc > 1 ? atol(argv[1]) : 50176, rowbytes = argc > 2 ? atol(argv[2]) : 40192;   // X of C3 (padded): 196 panels x 314 chunks
   const int panels = rows / 256, chunks = rowbytes / 128;
   u32x4* A; unsigned* out;
   hipMalloc(&A, rows * rowbytes); hipMalloc(&out, 4);
@@ -54,7 +54,8 @@ int main() {
     printf("%s nt=%d grid=%4d  best %.3f ms %.2f TB/s   mean %.3f ms %.2f TB/s\n", mode ? "linear " : "strided", (int)nt, grid,
            best, bytes / best / 1e9, sum / 5, bytes / (sum / 5) / 1e9);
   };
-  for (int grid : {512, 1024, 2048})
+  printf("rows %ld x %ld bytes = %.1f MB\n", rows, rowbytes, rows * rowbytes / 1e6);
+  for (int grid : {512, 1024})
     for (int mode : {0, 1})
       for (int nt : {1, 0}) run(mode, nt, grid);
   return 0;

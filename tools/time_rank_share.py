@@ -10,7 +10,8 @@ m, n, k, P = 50000, 20000, 64, 300
 dev = "cuda:0"
 lo, hi = syn.shard_rows(m, N, 0)
 Xd = syn.x_rows_torch(torch, dev, 0, n, k, lo, hi, torch.bfloat16)
-eng = PrmfEngine(hi - lo, n, k, x_dtype="bf16", nranks=N, rank=0)
+MODE = os.environ.get("MODE", "replicated")
+eng = PrmfEngine(hi - lo, n, k, x_dtype="bf16", nranks=N, rank=0, dist_mode=MODE)
 eng.set_x(Xd, norm_x_sq=1e6); del Xd
 eng.set_library(PathwayLibrary.from_edge_lists(n, syn.tree_pathways(n, P, 300, 0)))
 eng.set_active([kk % P for kk in range(k)])
@@ -25,9 +26,13 @@ for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(50):
         eng.phase_u(); eng.phase_q()
-        b["q_recv"].copy_(b["q_send"][:b["q_recv"].numel()])      # stand-in for the reduce-scatter
-        eng.phase_v()
-        b["v_recv"].view(N, -1).copy_(b["v_send"].unsqueeze(0).expand(N, -1))   # stand-in for the all-gather
+        if eng.dist_mode == "replicated":
+            b["q_send"].mul_(1.0)                                      # stand-in for the in-place all-reduce of Q
+            eng.phase_v()
+        else:
+            b["q_recv"].copy_(b["q_send"][:b["q_recv"].numel()])      # stand-in for the reduce-scatter
+            eng.phase_v()
+            b["v_recv"].view(N, -1).copy_(b["v_send"].unsqueeze(0).expand(N, -1))   # stand-in for the all-gather
         eng.phase_post()
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     try:
@@ -35,4 +40,4 @@ for rep in range(3):
     except FloatingPointError:
         pass
 sw = " sweeps %.1f + %.1f us" % (eng.timing()[0] * 1e3, eng.timing()[1] * 1e3) if os.environ.get("SWEEP_EVENTS") else ""
-print("N=%d rank share %dx%d: %.1f us per iteration (device, incl. two stand-in copies)%s" % (N, hi - lo, n, el / 50 * 1e6, sw))
+print(eng.dist_mode, end=" "); print("N=%d rank share %dx%d: %.1f us per iteration (device, incl. two stand-in copies)%s" % (N, hi - lo, n, el / 50 * 1e6, sw))
