@@ -8,8 +8,8 @@ record, script/prmf_runner.py:420-447) on synthetic inputs of the configuration
 BASELINE.json's target is quoted on (c3: X 50000 x 20000 bf16, k = 64, 300 tree
 pathways).  X, U, V are resident in HBM before the timed
 region.  With N > 1 (launched by torch.distributed.run, one rank per GPU) the
-SAME global problem is row-sharded over the ranks (strong scaling), exchanges go
-over RCCL.  Rank 0 prints one JSON line.
+SAME global problem is row-sharded over the ranks (strong scaling); per iteration the
+k x k Gram U^T U and the n x k product X^T U are all-reduced over RCCL.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -165,7 +165,9 @@ def main():
                                    "active pathway k mod P, gamma=||X||/k, delta=10/||X||"
                                    % (args.workload, m, n, x_dtype, k, P),
                        "samples": m, "genes": n, "k_latent": k, "pathways": P,
-                       "parallelism": "X row-sharded x%d, V-update column-sharded" % world},
+                       "parallelism": ("single GPU" if world == 1 else
+                                       "X row-sharded x%d, V update %s, RCCL %s" % (
+                                           world, eng.dist_mode, "in-library" if runner.native else "host-driven"))},
             "recon_err": objs[-1]["recon"], "objective": objs[-1]["obj"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
