@@ -87,18 +87,27 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
+    # rehearsal on a one-GPU box: PRMF_BENCH_BACKEND=gloo PRMF_BENCH_SHARE_GPU=1 lets N ranks share cuda:0 and
+    # exchange through the host (RCCL refuses two ranks on one device); never used for reported numbers
+    backend = os.environ.get("PRMF_BENCH_BACKEND", "nccl")
+    if os.environ.get("PRMF_BENCH_SHARE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     m, n, k, P, x_dtype = syn.CONFIGS[args.workload]
     tdt = torch.bfloat16 if x_dtype == "bf16" else torch.float32
     lo, hi = syn.shard_rows(m, world, rank)
     Xd = syn.x_rows_torch(torch, dev, args.seed, n, k, lo, hi, tdt)
     eng = PrmfEngine(hi - lo, n, k, x_dtype=x_dtype, device=local_rank, nranks=world, rank=rank)
-    nsq = torch.tensor([eng.local_norm_sq(Xd)], dtype=torch.float64, device=dev)
+    cdev = dev if backend == "nccl" else "cpu"         # where the tiny control tensors of the collectives live
+    nsq = torch.tensor([eng.local_norm_sq(Xd)], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(nsq)
     norm_x = math.sqrt(float(nsq.item()))
@@ -131,7 +140,7 @@ def main():
     objs, _ = step(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
@@ -176,6 +185,8 @@ def main():
                          "ms_xv": ms_xv, "ms_xtu": ms_xtu,
                          "sweep_share_of_step": 2 * avg_ms / (1e3 * elapsed / args.steps)},
         }
+        if backend != "nccl":
+            out["config"]["rehearsal"] = "ranks share one GPU, exchanges staged through the host (%s): not a measurement" % backend
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, Xd, U0, V0, pathways, active, gamma, delta, m, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
