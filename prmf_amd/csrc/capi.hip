@@ -786,14 +786,25 @@ int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma,
   if (n_steps < 0) return fail(c, PRMF_ERR_ARG, "n_steps < 0");
   hipStream_t s = (hipStream_t)stream;
   const RcclApi& N = rccl();
+  const bool overlap = c->side.stream && !(getenv("PRMF_DIST_OVERLAP") && atoi(getenv("PRMF_DIST_OVERLAP")) == 0);
   int done = 0, rc;
   while (done < n_steps) {
     const int batch = n_steps - done < MAX_RECORDS ? n_steps - done : MAX_RECORDS;
     if ((rc = prmf_begin(c, dU, dV, gamma, delta, tradeoff, stream))) return rc;
     for (int i = 0; i < batch; ++i) {
       if ((rc = prmf_phase_u(c, stream))) return rc;
-      NCCL_TRY(c, N.AllReduce(c->gram_buf, c->gram_buf, (size_t)c->k * c->k, ncclFloat64, ncclSum, c->comm, s));
+      // The k x k all-reduce is latency-bound and its result is first needed by phase_v: it runs on the side
+      // stream next to the X^T U sweep (which depends only on the local U) and is joined before phase_v.
+      if (overlap) {
+        HIP_TRY(c, hipEventRecord(c->side.fork, s));
+        HIP_TRY(c, hipStreamWaitEvent(c->side.stream, c->side.fork, 0));
+        NCCL_TRY(c, N.AllReduce(c->gram_buf, c->gram_buf, (size_t)c->k * c->k, ncclFloat64, ncclSum, c->comm, c->side.stream));
+        HIP_TRY(c, hipEventRecord(c->side.join, c->side.stream));
+      } else {
+        NCCL_TRY(c, N.AllReduce(c->gram_buf, c->gram_buf, (size_t)c->k * c->k, ncclFloat64, ncclSum, c->comm, s));
+      }
       if ((rc = prmf_phase_q(c, stream))) return rc;
+      if (overlap) HIP_TRY(c, hipStreamWaitEvent(s, c->side.join, 0));
       if (c->replicated) {
         // every rank gets the full Q and runs the fused single-rank V update on it: no third exchange
         NCCL_TRY(c, N.AllReduce(c->q_send, c->q_send, (size_t)c->n * c->k, ncclFloat32, ncclSum, c->comm, s));
