@@ -1,0 +1,69 @@
+"""Edge shapes and every sweep variant of the HIP path against the oracle: one sample, one gene block,
+one latent factor, a pathway of two nodes, fewer rows than a wave tile, and the workgroup shapes that the
+library only picks for other k (forced through the PRMF_SWEEP_* knobs)."""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def check(case, x_dtype, steps=5):
+    import torch
+    from oracle import prmf_oracle as orc
+    from prmf_amd import PathwayLibrary
+    from prmf_amd.solver import PrmfEngine
+    m, n = case["X"].shape
+    k = case["k"]
+    eng = PrmfEngine(m, n, k, x_dtype=x_dtype)
+    eng.set_x(case["X"])
+    eng.set_library(PathwayLibrary.from_edge_lists(n, case["pathways"]))
+    P = len(case["pathways"])
+    eng.set_active(np.arange(k) % P)
+    U = eng.device_tensor(case["U0"], torch.float32)
+    V = eng.device_tensor(case["V0"], torch.float32)
+    objs, _ = eng.step(U, V, steps, case["gamma"], case["delta"])
+    eng.close()
+    pws = [orc.pathway_from_edges(n, e, nodes, w) for (e, w, nodes) in case["pathways"]]
+    tr = []
+    Ur, Vr, od = orc.nmf_manifold_vec_update(case["X"], case["U0"], case["V0"], [pws[i % P] for i in range(k)],
+                                             n_steps=steps, gamma=case["gamma"], delta=case["delta"], trace=tr)
+    assert rel(U.cpu().numpy(), Ur) < 1e-4 and rel(V.cpu().numpy(), Vr) < 1e-4
+    for a, b in zip(objs, tr):
+        for key in ("recon", "manifold", "ignore", "fro", "obj"):
+            assert abs(a[key] - b[key]) <= 1e-4 * max(abs(b[key]), 1e-12), key
+
+
+@pytest.mark.parametrize("m,n,k,P,order,x_dtype", [
+    (1, 40, 1, 1, 2, "f32"),          # one sample, one latent factor, a two-node pathway
+    (3, 33, 2, 1, 5, "bf16"),
+    (31, 64, 4, 2, 10, "f32"),        # fewer rows than one MFMA tile, fused epilogues (k % 4 == 0)
+    (33, 31, 3, 3, 8, "bf16"),        # fewer genes than one tile
+    (257, 129, 8, 2, 20, "bf16"),     # one row past a 256-row panel, one chunk past 128 genes
+    (64, 2049, 32, 4, 30, "f32"),
+])
+def test_tiny_and_ragged_shapes(m, n, k, P, order, x_dtype):
+    case = synth.small_case(seed=21, m=m, n=n, k=k, P=P, order=order, zero_genes=min(3, n // 8), isolated=1,
+                            bf16_x=(x_dtype == "bf16"))
+    check(case, x_dtype)
+
+
+@pytest.mark.parametrize("env", [
+    {"PRMF_SWEEP_NW": "8", "PRMF_SWEEP_MT": "1"},
+    {"PRMF_SWEEP_NW": "8", "PRMF_SWEEP_MT": "2"},
+    {"PRMF_SWEEP_NW": "4", "PRMF_SWEEP_MT": "1"},
+    {"PRMF_SWEEP_NW": "4", "PRMF_SWEEP_MT": "2", "PRMF_SWEEP_BDB": "0"},
+    {"PRMF_NO_FUSED_EPILOGUE": "1"},
+])
+@pytest.mark.parametrize("k,x_dtype", [(16, "f32"), (64, "bf16")])
+def test_sweep_variants(env, k, x_dtype, monkeypatch):
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    case = synth.small_case(seed=23, m=900, n=1700, k=k, P=6, order=60, bf16_x=(x_dtype == "bf16"))
+    check(case, x_dtype, steps=4)
