@@ -1128,24 +1128,31 @@ finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, in
                 int nranks, int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* __restrict__ hyper,
                 double* __restrict__ record, const double* __restrict__ loc_partial, int loc_nblocks,
                 const double* __restrict__ loc_colres) {
-  __shared__ double red[256];
+  __shared__ double red[5][256];
   const int tid = threadIdx.x;
-  double gg = 0.0, fro = 0.0;
-  for (int i = tid; i < k * k; i += 256) gg += Gu[i] * Gv[i];
-  for (int a = tid; a < k; a += 256) fro += Gu[a * k + a];
-  gg = block_sum_256(gg, red);
-  fro = block_sum_256(fro, red);
-  double lcross = 0.0, lman = 0.0, lign = 0.0;
+  // five sums, one tree reduction (fixed order: deterministic)
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // <Gu,Gv>, trace Gu, cross, manifold, ignore
+  for (int i = tid; i < k * k; i += 256) acc[0] += Gu[i] * Gv[i];
+  for (int a = tid; a < k; a += 256) acc[1] += Gu[a * k + a];
   if (loc_partial) {
-    for (int b = tid; b < loc_nblocks; b += 256) lcross += loc_partial[(int64_t)b * (k + 1) + k];
+    for (int b = tid; b < loc_nblocks; b += 256) acc[2] += loc_partial[(int64_t)b * (k + 1) + k];
     for (int c = tid; c < k; c += 256) {
-      lman += loc_colres[2 * c];
-      lign += loc_colres[2 * c + 1];
+      acc[3] += loc_colres[2 * c];
+      acc[4] += loc_colres[2 * c + 1];
     }
-    lcross = block_sum_256(lcross, red);
-    lman = block_sum_256(lman, red);
-    lign = block_sum_256(lign, red);
   }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) red[j][tid] = acc[j];
+  __syncthreads();
+#pragma unroll
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) red[j][tid] += red[j][tid + s];
+    }
+    __syncthreads();
+  }
+  const double gg = red[0][0], fro = red[1][0], lcross = red[2][0], lman = red[3][0], lign = red[4][0];
   if (tid == 0) {
     double cross = lcross, man = lman, ign = lign;
     if (!loc_partial)
