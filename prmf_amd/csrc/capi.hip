@@ -99,6 +99,15 @@ struct prmf_ctx {
   int timed_iters = 0;
 
   SweepSide side{};                   // side stream for the sweeps' tail launches
+  // The small kernels between the sweeps (Gram reductions, pathway terms, objective pieces, record) are not on
+  // the sweeps' dependency chain: inside prmf_step / prmf_step_dist they run on `aux` next to the following
+  // sweep and are joined where their results are first read (U epilogue: V^T V; V epilogue: U^T U + pathway
+  // terms; prmf_end: records).  Off for the caller-driven phase interface, whose collectives run on the
+  // caller's stream between the phase calls.
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_post = nullptr;
+  bool internal_driver = false, overlap_small = true;
+  bool mid_pending = false, post_pending = false;
 
   // RCCL (resolved at run time, see prmf_comm_init)
   ncclComm_t comm = nullptr;
@@ -324,6 +333,14 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
     fail(c, PRMF_ERR_HIP, "side stream / events could not be created");
     return bail(PRMF_ERR_HIP);
   }
+  if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming) != hipSuccess) {
+    fail(c, PRMF_ERR_HIP, "aux stream / events could not be created");
+    return bail(PRMF_ERR_HIP);
+  }
+  if (const char* e = getenv("PRMF_OVERLAP_SMALL")) c->overlap_small = atoi(e) != 0;
   if ((flags & PRMF_FLAG_TIMING) && (rc = prmf_set_timing(c, 1))) return bail(rc);
   *out = c;
   return PRMF_OK;
@@ -352,6 +369,10 @@ int prmf_destroy(prmf_ctx* c) {
     }
   }
   if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
+  if (c->ev_post) (void)hipEventDestroy(c->ev_post);
+  if (c->aux) (void)hipStreamDestroy(c->aux);
   if (c->side.fork) (void)hipEventDestroy(c->side.fork);
   if (c->side.join) (void)hipEventDestroy(c->side.join);
   if (c->side.stream) (void)hipStreamDestroy(c->side.stream);
@@ -550,6 +571,7 @@ int prmf_begin(prmf_ctx* c, float* dU, float* dV, double gamma, double delta, do
   HIP_TRY(c, hipMemcpyAsync(c->hyper, c->hyper_host, 4 * sizeof(double), hipMemcpyHostToDevice, s));
   c->cursor = 0;
   c->graph_done = false;
+  c->mid_pending = c->post_pending = false;
   if (!c->prepared && (rc = prepare(c, s))) return rc;
   return PRMF_OK;
 }
@@ -569,15 +591,29 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 1], s));
     // U <- U * P / (U Gv + U)                              (:421-422)
     FactorView fu{c->U, (int)c->m, c->k, c->k, 0};
+    if (c->post_pending) {            // V^T V (and gamma/delta) of the previous iteration come from the aux stream
+      HIP_TRY(c, hipStreamWaitEvent(s, c->ev_post, 0));
+      c->post_pending = false;
+    }
     if (c->fused_u) {
       bool gram_done = false;
       HIP_TRY(c, launch_u_epilogue(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP,
                                    c->Gv, c->x_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, s));
       if (gram_done) {
         // one launch: reduce (this rank's) U^T U and compute the pathway terms of the own columns
-        // (they depend on the old V and gamma/delta only)
+        // (they depend on the old V and gamma/delta only); next to the X^T U sweep when driven internally
+        hipStream_t ms = s;
+        if (c->internal_driver && c->overlap_small) {
+          HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+          HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+          ms = c->aux;
+        }
         HIP_TRY(c, launch_mid((const float*)c->gram_partial, epilogue_blocks(c->Kpad_xt), c->k, c->gram_buf, c->lib,
-                              c->active_dev, c->col0, c->ncols, c->V, c->hyper, c->gnum, c->gden, s));
+                              c->active_dev, c->col0, c->ncols, c->V, c->hyper, c->gnum, c->gden, ms));
+        if (ms != s) {
+          HIP_TRY(c, hipEventRecord(c->ev_mid, c->aux));
+          c->mid_pending = true;
+        }
         c->graph_done = true;
         return PRMF_OK;
       }
@@ -587,6 +623,10 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
     }
     HIP_TRY(c, launch_gram(fu, c->gram_partial, c->gram_buf, s));
   } else {
+    if (c->post_pending) {
+      HIP_TRY(c, hipStreamWaitEvent(s, c->ev_post, 0));
+      c->post_pending = false;
+    }
     HIP_TRY(c, hipMemsetAsync(c->gram_buf, 0, (size_t)c->k * c->k * sizeof(double), s));
   }
   return PRMF_OK;
@@ -618,6 +658,10 @@ int prmf_phase_v(prmf_ctx* c, void* stream) {
   if ((rc = check_ready(c))) return rc;
   if ((rc = set_device(c))) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if (c->mid_pending) {               // U^T U and the pathway terms were computed next to the X^T U sweep
+    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_mid, 0));
+    c->mid_pending = false;
+  }
   // sparse pathway terms on the OLD V                    (:431-438)
   if (!c->graph_done)
     HIP_TRY(c, launch_graph_terms(c->lib, c->active_dev, c->col0, c->ncols, c->V, c->k, c->hyper, c->gnum, c->gden, s));
@@ -667,10 +711,22 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
     }
   }
   if (c->fused_v && c->gram_v_done) {
+    // V^T V, the objective pieces and the record are first read by the NEXT iteration's U epilogue (and by
+    // prmf_end): next to the following X V sweep when driven internally
+    hipStream_t ps = s;
+    if (c->internal_driver && c->overlap_small) {
+      HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+      HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+      ps = c->aux;
+    }
     HIP_TRY(c, launch_post((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x), c->k, c->Gv, c->lib, c->active_dev, c->V,
-                           c->vpartial, c->vblocks, c->colres, c->obj_scratch, s));
+                           c->vpartial, c->vblocks, c->colres, c->obj_scratch, ps));
     HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->lr, c->v_send_floats, c->extras_off, c->norm_x_sq,
-                               c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, c->vpartial, c->vblocks, c->colres, s));
+                               c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, c->vpartial, c->vblocks, c->colres, ps));
+    if (ps != s) {
+      HIP_TRY(c, hipEventRecord(c->ev_post, c->aux));
+      c->post_pending = true;
+    }
     c->cursor++;
     return PRMF_OK;
   }
@@ -687,6 +743,9 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
   int rc;
   if ((rc = set_device(c))) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if (c->mid_pending) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_mid, 0));
+  if (c->post_pending) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_post, 0));
+  c->mid_pending = c->post_pending = false;
   if (n_steps > 0)
     HIP_TRY(c, hipMemcpyAsync(c->records_host, c->records + (size_t)(c->cursor - n_steps) * PRMF_OBJ_STRIDE,
                               (size_t)n_steps * PRMF_OBJ_STRIDE * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -723,6 +782,11 @@ int prmf_step(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma, doub
   if (n_steps < 0) return fail(c, PRMF_ERR_ARG, "n_steps < 0");
   int done = 0;
   int rc;
+  struct Internal {
+    prmf_ctx* c;
+    explicit Internal(prmf_ctx* c_) : c(c_) { c->internal_driver = true; }
+    ~Internal() { c->internal_driver = false; }
+  } internal(c);
   while (done < n_steps || (n_steps == 0 && done == 0)) {
     int batch = n_steps - done < MAX_RECORDS ? n_steps - done : MAX_RECORDS;
     if ((rc = prmf_begin(c, dU, dV, gamma, delta, tradeoff, stream))) return rc;
@@ -788,6 +852,11 @@ int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma,
   const RcclApi& N = rccl();
   const bool overlap = c->side.stream && !(getenv("PRMF_DIST_OVERLAP") && atoi(getenv("PRMF_DIST_OVERLAP")) == 0);
   int done = 0, rc;
+  struct Internal {
+    prmf_ctx* c;
+    explicit Internal(prmf_ctx* c_) : c(c_) { c->internal_driver = true; }
+    ~Internal() { c->internal_driver = false; }
+  } internal(c);
   while (done < n_steps) {
     const int batch = n_steps - done < MAX_RECORDS ? n_steps - done : MAX_RECORDS;
     if ((rc = prmf_begin(c, dU, dV, gamma, delta, tradeoff, stream))) return rc;
@@ -795,16 +864,20 @@ int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma,
       if ((rc = prmf_phase_u(c, stream))) return rc;
       // The k x k all-reduce is latency-bound and its result is first needed by phase_v: it runs on the side
       // stream next to the X^T U sweep (which depends only on the local U) and is joined before phase_v.
-      if (overlap) {
-        HIP_TRY(c, hipEventRecord(c->side.fork, s));
-        HIP_TRY(c, hipStreamWaitEvent(c->side.stream, c->side.fork, 0));
-        NCCL_TRY(c, N.AllReduce(c->gram_buf, c->gram_buf, (size_t)c->k * c->k, ncclFloat64, ncclSum, c->comm, c->side.stream));
-        HIP_TRY(c, hipEventRecord(c->side.join, c->side.stream));
+      if (c->mid_pending) {
+        // the Gram reduction already runs on the aux stream: the all-reduce follows it there
+        NCCL_TRY(c, N.AllReduce(c->gram_buf, c->gram_buf, (size_t)c->k * c->k, ncclFloat64, ncclSum, c->comm, c->aux));
+        HIP_TRY(c, hipEventRecord(c->ev_mid, c->aux));          // phase_v joins on this
+      } else if (overlap) {
+        HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+        HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        NCCL_TRY(c, N.AllReduce(c->gram_buf, c->gram_buf, (size_t)c->k * c->k, ncclFloat64, ncclSum, c->comm, c->aux));
+        HIP_TRY(c, hipEventRecord(c->ev_mid, c->aux));
+        c->mid_pending = true;
       } else {
         NCCL_TRY(c, N.AllReduce(c->gram_buf, c->gram_buf, (size_t)c->k * c->k, ncclFloat64, ncclSum, c->comm, s));
       }
       if ((rc = prmf_phase_q(c, stream))) return rc;
-      if (overlap) HIP_TRY(c, hipStreamWaitEvent(s, c->side.join, 0));
       if (c->replicated) {
         // every rank gets the full Q and runs the fused single-rank V update on it: no third exchange
         NCCL_TRY(c, N.AllReduce(c->q_send, c->q_send, (size_t)c->n * c->k, ncclFloat32, ncclSum, c->comm, s));
