@@ -100,13 +100,16 @@ struct prmf_ctx {
 
   SweepSide side{};                   // side stream for the sweeps' tail launches
   // The small kernels between the sweeps (Gram reductions, pathway terms, objective pieces, record) are not on
-  // the sweeps' dependency chain: inside prmf_step / prmf_step_dist they run on `aux` next to the following
-  // sweep and are joined where their results are first read (U epilogue: V^T V; V epilogue: U^T U + pathway
-  // terms; prmf_end: records).  Off for the caller-driven phase interface, whose collectives run on the
+  // the sweeps' dependency chain: inside prmf_step / prmf_step_dist they CAN run on `aux` next to the following
+  // sweep, joined where their results are first read (U epilogue: V^T V; V epilogue: U^T U + pathway terms;
+  // prmf_end: records).  Measured: each cross-stream event edge costs about 5 us, four per iteration:
+  // +0.8% at 50000x20000 k=64 (27 us hidden), neutral at 25000x25000 k=128, -15% at 5000x10000 k=16 -- so it
+  // is OFF by default (PRMF_OVERLAP_SMALL=1 turns it on).  The multi-rank step uses `aux` for the k x k
+  // all-reduce either way.  Never used by the caller-driven phase interface, whose collectives run on the
   // caller's stream between the phase calls.
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_post = nullptr;
-  bool internal_driver = false, overlap_small = true;
+  bool internal_driver = false, overlap_small = false;
   bool mid_pending = false, post_pending = false;
 
   // RCCL (resolved at run time, see prmf_comm_init)

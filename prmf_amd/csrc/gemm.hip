@@ -161,16 +161,16 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], const u32x4
 }
 
 // ---- loads ----------------------------------------------------------------------
-// The next chunk's A lines and B slice are loaded (plain loads) right after the MFMAs
-// of the current chunk and written to LDS as soon as they arrive; the latency is
-// covered by the other resident workgroup(s) of the CU, not by a software pipeline.
-// History (kept because it cost a day): a deeper pipeline with hand-issued asm loads
-// and counted `s_waitcnt vmcnt(N)` (newest loads left in flight) was (a) not faster at
-// this occupancy and (b) UNSAFE: at 50000x20000 about 1e-5 of the wave-steps saw an
-// OLDER load still outstanding with only the N youngest pending -> 2-4 wrong 32-row
-// tiles per launch, different every run.  With vmcnt(0)-style full waits the results
-// are bit-identical run to run.  The design therefore never relies on the completion
-// order of global loads.
+// The next chunk's A lines and B slice are loaded (plain loads into registers) BEFORE the MFMAs of the current
+// chunk, so they are in flight while the wave computes from LDS, and are written to LDS afterwards (one full
+// wait per chunk).  With 64-row wave tiles this order is worth +5% at k = 128 (where a chunk is 64 MFMAs per
+// wave) and +8% on the sweeps of the f32 k = 16 case; at k = 64 it is neutral (it was 2% slower with the earlier
+// 8 x 32-row shape, whose waves had half the MFMA work per chunk to hide the loads behind).
+// History (kept because it cost a day): a deeper pipeline with hand-issued asm loads and counted
+// `s_waitcnt vmcnt(N)` (newest loads left in flight across iterations) was (a) not faster and (b) UNSAFE: at
+// 50000x20000 about 1e-5 of the wave-steps saw an OLDER load still outstanding with only the N youngest
+// pending -> 2-4 wrong 32-row tiles per launch, different every run.  The design therefore never carries a
+// load across a chunk boundary: every chunk ends with all of its loads landed and stored.
 
 #ifndef PRMF_A_NT
 #define PRMF_A_NT 1
@@ -182,7 +182,7 @@ constexpr bool NT_LOADS = PRMF_A_NT != 0;   // A is read exactly once: non-tempo
 constexpr bool SLAB_NT = PRMF_SLAB_NT != 0; // slabs leave as full-line streaming writes (see the sweep's epilogue)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef PRMF_LOADS_FIRST
-#define PRMF_LOADS_FIRST 0
+#define PRMF_LOADS_FIRST 1
 #endif
 constexpr bool LOADS_FIRST = PRMF_LOADS_FIRST != 0;
 
@@ -365,13 +365,15 @@ struct SweepVariant { int nw; bool bdb; int wgs_per_cu; int mt; };
 // k <= 64 (NT <= 2): 4 waves x 64 rows per workgroup (two 32-row MFMA tiles per wave share every B fragment
 // read: half the LDS traffic per byte of X of the 8 x 32 shape; measured at 50000x20000 k=64 0.336/0.343 ms
 // against 0.347/0.352, at 5000x10000 k=16 f32 +5%), B double-buffered, 2 workgroups per CU.
-// k > 64: 8 waves x 32 rows (the 64-row tile would need > 256 registers), B double-buffered only while two
-// workgroups still fit the 160 KiB LDS (k = 128: 32 + 32 KiB single-buffered, 0.368 vs 0.396 ms).
+// k > 64: the same 4 x 64-row shape with the factor single-buffered (k = 128: 32 KiB of A tiles + 32 KiB of factor,
+// two workgroups per CU, 110 VGPRs + 128 accumulator registers; 25000x25000 k=128: 0.337 ms against 0.355 for
+// 8 waves x 32 rows, where the 8 waves read 256 KiB of factor fragments from LDS per 32 KiB of X).
 static SweepVariant sweep_variant(int NT) {
-  SweepVariant r{NT <= 2 ? 4 : 8, NT <= 2, 2, NT <= 2 ? 2 : 1};
-  if (const char* e = getenv("PRMF_SWEEP_MT")) r.mt = (atoi(e) == 2 && NT <= 2) ? 2 : 1;
+  SweepVariant r{4, NT <= 2, 2, 2};
+  if (const char* e = getenv("PRMF_SWEEP_MT")) r.mt = atoi(e) == 2 ? 2 : 1;
   if (const char* e = getenv("PRMF_SWEEP_NW")) r.nw = atoi(e) == 4 ? 4 : 8;
   if (const char* e = getenv("PRMF_SWEEP_BDB")) r.bdb = atoi(e) != 0;
+  if (r.mt == 2 && NT > 2) { r.nw = 4; r.bdb = false; }
   const int lds_kib = r.nw * 4 * r.mt + (r.bdb ? 2 : 1) * 8 * NT;
   r.wgs_per_cu = 160 / lds_kib;
   if (r.wgs_per_cu * r.nw > 16 / r.mt) r.wgs_per_cu = 16 / r.mt / r.nw;   // register-limited: 4 (MT=1) or 2 (MT=2) waves per SIMD
@@ -519,7 +521,11 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
                        const SweepSide& side) {
   const int64_t lda16 = lda * elem_bytes(x_dtype) / 16;
   const struct { int nw; bool bdb; } v{p.nw, p.bdb};
-  if (p.mt == 2 && NT <= 2) {   // experiment: 64 rows per wave (B fragments reused twice), 4 or 8 waves
+  if (p.mt == 2 && NT > 2) {    // k > 64: 4 waves x 64 rows, factor single-buffered (64 KiB of LDS per workgroup at k = 128)
+    return x_dtype == 1 ? launch_sweep_nt<true, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)
+                        : launch_sweep_nt<false, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side);
+  }
+  if (p.mt == 2 && NT <= 2) {   // 64 rows per wave (B fragments reused twice), 4 or 8 waves
     if (x_dtype == 1)
       return v.nw == 8 ? launch_sweep_nt<true, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)
                        : launch_sweep_nt<true, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side);
