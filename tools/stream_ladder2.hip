@@ -30,7 +30,26 @@ __global__ void __launch_bounds__(512) ladder(const u32x4* __restrict__ A, long 
         const int r = wave * 32 + 8 * i + (lane >> 3);
         v[i] = __builtin_nontemporal_load(A + ((long)p * 256 + r) * ld16 + (long)c * 8 + (lane & 7));
       }
-      if (MODE >= 3) { const long cbx = MODE == 11 ? (c & 3) : c; b[0] = B[cbx * 1024 + tid]; b[1] = B[cbx * 1024 + 512 + tid]; }
+      if (MODE >= 3 && MODE != 12) { const long cbx = MODE == 11 ? (c & 3) : c; b[0] = B[cbx * 1024 + tid]; b[1] = B[cbx * 1024 + 512 + tid]; }
+      if (MODE == 12) {
+        // every wave reads its 16 B fragments of the chunk straight from global memory (L1/L2): no LDS staging, no barrier
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sA[wave][i * 64 + lane] = v[i];
+        u32x4 bf[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) bf[f] = B[(long)c * 1024 + f * 64 + lane];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const u32x4 a = sA[wave][(lane & 31) * 8 + ((2 * s4 + (lane >> 5)) ^ ((lane >> 1) & 7))];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            f32x16& cc = t ? c1 : c0;
+            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bf[(s4 * 2 + t) * 2]), cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bf[(s4 * 2 + t) * 2 + 1]), cc, 0, 0, 0);
+          }
+        }
+        continue;
+      }
       if (MODE >= 2) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) sA[wave][i * 64 + lane] = v[i];
@@ -92,6 +111,7 @@ __global__ void __launch_bounds__(512) ladder(const u32x4* __restrict__ A, long 
     u += ce - cb;
   }
   if (MODE >= 4) acc += (unsigned)(c0[0] + c1[3]);
+
   if (acc == 0x12345678u) out[0] = acc;
 }
 
@@ -121,6 +141,7 @@ int main() {
         case 9: ladder<9><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
         case 10: ladder<10><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
         case 11: ladder<11><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
+        case 12: ladder<12><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
       }
       (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
       float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -130,6 +151,6 @@ int main() {
     printf("mode %d: best %.3f ms %.2f TB/s   mean %.3f ms %.2f TB/s\n", mode, best, bytes / best / 1e9, sum / 6, bytes / (sum / 6) / 1e9);
   };
   for (int rep = 0; rep < 2; ++rep)
-    for (int mode : {2, 4, 11, 10}) run(mode);
+    for (int mode : {2, 4, 12}) run(mode);
   return 0;
 }
