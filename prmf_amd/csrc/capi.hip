@@ -480,6 +480,12 @@ int prmf_set_pathway_library(prmf_ctx* c, int P, const int64_t* sup_ptr, const i
   PathwayLibDev L{};
   L.P = P;
   L.max_support = max_sup;
+  int64_t max_nnz = 0;
+  for (int pp = 0; pp < P; ++pp) {
+    const int64_t e = row_ptr[sup_ptr[pp + 1]] - row_ptr[sup_ptr[pp]];
+    if (e > max_nnz) max_nnz = e;
+  }
+  L.max_nnz = (int)max_nnz;
   L.total_support = ts;
   L.total_nnz = nnz;
   if ((rc = up(sup_ptr, (size_t)(P + 1) * 8, (void**)&L.sup_ptr))) return rc;

@@ -77,6 +77,7 @@ hipError_t launch_transpose_pad(int x_dtype, const void* src, int64_t ld_src, in
 struct PathwayLibDev {
   int P;
   int max_support;
+  int max_nnz;              // most adjacency entries of one pathway
   int64_t total_support, total_nnz;
   const int64_t* sup_ptr;   // [P+1]
   const int32_t* sup_idx;   // [total_support] gene index

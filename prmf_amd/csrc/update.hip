@@ -1206,37 +1206,118 @@ __global__ void __launch_bounds__(256) colnorm_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) out[kk] = sqrt(s);
 }
 
-__global__ void __launch_bounds__(64)
+// One workgroup per (pathway p, block of 32 latent columns).  Everything the inner loop touches is staged in LDS
+// first: the |S_p| x 32 block of V as 128-B row segments (coalesced: 32 consecutive latents of one gene) and the
+// pathway's CSR (row pointers, support-local column indices, weights) with D^-1/2 and the degrees.  Lane j of every
+// wave then owns latent kk0 + j and walks the CSR rows of its eighth of the support from LDS only (bank = latent:
+// conflict-free; CSR entries are wave-uniform broadcasts).  The first version (one wave per (p, latent), single-float
+// gathers of V and CSR loads from global memory per non-zero) took 0.15 / 0.98 ms of kernel time at (k=64, P=300) /
+// (k=128, P=1000); staging V alone left the dependent global CSR loads: 0.078 / 0.47 ms.
+struct ScoreLds {
+  float* ys;       // [ns][33]
+  double* dis;     // [ns]
+  double* deg;     // [ns]
+  double* w;       // [nnz]
+  int* rowp;       // [ns + 1]  (relative to the pathway's first entry)
+  int* col;        // [nnz]
+};
+__host__ __device__ inline size_t score_lds_bytes(int ns, int nnz) {
+  return (size_t)ns * 33 * 4 + (size_t)ns * 16 + (size_t)nnz * 8 + (size_t)(ns + 1) * 4 + (size_t)nnz * 4 + 16;
+}
+
+template <bool USE_LDS>
+__global__ void __launch_bounds__(256)
 score_kernel(PathwayLibDev lib, const float* __restrict__ V, int k, const double* __restrict__ colnorm,
              double* __restrict__ scores) {
-  const int p = blockIdx.x, kk = blockIdx.y, lane = threadIdx.x;
+  extern __shared__ double score_smem[];
+  __shared__ double red[2][4][32];
+  const int p = blockIdx.x, kk0 = blockIdx.y * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, half = lane >> 5;    // latent within the block; the two half-waves split the rows
+  const int kk = kk0 + j;
   const int64_t s0 = lib.sup_ptr[p];
   const int ns = (int)(lib.sup_ptr[p + 1] - s0);
-  const double inv = 1.0 / colnorm[kk];
-  double mass = 0.0, man = 0.0;
-  for (int s = lane; s < ns; s += 64) {
-    const double vh = (double)V[(int64_t)lib.sup_idx[s0 + s] * k + kk] * inv;
-    const double ys = vh * lib.sup_dis[s0 + s];
-    double wy = 0.0;
-    for (int64_t e = lib.row_ptr[s0 + s]; e < lib.row_ptr[s0 + s + 1]; ++e) {
-      const int cl = lib.col_local[e];
-      wy += lib.w[e] * ((double)V[(int64_t)lib.sup_idx[s0 + cl] * k + kk] * inv * lib.sup_dis[s0 + cl]);
+  const int64_t e0 = lib.row_ptr[s0];
+  const int nnz = (int)(lib.row_ptr[s0 + ns] - e0);
+  const double inv = kk < k ? 1.0 / colnorm[kk] : 0.0;
+  ScoreLds L;
+  if constexpr (USE_LDS) {
+    // doubles first (8-byte aligned), then the 4-byte arrays
+    L.dis = score_smem;
+    L.deg = L.dis + ns;
+    L.w = L.deg + ns;
+    L.ys = reinterpret_cast<float*>(L.w + nnz);
+    L.rowp = reinterpret_cast<int*>(L.ys + (size_t)ns * 33);
+    L.col = L.rowp + (ns + 1);
+    for (int e = tid; e < ns * 32; e += 256) {
+      const int s = e >> 5, jj = e & 31;
+      const int col = kk0 + jj;
+      L.ys[s * 33 + jj] = col < k ? V[(int64_t)lib.sup_idx[s0 + s] * k + col] : 0.f;
     }
-    mass += vh * vh;
-    man += ys * (lib.sup_deg[s0 + s] * ys - wy);
+    for (int s = tid; s < ns; s += 256) {
+      L.dis[s] = lib.sup_dis[s0 + s];
+      L.deg[s] = lib.sup_deg[s0 + s];
+    }
+    for (int s = tid; s <= ns; s += 256) L.rowp[s] = (int)(lib.row_ptr[s0 + s] - e0);
+    for (int e = tid; e < nnz; e += 256) {
+      L.col[e] = lib.col_local[e0 + e];
+      L.w[e] = lib.w[e0 + e];
+    }
+    __syncthreads();
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    mass += __shfl_down(mass, off);
-    man += __shfl_down(man, off);
+  double mass = 0.0, man = 0.0;
+  if (kk < k) {
+    for (int s = wave * 2 + half; s < ns; s += 8) {
+      if constexpr (USE_LDS) {
+        const double vh = (double)L.ys[s * 33 + j] * inv;
+        const double ysv = vh * L.dis[s];
+        double wy = 0.0;
+        for (int e = L.rowp[s]; e < L.rowp[s + 1]; ++e) {
+          const int cl = L.col[e];
+          wy += L.w[e] * ((double)L.ys[cl * 33 + j] * inv * L.dis[cl]);
+        }
+        mass += vh * vh;
+        man += ysv * (L.deg[s] * ysv - wy);
+      } else {
+        const double vh = (double)V[(int64_t)lib.sup_idx[s0 + s] * k + kk] * inv;
+        const double ysv = vh * lib.sup_dis[s0 + s];
+        double wy = 0.0;
+        for (int64_t e = lib.row_ptr[s0 + s]; e < lib.row_ptr[s0 + s + 1]; ++e) {
+          const int cl = lib.col_local[e];
+          wy += lib.w[e] * ((double)V[(int64_t)lib.sup_idx[s0 + cl] * k + kk] * inv * lib.sup_dis[s0 + cl]);
+        }
+        mass += vh * vh;
+        man += ysv * (lib.sup_deg[s0 + s] * ysv - wy);
+      }
+    }
   }
-  if (lane == 0) scores[(int64_t)kk * lib.P + p] = sqrt(mass) + (1.0 - man);
+  // fixed-order reduction: half-waves, then the 4 waves
+  mass += __shfl_xor(mass, 32);
+  man += __shfl_xor(man, 32);
+  if (half == 0) {
+    red[0][wave][j] = mass;
+    red[1][wave][j] = man;
+  }
+  __syncthreads();
+  if (tid < 32 && kk0 + tid < k) {
+    const double ms = ((red[0][0][tid] + red[0][1][tid]) + red[0][2][tid]) + red[0][3][tid];
+    const double mn = ((red[1][0][tid] + red[1][1][tid]) + red[1][2][tid]) + red[1][3][tid];
+    scores[(int64_t)(kk0 + tid) * lib.P + p] = sqrt(ms) + (1.0 - mn);
+  }
 }
 
 hipError_t launch_score_candidates(const PathwayLibDev& lib, const float* V, int64_t n, int k, double* colnorm_scratch,
                                    double* scores, hipStream_t s) {
   colnorm_kernel<<<k, 256, 0, s>>>(V, n, k, colnorm_scratch);
-  score_kernel<<<dim3(lib.P, k), 64, 0, s>>>(lib, V, k, colnorm_scratch, scores);
+  const dim3 grid(lib.P, (k + 31) / 32);
+  const size_t lds = score_lds_bytes(lib.max_support, lib.max_nnz);
+  if (lds <= 150 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(score_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    score_kernel<true><<<grid, 256, lds, s>>>(lib, V, k, colnorm_scratch, scores);
+  } else {
+    score_kernel<false><<<grid, 256, 0, s>>>(lib, V, k, colnorm_scratch, scores);   // pathway too large for LDS: global gathers
+  }
   return hipGetLastError();
 }
 
