@@ -236,6 +236,20 @@ int prmf_score_candidates(prmf_ctx* ctx, const float* dV, double* scores_out, vo
  */
 int prmf_cv_error(prmf_ctx* ctx, const float* dV, double* err_out, void* stream);
 
+/*
+ * Per-gene quantile normalisation, replaces `X = quantile_transform(X)` (script/prmf_runner.py:1019-1020;
+ * sklearn.preprocessing.quantile_transform with its defaults: n_quantiles = 1000, uniform output, axis 0).
+ * dX: m x n float64 row-major device buffer (leading dimension ld >= n), transformed IN PLACE.  The quantiles of
+ * every column are numpy's `linear` percentiles at linspace(0, 1, nq), nq = min(n_quantiles, rows used for the
+ * fit), made monotone, and every value is mapped with the mean of an ascending and a descending np.interp --
+ * float64, operation for operation as scikit-learn 1.7 / numpy 2.2 do it.  fit_rows (host, nullable): the row
+ * subset the quantiles are fitted on (scikit-learn subsamples rows when m > 1e5; the caller draws them with the
+ * reference's RNG), n_fit of them; NULL: all m rows.  NaNs are ignored by the fit and stay NaN.  No context
+ * needed; synchronises `stream`.
+ */
+int prmf_quantile_transform(int device, double* dX, int64_t m, int64_t n, int64_t ld, const int64_t* fit_rows,
+                            int64_t n_fit, int n_quantiles, void* stream);
+
 /* Introspection used by bench.py for the roofline block: launch geometry and
  * per-launch algorithmic bytes of the dominant kernel (the X / X^T sweep). */
 typedef struct prmf_sweep_info {

@@ -60,6 +60,7 @@ SIGNATURES = {
     "prmf_step_dist": (_i, [_vp, _vp, _vp, _i, _d, _d, _d, _vp, _vp, _vp]),
     "prmf_score_candidates": (_i, [_vp, _vp, _vp, _vp]),
     "prmf_cv_error": (_i, [_vp, _vp, _vp, _vp]),
+    "prmf_quantile_transform": (_i, [_i, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int64, _i, _vp]),
     "prmf_get_sweep_info": (_i, [_vp, C.POINTER(SweepInfo)]),
     "prmf_set_timing": (_i, [_vp, _i]),
     "prmf_get_timing": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)]),

@@ -971,6 +971,39 @@ int prmf_cv_error(prmf_ctx* c, const float* dV, double* err_out, void* stream) {
 /* debug (not in the public header): device buffer of 2*grid uint64 start/end stamps of the next sweep launches */
 extern "C" int prmf_debug_set_stamps(void* dev_buf) { prmf::g_sweep_stamps = (unsigned long long*)dev_buf; return 0; }
 
+int prmf_quantile_transform(int device, double* dX, int64_t m, int64_t n, int64_t ld, const int64_t* fit_rows,
+                            int64_t n_fit, int n_quantiles, void* stream) {
+  if (m < 0 || n < 0 || (m > 0 && n > 0 && !dX) || ld < n || n_quantiles < 1)
+    return fail(nullptr, PRMF_ERR_ARG, "prmf_quantile_transform: bad arguments");
+  if (m == 0 || n == 0) return PRMF_OK;
+  if (!fit_rows) n_fit = m;
+  if (n_fit < 1 || n_fit > m) return fail(nullptr, PRMF_ERR_ARG, "prmf_quantile_transform: n_fit=%lld outside [1, m]", (long long)n_fit);
+  if (fit_rows)
+    for (int64_t i = 0; i < n_fit; ++i)
+      if (fit_rows[i] < 0 || fit_rows[i] >= m) return fail(nullptr, PRMF_ERR_ARG, "prmf_quantile_transform: fit row outside [0, m)");
+  if (hipSetDevice(device) != hipSuccess) return fail(nullptr, PRMF_ERR_HIP, "hipSetDevice(%d) failed", device);
+  hipStream_t s = (hipStream_t)stream;
+  const int nq = (int)(n_quantiles < n_fit ? n_quantiles : n_fit);
+  // references = np.linspace(0, 1, nq): i * (1 / (nq - 1)), last element exactly 1; percentile's q = (references * 100) / 100
+  std::vector<double> host((size_t)2 * nq);
+  const double step = nq > 1 ? 1.0 / (double)(nq - 1) : 0.0;
+  for (int i = 0; i < nq; ++i) host[(size_t)i] = (double)i * step;
+  if (nq > 1) host[(size_t)nq - 1] = 1.0;
+  for (int i = 0; i < nq; ++i) host[(size_t)nq + i] = (host[(size_t)i] * 100.0) / 100.0;
+  double* dref = nullptr;
+  int64_t* drows = nullptr;
+  hipError_t e = hipMalloc((void**)&dref, host.size() * 8);
+  if (e == hipSuccess && fit_rows) e = hipMalloc((void**)&drows, (size_t)n_fit * 8);
+  if (e == hipSuccess) e = hipMemcpyAsync(dref, host.data(), host.size() * 8, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && fit_rows) e = hipMemcpyAsync(drows, fit_rows, (size_t)n_fit * 8, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = quantile_transform_device(dX, m, n, ld, drows, n_fit, dref, dref + nq, nq, s);
+  (void)hipFree(dref);
+  (void)hipFree(drows);
+  if (e != hipSuccess) return fail(nullptr, PRMF_ERR_HIP, "prmf_quantile_transform: %s", hipGetErrorString(e));
+  return PRMF_OK;
+}
+
 /* debug (not in the public header): advance the iteration cursor without running phase_post, so that partial
  * iterations can be timed (tools/sweep_context.py) */
 extern "C" int prmf_debug_bump_cursor(prmf_ctx* c) {

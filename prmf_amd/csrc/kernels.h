@@ -163,4 +163,11 @@ hipError_t launch_gram_f64(const float* V, int64_t n, int k, double* partial, do
 hipError_t launch_nnls(const double* G, const double* H, const double* xx, int64_t m, int k, int64_t n, double* err,
                        int* n_not_converged, hipStream_t s);
 
+// ---------------------------------------------------------------------------
+// prep.hip
+// ---------------------------------------------------------------------------
+// sklearn.preprocessing.quantile_transform (uniform output, axis 0) in place on a float64 row-major device matrix
+hipError_t quantile_transform_device(double* dX, int64_t m, int64_t n, int64_t ld, const int64_t* fit_rows_dev, int64_t n_fit,
+                                     const double* refs, const double* qs, int nq, hipStream_t s);
+
 }  // namespace prmf

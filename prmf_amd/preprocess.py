@@ -1,0 +1,55 @@
+"""Pre-processing of the data matrix on the GPU.
+
+`quantile_transform` is the per-gene quantile normalisation the reference's CLI applies unless --no-normalize is
+given (script/prmf_runner.py:1019-1020: sklearn.preprocessing.quantile_transform with its defaults).  The HIP
+implementation (prmf_amd/csrc/prep.hip, `prmf_quantile_transform`) reproduces scikit-learn 1.7 / numpy 2.2
+operation for operation in float64; this module only moves the matrix to the device and, for more than 1e5
+samples, draws the row subsample exactly as scikit-learn does (same global numpy RNG calls)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+SUBSAMPLE = int(1e5)          # quantile_transform's default `subsample`
+
+
+def _subsample_rows(m, random_state=None):
+    """sklearn.utils.resample(X, replace=False, n_samples=SUBSAMPLE, random_state=random_state):
+    indices = arange(m); random_state.shuffle(indices); indices[:SUBSAMPLE]."""
+    if random_state is None or random_state is np.random:
+        rs = np.random.mtrand._rand
+    elif isinstance(random_state, (int, np.integer)):
+        rs = np.random.RandomState(random_state)
+    else:
+        rs = random_state
+    idx = np.arange(m)
+    rs.shuffle(idx)
+    return np.ascontiguousarray(idx[:SUBSAMPLE], dtype=np.int64)
+
+
+def quantile_transform(X, n_quantiles=1000, random_state=None, device=0, copy=True):
+    """Drop-in for sklearn.preprocessing.quantile_transform(X) (uniform output, axis 0): numpy in, numpy out."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("prmf_amd.preprocess.quantile_transform needs a ROCm GPU; there is no CPU path here")
+    lib = _capi.load()
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim != 2:
+        raise ValueError("X must be 2-D (samples x genes)")
+    m, n = X.shape
+    if m == 0 or n == 0:
+        return X.copy() if copy else X
+    rows = _subsample_rows(m, random_state) if m > SUBSAMPLE else None
+    Xd = torch.from_numpy(np.ascontiguousarray(X)).to("cuda:%d" % device)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    rc = lib.prmf_quantile_transform(int(device), C.c_void_p(Xd.data_ptr()), m, n, n,
+                                     rows.ctypes.data_as(C.c_void_p) if rows is not None else None,
+                                     len(rows) if rows is not None else m, int(n_quantiles), stream)
+    if rc != _capi.PRMF_OK:
+        raise _capi.PrmfError(rc, lib.prmf_last_error(None).decode())
+    out = Xd.cpu().numpy()
+    if not copy:
+        X[...] = out
+        return X
+    return out

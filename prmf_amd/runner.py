@@ -147,7 +147,6 @@ def nmf_init_v(X, u):
 def main(argv=None):
     import pandas as pd
     from sklearn.model_selection import KFold
-    from sklearn.preprocessing import quantile_transform
 
     parser = argparse.ArgumentParser(description="""
 MI355X implementation of Pathway-Regularized NMF (same interface as prmf_runner.py).
@@ -243,7 +242,8 @@ Solve an optimization problem of the form
             samples = [samples[i] for i in train_index]
             break
 
-    if not args.no_normalize:                           # :1019-1020
+    if not args.no_normalize:                           # :1019-1020, on the GPU (prmf_quantile_transform)
+        from .preprocess import quantile_transform
         X = quantile_transform(X)
 
     U_init = V_init = None                              # :1022-1064
