@@ -10,7 +10,8 @@ Same flags, exit codes, stdout lines and output files as the reference CLI
     test_error.csv      with --cross-validation
 
 The solve itself is prmf_amd.solver.nmf_pathway (HIP kernels on the GPU).  Added
-flags (the reference's are unchanged): --x-dtype {f32,bf16}.
+flags (the reference's are unchanged): --x-dtype {f32,bf16}; --data also accepts a .npy matrix
+(samples x genes, no header: needs --nodelist).
 
 Reference quirks that are kept on purpose: --delta,
 --tolerence, --node-attribute and --m-samples are parsed but unused; graph nodes
@@ -184,10 +185,16 @@ Solve an optimization problem of the form
         np.random.seed(seed)
         random.seed(seed)
 
-    has_header = check_header(args.data, args.delimiter)
-    has_row_names = check_row_names(args.data, args.delimiter, has_header)
-    X = pd.read_csv(args.data, sep=args.delimiter, header='infer' if has_header else None, nrows=None,
-                    index_col=0 if has_row_names else None)
+    if args.data.endswith(".npy"):
+        # extension: a binary matrix (samples x genes, no header, no row names -> --nodelist is required), for sizes
+        # where parsing 1e9 delimited numbers would dominate the run; everything downstream is unchanged
+        has_header = has_row_names = False
+        X = pd.DataFrame(np.load(args.data, mmap_mode="r"))
+    else:
+        has_header = check_header(args.data, args.delimiter)
+        has_row_names = check_row_names(args.data, args.delimiter, has_header)
+        X = pd.read_csv(args.data, sep=args.delimiter, header='infer' if has_header else None, nrows=None,
+                        index_col=0 if has_row_names else None)
     samples = list(X.index)
 
     m, n = X.shape                                      # :946-952

@@ -197,6 +197,23 @@ def test_cli_more_variants_vs_reference(golden_dir, tmp_path, tag):
         assert "Using the following manifolds for initialization:" in stdout
 
 
+def test_cli_npy_input(golden_dir, tmp_path):
+    """--data file.npy (extension for large matrices) gives the run of the delimited file."""
+    g = np.load(os.path.join(golden_dir, "g6_nonorm.npz"))
+    c = synth.cli_case(str(tmp_path), variant=1)
+    npy = str(tmp_path / "data.npy")
+    np.save(npy, c["X"])
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    _cli(["--data", npy, "--manifolds"] + c["manifolds"] + ["--node-attribute", "name", "--nodelist", c["nodelist"],
+                                                           "--outdir", out, "--seed", "1", "--no-normalize"], str(tmp_path))
+    vals, mapping = _read_obj(os.path.join(out, "obj.txt"))
+    ref = json.loads(str(g["obj_txt"]))
+    for key in ref:
+        assert abs(vals[key] - ref[key]) <= 2e-4 * max(abs(ref[key]), 1e-3), key
+    assert mapping == json.loads(str(g["mapping"]))
+
+
 def test_cli_config1_plumbing(golden_dir, tmp_path):
     """BASELINE.json configs[0]: header-inferred nodelist, -k 4, 2 manifolds, --cross-validation 0.2
     (quantile-normalised)."""
