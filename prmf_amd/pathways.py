@@ -48,6 +48,7 @@ class PathwayLibrary(object):
             cols.append(a.indices.astype(np.int32))
             ws.append(a.data.astype(np.float64))
         cat = lambda xs, dt: (np.concatenate(xs) if len(xs) else np.zeros(0)).astype(dt)
+        self.degs = degs                                  # per pathway, reused by laplacian_quadratic
         self.sup_deg = cat(degs, np.float64)
         self.sup_ldiag = cat(ldiags, np.float64)
         self.row_ptr = cat(rows, np.int64)
@@ -122,8 +123,7 @@ class PathwayLibrary(object):
         s = self.supports[p]
         vs = np.asarray(v, dtype=np.float64)[s]
         a = self.local_adj[p]
-        deg = np.asarray(a.sum(axis=0)).ravel()
-        return float(vs.dot(deg * vs - a.dot(vs)))
+        return float(vs.dot(self.degs[p] * vs - a.dot(vs)))
 
     def arrays(self):
         return (self.sup_ptr, self.sup_idx, self.sup_deg, self.sup_ldiag, self.row_ptr, self.col_local, self.w)
