@@ -98,7 +98,6 @@ struct prmf_ctx {
   double ms_xv = 0, ms_xtu = 0, ms_total = 0;
   int timed_iters = 0;
 
-  SweepSide side{};                   // side stream for the sweeps' tail launches
   // The small kernels between the sweeps (Gram reductions, pathway terms, objective pieces, record) are not on
   // the sweeps' dependency chain: inside prmf_step / prmf_step_dist they CAN run on `aux` next to the following
   // sweep, joined where their results are first read (U epilogue: V^T V; V epilogue: U^T U + pathway terms;
@@ -330,12 +329,6 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
     fail(c, PRMF_ERR_HIP, "hipHostMalloc failed");
     return bail(PRMF_ERR_HIP);
   }
-  if (hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming) != hipSuccess) {
-    fail(c, PRMF_ERR_HIP, "side stream / events could not be created");
-    return bail(PRMF_ERR_HIP);
-  }
   if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming) != hipSuccess ||
@@ -376,9 +369,6 @@ int prmf_destroy(prmf_ctx* c) {
   if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
   if (c->ev_post) (void)hipEventDestroy(c->ev_post);
   if (c->aux) (void)hipStreamDestroy(c->aux);
-  if (c->side.fork) (void)hipEventDestroy(c->side.fork);
-  if (c->side.join) (void)hipEventDestroy(c->side.join);
-  if (c->side.stream) (void)hipStreamDestroy(c->side.stream);
   for (void* p : c->lib_allocs) dev_free(p);
   dev_free(c->active_dev);
   dev_free(c->pos);
@@ -596,7 +586,7 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
     const bool timing = (c->flags & PRMF_FLAG_TIMING) != 0;
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 0], s));
     // P = X V                                             (prmf_runner.py:420)
-    HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xv, c->X, c->ldx, c->m, c->Vp, c->NT, c->slabs, c->slab_stride_p, s, c->side));
+    HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xv, c->X, c->ldx, c->m, c->Vp, c->NT, c->slabs, c->slab_stride_p, s));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 1], s));
     // U <- U * P / (U Gv + U)                              (:421-422)
     FactorView fu{c->U, (int)c->m, c->k, c->k, 0};
@@ -650,7 +640,7 @@ int prmf_phase_q(prmf_ctx* c, void* stream) {
   if (c->m > 0) {
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 2], s));
     // Q = X^T U_new                                       (:424)
-    HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xtu, c->XT, c->ldxt, c->n, c->Up, c->NT, c->slabs, c->slab_stride_q, s, c->side));
+    HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xtu, c->XT, c->ldxt, c->n, c->Up, c->NT, c->slabs, c->slab_stride_q, s));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 3], s));
     // the replicated multi-rank mode all-reduces Q, so it needs the summed dense form even on the fused path
     if (!c->fused_v || c->replicated)
@@ -859,7 +849,7 @@ int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma,
   if (n_steps < 0) return fail(c, PRMF_ERR_ARG, "n_steps < 0");
   hipStream_t s = (hipStream_t)stream;
   const RcclApi& N = rccl();
-  const bool overlap = c->side.stream && !(getenv("PRMF_DIST_OVERLAP") && atoi(getenv("PRMF_DIST_OVERLAP")) == 0);
+  const bool overlap = c->aux && !(getenv("PRMF_DIST_OVERLAP") && atoi(getenv("PRMF_DIST_OVERLAP")) == 0);
   int done = 0, rc;
   struct Internal {
     prmf_ctx* c;

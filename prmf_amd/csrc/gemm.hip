@@ -420,22 +420,6 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus) {
     }
   }
   if (G < 1) G = 1;
-  // Optional tail launch (PRMF_SWEEP_TAIL=<percent>, default off): the last chunk pairs of every panel go
-  // to a second, small launch on a side stream, in the hope that the dispatcher starts its short workgroups
-  // as main workgroups finish (their finish times spread by +-7%).  Measured at 50000x20000: slower
-  // (X*V 0.355 -> 0.38 ms, X^T*U 0.37-0.39 -> 0.39-0.43 ms at 6-12%): the two queues do not interleave
-  // that way.  Kept as an experiment knob only.
-  int tail_pct = 0;
-  if (const char* e = getenv("PRMF_SWEEP_TAIL")) tail_pct = atoi(e);
-  p.tail_groups = 0;
-  if (tail_pct > 0 && G >= 64 && p.ngroups >= 32) {
-    p.tail_groups = (int)((int64_t)p.ngroups * tail_pct / 100);
-    if (p.tail_groups < 2) p.tail_groups = 0;
-  }
-  p.main_groups = p.ngroups - p.tail_groups;
-  p.tail_pieces = p.tail_groups > 12 ? 2 : 1;
-  p.tail_grid = p.tail_groups > 0 ? p.panels * p.tail_pieces : 0;
-
   // which slabs does every panel receive?  simulate the kernel's decomposition for one launch
   auto simulate = [&](int ngroups_sub, int nx, int64_t Gl, int seg_base, int* pmax_out, std::vector<uint32_t>* mask) -> bool {
     const int64_t Gx = Gl / nx;
@@ -465,17 +449,12 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus) {
   for (;;) {
     p.grid = (int)G;
     p.segmask.assign(p.panels, 0u);
-    bool ok = simulate(p.main_groups, p.nx, G, 0, &p.pmax, &p.segmask);
-    p.tail_seg_base = p.nx * p.pmax;
-    p.tail_pmax = 1;
-    if (ok && p.tail_grid > 0) ok = simulate(p.tail_groups, 1, p.tail_grid, p.tail_seg_base, &p.tail_pmax, &p.segmask);
-    if (ok) {
-      p.max_seg = p.tail_seg_base + (p.tail_grid > 0 ? p.tail_pmax : 0);
+    if (simulate(p.ngroups, p.nx, G, 0, &p.pmax, &p.segmask)) {
+      p.max_seg = p.nx * p.pmax;
       break;
     }
-    // too many segments per panel for the 32-bit mask: drop the tail launch, then the slices, then workgroups
-    if (p.tail_grid > 0) { p.tail_grid = 0; p.tail_groups = 0; p.main_groups = p.ngroups; }
-    else if (p.nx > 1) p.nx = 1;
+    // too many segments per panel for the 32-bit mask: drop the slices, then workgroups
+    if (p.nx > 1) p.nx = 1;
     else G = G > 16 ? G / 2 : 1;
   }
   return p;
@@ -485,21 +464,11 @@ unsigned long long* g_sweep_stamps = nullptr;   // debug: per-workgroup start/en
 
 template <bool BF16, int NW, bool BDB, int MTV>
 static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda16, int64_t M_store, const void* Bp,
-                                  int NT, float* slabs, int64_t slab_stride, hipStream_t s, const SweepSide& side) {
-  const bool tail = p.tail_grid > 0 && side.stream;
-  if (tail) {
-    hipError_t e = hipEventRecord(side.fork, s);
-    if (e == hipSuccess) e = hipStreamWaitEvent(side.stream, side.fork, 0);
-    if (e != hipSuccess) return e;
-  }
-#define PRMF_LAUNCH(NTV)                                                                                              \
-  sweep_kernel<BF16, MTV, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), 0, s>>>(                                         \
-      (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, 0, tail ? p.main_groups : p.ngroups, p.nx, p.pmax, \
-      0, slabs, slab_stride, g_sweep_stamps);                                                                         \
-  if (tail)                                                                                                           \
-    sweep_kernel<BF16, MTV, NTV, NW, BDB><<<dim3(p.tail_grid), dim3(64 * NW), 0, side.stream>>>(                        \
-        (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, p.main_groups, p.tail_groups, 1, p.tail_pmax,    \
-        p.tail_seg_base, slabs, slab_stride, nullptr)
+                                  int NT, float* slabs, int64_t slab_stride, hipStream_t s) {
+#define PRMF_LAUNCH(NTV)                                                                                       \
+  sweep_kernel<BF16, MTV, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), 0, s>>>(                                  \
+      (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, 0, p.ngroups, p.nx, p.pmax, 0, slabs, slab_stride, \
+      g_sweep_stamps)
   switch (NT) {
     case 1: PRMF_LAUNCH(1); break;
     case 2: PRMF_LAUNCH(2); break;
@@ -508,35 +477,29 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
     default: return hipErrorInvalidValue;
   }
 #undef PRMF_LAUNCH
-  hipError_t e = hipGetLastError();
-  if (tail && e == hipSuccess) {
-    e = hipEventRecord(side.join, side.stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(s, side.join, 0);
-  }
-  return e;
+  return hipGetLastError();
 }
 
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
-                       const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s,
-                       const SweepSide& side) {
+                       const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s) {
   const int64_t lda16 = lda * elem_bytes(x_dtype) / 16;
   const struct { int nw; bool bdb; } v{p.nw, p.bdb};
   if (p.mt == 2 && NT > 2) {    // k > 64: 4 waves x 64 rows, factor single-buffered (64 KiB of LDS per workgroup at k = 128)
-    return x_dtype == 1 ? launch_sweep_nt<true, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)
-                        : launch_sweep_nt<false, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side);
+    return x_dtype == 1 ? launch_sweep_nt<true, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)
+                        : launch_sweep_nt<false, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
   }
   if (p.mt == 2 && NT <= 2) {   // 64 rows per wave (B fragments reused twice), 4 or 8 waves
     if (x_dtype == 1)
-      return v.nw == 8 ? launch_sweep_nt<true, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)
-                       : launch_sweep_nt<true, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side);
-    return v.nw == 8 ? launch_sweep_nt<false, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)
-                     : launch_sweep_nt<false, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side);
+      return v.nw == 8 ? launch_sweep_nt<true, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)
+                       : launch_sweep_nt<true, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
+    return v.nw == 8 ? launch_sweep_nt<false, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)
+                     : launch_sweep_nt<false, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
   }
 #define PRMF_DISPATCH(BF)                                                                                                    \
-  (v.nw == 8 ? (v.bdb ? launch_sweep_nt<BF, 8, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)      \
-                      : launch_sweep_nt<BF, 8, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side))    \
-              : (v.bdb ? launch_sweep_nt<BF, 4, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)     \
-                      : launch_sweep_nt<BF, 4, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, side)))
+  (v.nw == 8 ? (v.bdb ? launch_sweep_nt<BF, 8, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)      \
+                      : launch_sweep_nt<BF, 8, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s))    \
+              : (v.bdb ? launch_sweep_nt<BF, 4, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)     \
+                      : launch_sweep_nt<BF, 4, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)))
   return x_dtype == 1 ? PRMF_DISPATCH(true) : PRMF_DISPATCH(false);
 #undef PRMF_DISPATCH
 }

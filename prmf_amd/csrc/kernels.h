@@ -53,19 +53,11 @@ struct GemmPlan {
   int pmax = 1;             // most workgroups that touch one (panel, slice)
   int max_seg = 1;          // slabs allocated: nx * pmax
   std::vector<uint32_t> segmask;   // [panels] bit s set <=> slab s holds a segment of this panel
-  // tail launch (side stream): the last tail_groups chunk pairs of every panel
-  int main_groups = 0, tail_groups = 0, tail_pieces = 1, tail_grid = 0, tail_pmax = 1, tail_seg_base = 0;
-};
-// side stream + fork/join events used to run the tail launch next to the main launch (all null: no tail)
-struct SweepSide {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
 };
 GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus);
 extern unsigned long long* g_sweep_stamps;   // debug only
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
-                       const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s,
-                       const SweepSide& side);
+                       const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s);
 hipError_t launch_copy_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols,
                            void* dst, int64_t ld_dst, hipStream_t s);
 hipError_t launch_transpose_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols,
