@@ -400,10 +400,9 @@ int prmf_set_x(prmf_ctx* c, const void* dX, int64_t ld, double norm_x_sq, void* 
   hipStream_t s = (hipStream_t)stream;
   const int eb = elem_bytes(c->x_dtype);
   const int64_t rows_x = round_up(c->m > 0 ? c->m : 1, M_PAD), rows_xt = round_up(c->n, M_PAD);
-  // row stride = padded reduction length (+ optional extra padding, elements; experiment knob)
-  const int64_t ld_pad = getenv("PRMF_LD_PAD") ? atoll(getenv("PRMF_LD_PAD")) : 0;
-  c->ldx = c->Kpad_x + ld_pad;
-  c->ldxt = c->Kpad_xt + ld_pad;
+  // row stride = padded reduction length (extra padding of the stride was measured: no effect)
+  c->ldx = c->Kpad_x;
+  c->ldxt = c->Kpad_xt;
   if (!c->X) {
     c->x_bytes = (size_t)(rows_x * c->ldx * eb);
     c->xt_bytes = (size_t)(rows_xt * c->ldxt * eb);
