@@ -138,7 +138,10 @@ struct RcclApi {
 RcclApi& rccl() {
   static RcclApi api = [] {
     RcclApi a;
-    a.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // PRMF_RCCL_LIB: another library with the same seven entry points (tests/native/mock_rccl.cpp runs the
+    // multi-rank step with two ranks on one GPU, which RCCL itself refuses)
+    if (const char* e = getenv("PRMF_RCCL_LIB")) a.handle = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+    if (!a.handle) a.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!a.handle) a.handle = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!a.handle) return a;
 #define PRMF_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.handle, name))

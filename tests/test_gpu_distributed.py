@@ -21,6 +21,32 @@ def _free_port():
     return p
 
 
+def _collect(procs, q, deadline_s=300):
+    """Results of the worker processes, drained BEFORE joining (they are larger than a pipe buffer); a worker that
+    dies or a run that exceeds the deadline fails the test instead of blocking it."""
+    import time
+    res = {}
+    t0 = time.time()
+    while len(res) < len(procs):
+        if not q.empty():
+            item = q.get()
+            res[item[0]] = item[1:]
+            continue
+        dead = [p for p in procs if p.exitcode not in (None, 0)]
+        if dead or time.time() - t0 > deadline_s:
+            for p in procs:
+                if p.is_alive():
+                    p.kill()
+            raise AssertionError("worker failed (exit codes %s) or timed out" % [p.exitcode for p in procs])
+        time.sleep(0.05)
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    return res
+
+
 def _worker(rank, world, port, k, x_dtype, mode, q):
     import torch
     import torch.distributed as dist
@@ -61,13 +87,7 @@ def test_two_ranks_match_single_rank(k, x_dtype, mode):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, k, x_dtype, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = {}
-    for _ in procs:
-        r, U, V, objs = q.get()
-        res[r] = (U, V, objs)
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+    res = _collect(procs, q)
     assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]      # replicated state agrees bitwise
     U = np.concatenate([res[0][0], res[1][0]])
     case = synth.small_case(seed=13, m=700, n=1500, k=k, P=6, order=80, bf16_x=(x_dtype == "bf16"))
@@ -108,3 +128,68 @@ def test_in_library_rccl_step_single_rank():
         res.append((U.cpu().numpy(), V.cpu().numpy(), objs))
         eng.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+
+
+def _native_worker(rank, world, port, k, mode, mock, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PRMF_RCCL_LIB"] = mock
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from prmf_amd import PathwayLibrary
+        from prmf_amd.distributed import DistributedPrmf
+        from prmf_amd.solver import PrmfEngine
+        from prmf_amd.synthetic import shard_rows
+        case = synth.small_case(seed=13, m=700, n=1500, k=k, P=6, order=80, bf16_x=True)
+        X = case["X"]
+        lo, hi = shard_rows(X.shape[0], world, rank)
+        eng = PrmfEngine(hi - lo, X.shape[1], k, x_dtype="bf16", device=0, nranks=world, rank=rank, dist_mode=mode)
+        eng.set_x(X[lo:hi], norm_x_sq=float(np.sum(X * X)))
+        eng.set_library(PathwayLibrary.from_edge_lists(X.shape[1], case["pathways"]))
+        eng.set_active(np.arange(k) % 6)
+        U = eng.device_tensor(case["U0"][lo:hi], torch.float32)
+        V = eng.device_tensor(case["V0"], torch.float32)
+        runner = DistributedPrmf(eng, native=True)
+        assert runner.native                                   # the in-library step, collectives through the mock
+        objs, gd = runner.step(U, V, 6, case["gamma"], case["delta"])
+        q.put((rank, U.cpu().numpy(), V.cpu().numpy(), objs))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,mode", [(64, "replicated"), (13, "replicated"), (16, "colshard")])
+def test_in_library_step_two_ranks_through_mock_rccl(k, mode, tmp_path):
+    """prmf_step_dist with TWO ranks: the collectives go through tests/native/mock_rccl.cpp (shared memory between
+    the two processes, same entry points and call order as RCCL), so the library's own sequencing -- buffers, counts,
+    the auxiliary stream of the Gram all-reduce, the in-place all-reduce of Q -- is checked against the oracle."""
+    import subprocess
+    import torch.multiprocessing as mp
+    from oracle import prmf_oracle as orc
+    mock = str(tmp_path / "libmock_rccl.so")
+    cc = subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                         os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "mock_rccl.cpp"), "-o", mock,
+                         "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_native_worker, args=(r, 2, port, k, mode, mock, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = _collect(procs, q)
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+    U = np.concatenate([res[0][0], res[1][0]])
+    case = synth.small_case(seed=13, m=700, n=1500, k=k, P=6, order=80, bf16_x=True)
+    pws = [orc.pathway_from_edges(1500, e, nodes, w) for (e, w, nodes) in case["pathways"]]
+    tr = []
+    Ur, Vr, od = orc.nmf_manifold_vec_update(case["X"], case["U0"], case["V0"], [pws[i % 6] for i in range(k)],
+                                             n_steps=6, gamma=case["gamma"], delta=case["delta"], trace=tr)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert rel(U, Ur) < 1e-4 and rel(res[0][1], Vr) < 1e-4
+    for a, b in zip(res[0][2], tr):
+        for key in ("recon", "manifold", "ignore", "fro", "obj"):
+            assert abs(a[key] - b[key]) <= 1e-4 * max(abs(b[key]), 1e-12), key
+
