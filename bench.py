@@ -123,7 +123,8 @@ def main():
 
     if world > 1:
         from prmf_amd.distributed import DistributedPrmf
-        runner = DistributedPrmf(eng)
+        # rehearsal with the RCCL test double (PRMF_RCCL_LIB): force the in-library step although the backend is gloo
+        runner = DistributedPrmf(eng, native=True if os.environ.get("PRMF_RCCL_LIB") else None)
         step = lambda s: runner.step(U, V, s, gamma, delta)
     else:
         step = lambda s: eng.step(U, V, s, gamma, delta)
