@@ -79,7 +79,8 @@ struct prmf_ctx {
   double* vpartial = nullptr;         // [v_update_blocks][kc+1]
   int vblocks = 0;
   bool fused_u = false, fused_v = false, gram_v_done = false;
-  bool graph_done = false;            // the pathway terms of this iteration were already computed in phase_u (merged launch)   // MFMA epilogues (k % 4 == 0; V path single-rank only)
+  // fused_u / fused_v: MFMA epilogues (k % 4 == 0; the V one when there is one column block: single rank or replicated mode)
+  bool graph_done = false;            // the pathway terms of this iteration were already computed in phase_u (merged launch)
 
   // hyper-parameters + records
   double* hyper = nullptr;            // device: gamma, delta, tradeoff
