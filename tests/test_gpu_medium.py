@@ -77,18 +77,20 @@ def test_xcd_sliced_decomposition_matches_unsliced(xcd, monkeypatch):
         assert abs(x["obj"] - y["obj"]) <= 1e-5 * abs(y["obj"])
 
 
-def test_full_size_c3_properties():
-    """BASELINE.json's headline size (50000 x 20000, k = 64, 300 pathways, bf16 X): size-independent
+@pytest.mark.parametrize("workload,x_dtype", [("c3", "bf16"), ("c3", "f32"), ("c5shard", "bf16")])
+def test_full_size_c3_properties(workload, x_dtype):
+    """BASELINE.json's headline size (50000 x 20000, k = 64, 300 pathways, bf16 X; also with f32 X) and one rank's
+    share of the 8-GPU configuration (25000 x 25000, k = 128, 1000 pathways): size-independent
     properties instead of an oracle run -- the Gram-identity reconstruction error equals the directly
     computed ||X - U V^T||_F, fro = sum U^2, V >= eps, finite, and two runs are bit-identical."""
     import math
     import torch
     from prmf_amd import PathwayLibrary, synthetic as syn
     from prmf_amd.solver import PrmfEngine
-    m, n, k, P = syn.CONFIGS["c3"][:4]
+    m, n, k, P = syn.CONFIGS[workload][:4]
     dev = "cuda:0"
-    Xd = syn.x_rows_torch(torch, dev, 3, n, k, 0, m, torch.bfloat16)
-    eng = PrmfEngine(m, n, k, x_dtype="bf16")
+    Xd = syn.x_rows_torch(torch, dev, 3, n, k, 0, m, torch.bfloat16 if x_dtype == "bf16" else torch.float32)
+    eng = PrmfEngine(m, n, k, x_dtype=x_dtype)
     nsq = eng.set_x(Xd)
     eng.set_library(PathwayLibrary.from_edge_lists(n, syn.tree_pathways(n, P, 300, 3)))
     eng.set_active([kk % P for kk in range(k)])
