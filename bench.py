@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+F32_MFMA_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak (same guide)
 
 
 def parse():
@@ -159,6 +160,12 @@ def main():
     bytes_launch = 0.5 * ((ml * n * eb + n * k * 4 + ml * k * 4) + (ml * n * eb + ml * k * 4 + n * k * 4))
     avg_ms = 0.5 * (ms_xv + ms_xtu)
     achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
+    # f32 X runs on the f32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense = 1/16 of the bf16 rate): that pipe, not
+    # HBM, bounds the sweep there; the bf16 sweep is HBM-bound (its MFMA pipe is 30% busy)
+    flops_launch = 2.0 * ml * n * k
+    tflops = flops_launch / (avg_ms * 1e-3) / 1e12
+    # which roof is lower for this shape: flop per byte against the machine balance of the pipe that runs it
+    mfma_bound = x_dtype != "bf16" and flops_launch / bytes_launch > F32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
 
     out = None
     if rank == 0:
@@ -179,13 +186,16 @@ def main():
                                        "X row-sharded x%d, V update %s, RCCL %s" % (
                                            world, eng.dist_mode, "in-library" if runner.native else "host-driven"))},
             "recon_err": objs[-1]["recon"], "objective": objs[-1]["obj"],
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "sweep_kernel (X*V and X^T*U, 2 launches/iteration)",
-                         "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": avg_ms,
-                         "ms_xv": ms_xv, "ms_xtu": ms_xtu,
-                         "sweep_share_of_step": 2 * avg_ms / (1e3 * elapsed / args.steps)},
+            "roofline": ({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": achieved / HBM_PEAK_GBS, "tflops": tflops} if not mfma_bound else
+                         {"bound": "mfma", "achieved": tflops, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": tflops / F32_MFMA_PEAK_TFLOPS, "hbm_gbs": achieved}),
         }
+        out["roofline"].update({"traffic": traffic,
+                                "kernel": "sweep_kernel (X*V and X^T*U, 2 launches/iteration)",
+                                "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_flops_per_launch": flops_launch,
+                                "avg_launch_ms": avg_ms, "ms_xv": ms_xv, "ms_xtu": ms_xtu,
+                                "sweep_share_of_step": 2 * avg_ms / (1e3 * elapsed / args.steps)})
         if backend != "nccl":
             out["config"]["rehearsal"] = "ranks share one GPU, exchanges staged through the host (%s): not a measurement" % backend
         if world == 1 and not args.no_cpu_baseline:
