@@ -160,12 +160,13 @@ def main():
     bytes_launch = 0.5 * ((ml * n * eb + n * k * 4 + ml * k * 4) + (ml * n * eb + ml * k * 4 + n * k * 4))
     avg_ms = 0.5 * (ms_xv + ms_xtu)
     achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
-    # f32 X runs on the f32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense = 1/16 of the bf16 rate): that pipe, not
-    # HBM, bounds the sweep there; the bf16 sweep is HBM-bound (its MFMA pipe is 30% busy)
+    # f32 X at k > 64 runs on the f32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense = 1/16 of the bf16 rate): that
+    # pipe, not HBM, bounds the sweep there; bf16 X, and f32 X at k <= 64 (split into bf16 pieces), are HBM-bound
     flops_launch = 2.0 * ml * n * k
     tflops = flops_launch / (avg_ms * 1e-3) / 1e12
     # which roof is lower for this shape: flop per byte against the machine balance of the pipe that runs it
-    mfma_bound = x_dtype != "bf16" and flops_launch / bytes_launch > F32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    mfma_bound = (x_dtype != "bf16" and not eng.sweep_info().f32_split and
+                  flops_launch / bytes_launch > F32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9))
 
     out = None
     if rank == 0:

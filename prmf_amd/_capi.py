@@ -32,7 +32,7 @@ class CommSizes(C.Structure):
 class SweepInfo(C.Structure):
     _fields_ = [("bytes_x_sweep", C.c_int64), ("bytes_xt_sweep", C.c_int64),
                 ("splits_xv", C.c_int32), ("splits_xtu", C.c_int32),
-                ("grid_xv", C.c_int32), ("grid_xtu", C.c_int32)]
+                ("grid_xv", C.c_int32), ("grid_xtu", C.c_int32), ("f32_split", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol include/prmf_hip.h declares: name -> (restype, argtypes)

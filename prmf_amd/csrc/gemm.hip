@@ -123,11 +123,73 @@ hipError_t launch_pack_factor(const FactorView& f, int x_dtype, int NT, int64_t 
 // of the 256-B bank row (rows of equal parity in a group differ in (r>>1)&7).
 // No barrier is needed for A: a wave only reads what it wrote, and the LDS
 // executes one wave's instructions in order.
-template <bool BF16, int MT, int NT>
-__device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], const u32x4* __restrict__ sa,
-                                              const u32x4* __restrict__ sb, int lane) {
+// f32 -> three bf16 pieces by truncation: x = h + m + l exactly (8 + 8 + 8 mantissa bits)
+__device__ __forceinline__ void split3(unsigned xb, unsigned& hb, unsigned& mb, unsigned& lb) {
+  hb = xb & 0xFFFF0000u;
+  const float r1 = __uint_as_float(xb) - __uint_as_float(hb);
+  mb = __float_as_uint(r1) & 0xFFFF0000u;
+  const float r2 = r1 - __uint_as_float(mb);
+  lb = __float_as_uint(r2) & 0xFFFF0000u;
+}
+// 8 floats (two 16-B pieces) -> bf16x8 fragments of the high, middle and low pieces
+__device__ __forceinline__ void split_fragment(const u32x4& f0, const u32x4& f1, u32x4& fh, u32x4& fm, u32x4& fl) {
+  unsigned x[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3(x[2 * j], h0, m0, l0);
+    split3(x[2 * j + 1], h1, m1, l1);
+    fh[j] = (h0 >> 16) | h1;
+    fm[j] = (m0 >> 16) | m1;
+    fl[j] = (l0 >> 16) | l1;
+  }
+}
+
+// MODE 0: A f32, B f32 fragments, f32 MFMA | MODE 1: A bf16, B hi/lo bf16 | MODE 2: A f32 split into three bf16
+// pieces in registers, B hi/lo bf16 (5 bf16 MFMAs per fragment instead of 8 f32 MFMAs at 1/16 of the rate)
+// acc_lo (MODE 2 only): the cross terms (<= 2^-8 of the main products) are summed in their own accumulators -- added
+// into the main ones they fall below half an ulp of a long running sum and are always rounded DOWN (a -4.8e-6 bias of
+// X V at 50000 x 20000: exactly the mean of the lowest piece of X)
+template <int MODE, int MT, int NT>
+__device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&acc_lo)[MODE == 2 ? MT : 1][MODE == 2 ? NT : 1],
+                                              const u32x4* __restrict__ sa, const u32x4* __restrict__ sb, int lane) {
+  constexpr bool BF16 = MODE == 1;
   const int r = lane & 31, h = lane >> 5;
   const int swz = (r >> 1) & 7;
+  if constexpr (MODE == 2) {
+    // not unrolled over the two k-blocks: the three-piece split is register-hungry and the kernel must stay within
+    // 128 VGPRs next to its 2 x 64 accumulator registers (two waves per SIMD)
+#pragma unroll 1
+    for (int kb = 0; kb < 2; ++kb) {
+      u32x4 bh[NT], bl[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        bh[t] = sb[((kb * NT + t) * 2 + 0) * 64 + lane];
+        bl[t] = sb[((kb * NT + t) * 2 + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        u32x4 ah, am, al;
+        {
+          const u32x4 f0 = sa[mt * 256 + r * 8 + ((4 * kb + 2 * h) ^ swz)];
+          const u32x4 f1 = sa[mt * 256 + r * 8 + ((4 * kb + 2 * h + 1) ^ swz)];
+          split_fragment(f0, f1, ah, am, al);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          auto mm = [&](f32x16& d, const u32x4& a, const u32x4& b) {
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), d, 0, 0, 0);
+          };
+          mm(acc_lo[mt][t], al, bh[t]);      // smallest terms first
+          mm(acc_lo[mt][t], am, bl[t]);
+          mm(acc_lo[mt][t], ah, bl[t]);
+          mm(acc_lo[mt][t], am, bh[t]);
+          mm(acc[mt][t], ah, bh[t]);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int s4 = 0; s4 < 4; ++s4) {
     u32x4 av[MT];
@@ -225,15 +287,15 @@ __device__ __forceinline__ void store_b_chunk(u32x4* sb, const u32x4 (&src)[NB],
 //              workgroup -> more resident workgroups (bytes in flight) per CU
 // The host pads the reduction to an even number of chunks and gives every split an
 // even number, so the chunk loop is unrolled x2 with compile-time LDS buffer offsets.
-template <bool BF16, int MT, int NT, int NW, bool BDB>
-__global__ void __launch_bounds__(64 * NW)
+template <int MODE, int MT, int NT, int NW, bool BDB>
+__global__ void __launch_bounds__(64 * NW, (MODE == 2 && NT == 2 && NW == 4) ? 2 : 1)
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
              const uint4* __restrict__ Bp, int npanels, int g_begin, int ngroups /* chunk pairs [g_begin, g_begin+ngroups) of every row */,
              int nx, int pmax, int seg_base, float* __restrict__ slabs, int64_t slab_stride,
              unsigned long long* __restrict__ stamps /* debug, may be null */) {
   if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x] = wall_clock64();
   constexpr int NTHR = 64 * NW;
-  constexpr int BCH = BF16 ? 512 * NT : 256 * NT;   // uint4 per packed chunk
+  constexpr int BCH = MODE == 1 ? 512 * NT : 256 * NT;   // uint4 per packed chunk (64 bf16 or 32 f32 elements of the reduction)
   constexpr int BPT = (BCH + NTHR - 1) / NTHR;      // uint4 staged per thread per chunk (last one may be partial)
   __shared__ u32x4 sB[BDB ? 2 : 1][BCH];
   __shared__ u32x4 sA[NW][MT * 256];                // per wave: MT tiles of 32 rows x 128 B
@@ -290,12 +352,16 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   const uint4* bbase = Bp + (int64_t)c0 * BCH;
 
   f32x16 acc[MT][NT];
+  f32x16 acc_lo[MODE == 2 ? MT : 1][MODE == 2 ? NT : 1];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mt][t][i] = 0.f;
+      for (int i = 0; i < 16; ++i) {
+        acc[mt][t][i] = 0.f;
+        if constexpr (MODE == 2) acc_lo[mt][t][i] = 0.f;
+      }
 
   u32x4 a[MT][4];
   u32x4 bs[BPT];
@@ -314,14 +380,14 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int cn = min(c + u + 1, last);
-      if constexpr (LOADS_FIRST) {
+      if constexpr (LOADS_FIRST && MODE != 2) {
         // the next chunk's loads are in flight while this chunk is computed from LDS
         load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
         load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
         __builtin_amdgcn_sched_barrier(0);
       }
-      sweep_compute<BF16, MT, NT>(acc, myA, sB[BDB ? u : 0], lane);
-      if constexpr (!LOADS_FIRST) {
+      sweep_compute<MODE, MT, NT>(acc, acc_lo, myA, sB[BDB ? u : 0], lane);
+      if constexpr (!(LOADS_FIRST && MODE != 2)) {
         load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
         load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
       } else {
@@ -351,7 +417,11 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
-        const f32x4 v = {acc[mt][t][4 * q4], acc[mt][t][4 * q4 + 1], acc[mt][t][4 * q4 + 2], acc[mt][t][4 * q4 + 3]};
+        f32x4 v = {acc[mt][t][4 * q4], acc[mt][t][4 * q4 + 1], acc[mt][t][4 * q4 + 2], acc[mt][t][4 * q4 + 3]};
+        if constexpr (MODE == 2) {
+          const f32x4 w = {acc_lo[mt][t][4 * q4], acc_lo[mt][t][4 * q4 + 1], acc_lo[mt][t][4 * q4 + 2], acc_lo[mt][t][4 * q4 + 3]};
+          v += w;
+        }
         f32x4* dst = out + ((tile * NT + t) * 4 + q4) * 64 + lane;
         if constexpr (SLAB_NT) __builtin_nontemporal_store(v, dst);
         else *dst = v;
@@ -462,11 +532,11 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus) {
 
 unsigned long long* g_sweep_stamps = nullptr;   // debug: per-workgroup start/end stamps (tools/wg_spread.py)
 
-template <bool BF16, int NW, bool BDB, int MTV>
+template <int MODE, int NW, bool BDB, int MTV>
 static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda16, int64_t M_store, const void* Bp,
                                   int NT, float* slabs, int64_t slab_stride, hipStream_t s) {
 #define PRMF_LAUNCH(NTV)                                                                                       \
-  sweep_kernel<BF16, MTV, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), 0, s>>>(                                  \
+  sweep_kernel<MODE, MTV, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), 0, s>>>(                                  \
       (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, 0, p.ngroups, p.nx, p.pmax, 0, slabs, slab_stride, \
       g_sweep_stamps)
   switch (NT) {
@@ -481,26 +551,40 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
 }
 
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
-                       const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s) {
+                       const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s, bool split) {
   const int64_t lda16 = lda * elem_bytes(x_dtype) / 16;
-  const struct { int nw; bool bdb; } v{p.nw, p.bdb};
-  if (p.mt == 2 && NT > 2) {    // k > 64: 4 waves x 64 rows, factor single-buffered (64 KiB of LDS per workgroup at k = 128)
-    return x_dtype == 1 ? launch_sweep_nt<true, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)
-                        : launch_sweep_nt<false, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
+  const int mode = x_dtype == 1 ? 1 : (split ? 2 : 0);
+  // default shape: 4 waves x 64 rows; factor double-buffered at k <= 64
+  if (p.mt == 2 && p.nw == 4 && p.bdb == (NT <= 2)) {
+#define PRMF_GO(MODEV, BDBV) return launch_sweep_nt<MODEV, 4, BDBV, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)
+    if (NT <= 2) {
+      if (mode == 1) PRMF_GO(1, true);
+      if (mode == 2) PRMF_GO(2, true);
+      PRMF_GO(0, true);
+    }
+    if (mode == 1) PRMF_GO(1, false);
+    if (mode == 2) PRMF_GO(2, false);
+    PRMF_GO(0, false);
+#undef PRMF_GO
   }
-  if (p.mt == 2 && NT <= 2) {   // 64 rows per wave (B fragments reused twice), 4 or 8 waves
-    if (x_dtype == 1)
-      return v.nw == 8 ? launch_sweep_nt<true, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)
-                       : launch_sweep_nt<true, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
-    return v.nw == 8 ? launch_sweep_nt<false, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)
-                     : launch_sweep_nt<false, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
+  if (mode == 2) return hipErrorInvalidValue;      // the split form exists for the default shape only
+  // other shapes (tests, experiments): PRMF_SWEEP_NW / _MT / _BDB
+  if (p.mt == 2 && NT > 2)
+    return mode == 1 ? launch_sweep_nt<1, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)
+                     : launch_sweep_nt<0, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
+  if (p.mt == 2) {
+    if (mode == 1)
+      return p.nw == 8 ? launch_sweep_nt<1, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)
+                       : launch_sweep_nt<1, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
+    return p.nw == 8 ? launch_sweep_nt<0, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)
+                     : launch_sweep_nt<0, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
   }
-#define PRMF_DISPATCH(BF)                                                                                                    \
-  (v.nw == 8 ? (v.bdb ? launch_sweep_nt<BF, 8, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)      \
-                      : launch_sweep_nt<BF, 8, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s))    \
-              : (v.bdb ? launch_sweep_nt<BF, 4, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)     \
-                      : launch_sweep_nt<BF, 4, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)))
-  return x_dtype == 1 ? PRMF_DISPATCH(true) : PRMF_DISPATCH(false);
+#define PRMF_DISPATCH(MD)                                                                                               \
+  (p.nw == 8 ? (p.bdb ? launch_sweep_nt<MD, 8, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)      \
+                      : launch_sweep_nt<MD, 8, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s))    \
+             : (p.bdb ? launch_sweep_nt<MD, 4, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)      \
+                      : launch_sweep_nt<MD, 4, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)))
+  return mode == 1 ? PRMF_DISPATCH(1) : PRMF_DISPATCH(0);
 #undef PRMF_DISPATCH
 }
 

@@ -57,7 +57,8 @@ struct GemmPlan {
 GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus);
 extern unsigned long long* g_sweep_stamps;   // debug only
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
-                       const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s);
+                       const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s,
+                       bool split = false /* f32 X as three bf16 pieces, packedB in the bf16 hi/lo layout */);
 hipError_t launch_copy_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols,
                            void* dst, int64_t ld_dst, hipStream_t s);
 hipError_t launch_transpose_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols,

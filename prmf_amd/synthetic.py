@@ -7,7 +7,7 @@ CONFIGS = {
     # name: (m, n, k, P, x_dtype)   -- BASELINE.json configs[1..4]
     "c2": (5000, 10000, 16, 50, "f32"),
     "c3": (50000, 20000, 64, 300, "bf16"),
-    "c3f32": (50000, 20000, 64, 300, "f32"),      # the CLI default storage of X (exact f32 products)
+    "c3f32": (50000, 20000, 64, 300, "f32"),      # the CLI default storage of X
     "c5": (200000, 25000, 128, 1000, "bf16"),
     "c5shard": (25000, 25000, 128, 1000, "bf16"),     # one rank's share of c5 on 8 GPUs
 }

@@ -61,6 +61,7 @@ def test_tiny_and_ragged_shapes(m, n, k, P, order, x_dtype):
     {"PRMF_SWEEP_NW": "4", "PRMF_SWEEP_MT": "2", "PRMF_SWEEP_BDB": "0"},
     {"PRMF_NO_FUSED_EPILOGUE": "1"},
     {"PRMF_OVERLAP_SMALL": "1"},          # small kernels on the auxiliary stream next to the sweeps
+    {"PRMF_F32_SPLIT": "0"},              # f32 X on the f32 MFMA instead of the three-piece bf16 split
 ])
 @pytest.mark.parametrize("k,x_dtype", [(16, "f32"), (64, "bf16")])
 def test_sweep_variants(env, k, x_dtype, monkeypatch):
