@@ -103,6 +103,8 @@ def load(path=None):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    lib.prmf_debug_slab_sum.restype = _i           # validation hook, not part of the public header
+    lib.prmf_debug_slab_sum.argtypes = [_vp, _i, _vp, _vp]
     if lib.prmf_abi_version() != PRMF_ABI_VERSION:
         raise PrmfLibraryError("ABI version mismatch: library %d, binding %d" %
                                (lib.prmf_abi_version(), PRMF_ABI_VERSION))

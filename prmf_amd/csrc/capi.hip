@@ -73,7 +73,6 @@ struct prmf_ctx {
   std::vector<void*> lib_allocs;
   bool have_lib = false, have_active = false;
   int32_t* active_dev = nullptr;
-  int32_t* active_host_pinned = nullptr;
   int32_t* pos = nullptr;
   float *gnum = nullptr, *gden = nullptr;
   double* obj_scratch = nullptr;      // [kc][max_support]
@@ -337,8 +336,7 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, &c->records, (size_t)MAX_RECORDS * PRMF_OBJ_STRIDE))) return bail(rc);
   if ((rc = dev_alloc(c, &c->colnorm, (size_t)k))) return bail(rc);
   if (hipHostMalloc((void**)&c->hyper_host, 4 * sizeof(double)) != hipSuccess ||
-      hipHostMalloc((void**)&c->records_host, (size_t)MAX_RECORDS * PRMF_OBJ_STRIDE * sizeof(double)) != hipSuccess ||
-      hipHostMalloc((void**)&c->active_host_pinned, (size_t)k * sizeof(int32_t)) != hipSuccess) {
+      hipHostMalloc((void**)&c->records_host, (size_t)MAX_RECORDS * PRMF_OBJ_STRIDE * sizeof(double)) != hipSuccess) {
     fail(c, PRMF_ERR_HIP, "hipHostMalloc failed");
     return bail(PRMF_ERR_HIP);
   }
@@ -396,7 +394,6 @@ int prmf_destroy(prmf_ctx* c) {
   dev_free(c->scores_dev);
   if (c->hyper_host) (void)hipHostFree(c->hyper_host);
   if (c->records_host) (void)hipHostFree(c->records_host);
-  if (c->active_host_pinned) (void)hipHostFree(c->active_host_pinned);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   delete c;
@@ -513,9 +510,8 @@ int prmf_set_active(prmf_ctx* c, const int32_t* k_to_lapl, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   for (int i = 0; i < c->k; ++i)
     if (k_to_lapl[i] < 0 || k_to_lapl[i] >= c->lib.P) return fail(c, PRMF_ERR_ARG, "latent %d: pathway %d out of range", i, k_to_lapl[i]);
-  HIP_TRY(c, hipStreamSynchronize(s));   // the pinned staging buffer may still be in use
-  std::memcpy(c->active_host_pinned, k_to_lapl, (size_t)c->k * sizeof(int32_t));
-  HIP_TRY(c, hipMemcpyAsync(c->active_dev, c->active_host_pinned, (size_t)c->k * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  // the k indices travel as kernel arguments: no staging buffer, no stream synchronisation
+  HIP_TRY(c, launch_set_active(c->active_dev, k_to_lapl, c->k, s));
   HIP_TRY(c, launch_build_pos(c->lib, c->active_dev, c->col0, c->ncols, c->kc, c->n, c->pos, s));
   c->have_active = true;
   return PRMF_OK;
@@ -574,12 +570,7 @@ int prmf_begin(prmf_ctx* c, float* dU, float* dV, double gamma, double delta, do
   c->U = dU;
   c->V = dV;
   if ((rc = check_ready(c))) return rc;
-  HIP_TRY(c, hipStreamSynchronize(s));   // pinned staging reuse
-  c->hyper_host[0] = gamma;
-  c->hyper_host[1] = delta;
-  c->hyper_host[2] = tradeoff;
-  c->hyper_host[3] = 0.0;
-  HIP_TRY(c, hipMemcpyAsync(c->hyper, c->hyper_host, 4 * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(c, launch_set_hyper(c->hyper, gamma, delta, tradeoff, s));   // kernel arguments: no staging, no sync
   c->cursor = 0;
   c->graph_done = false;
   c->mid_pending = c->post_pending = false;
@@ -967,6 +958,23 @@ int prmf_cv_error(prmf_ctx* c, const float* dV, double* err_out, void* stream) {
   HIP_TRY(c, hipMemcpyAsync(&nfail, fail_dev, sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   if (nfail > 0) return fail(c, PRMF_ERR_NUMERIC, "nnls: %d of %lld samples did not converge in %d iterations", nfail, (long long)c->m, 3 * c->k);
+  return PRMF_OK;
+}
+
+/* debug (not in the public header): dense row-major copy of the product the last sweep left in the slabs --
+ * which = 0: P = X V [m][k] (valid between prmf_phase_u and prmf_phase_q), which = 1: Q = X^T U [n][k] (valid
+ * between prmf_phase_q and the next prmf_phase_u).  The full-size parity tests compare both with a float64
+ * restatement (tests/test_gpu_fullsize.py). */
+extern "C" int prmf_debug_slab_sum(prmf_ctx* c, int which, float* out_dev, void* stream) {
+  if (!c || !out_dev || (which != 0 && which != 1)) return PRMF_ERR_ARG;
+  if (!c->have_x) return fail(c, PRMF_ERR_STATE, "prmf_set_x has not been called");
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (which == 0)
+    HIP_TRY(c, launch_slab_sum_blocks(c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP, c->m, c->k, c->k, 1, out_dev, s));
+  else
+    HIP_TRY(c, launch_slab_sum_blocks(c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP, c->n, c->k, c->k, 1, out_dev, s));
   return PRMF_OK;
 }
 

@@ -104,6 +104,8 @@ hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStrea
 // Q slabs -> q_send[nranks][n][kc]
 hipError_t launch_slab_sum_blocks(const float* slabs, const uint32_t* segmask, int panel_rows, int64_t slab_stride, int KP,
                                   int64_t n, int k, int kc, int nranks, float* q_send, hipStream_t s);
+hipError_t launch_set_hyper(double* hyper, double gamma, double delta, double tradeoff, hipStream_t s);
+hipError_t launch_set_active(int32_t* active_dev, const int32_t* host_vals, int k, hipStream_t s);
 // pos[n][kc] = index in the active pathway's support of gene j for own column c, or -1
 hipError_t launch_build_pos(const PathwayLibDev& lib, const int32_t* active_dev, int col0, int ncols, int kc,
                             int64_t n, int32_t* pos, hipStream_t s);

@@ -783,6 +783,31 @@ hipError_t launch_slab_sum_blocks(const float* slabs, const uint32_t* segmask, i
 }
 
 // ---------------------------------------------------------------------------
+// host scalars -> device state without a staging buffer (kernel arguments): no
+// pinned-memory reuse hazard, so prmf_begin / prmf_set_active need no stream sync
+// ---------------------------------------------------------------------------
+__global__ void set_hyper_kernel(double* __restrict__ hyper, double gamma, double delta, double tradeoff) {
+  hyper[0] = gamma;
+  hyper[1] = delta;
+  hyper[2] = tradeoff;
+  hyper[3] = 0.0;
+}
+hipError_t launch_set_hyper(double* hyper, double gamma, double delta, double tradeoff, hipStream_t s) {
+  set_hyper_kernel<<<1, 1, 0, s>>>(hyper, gamma, delta, tradeoff);
+  return hipGetLastError();
+}
+struct ActiveArgs { int32_t v[MAX_KP]; };
+__global__ void set_active_kernel(int32_t* __restrict__ active, ActiveArgs a, int k) {
+  if ((int)threadIdx.x < k) active[threadIdx.x] = a.v[threadIdx.x];
+}
+hipError_t launch_set_active(int32_t* active_dev, const int32_t* host_vals, int k, hipStream_t s) {
+  ActiveArgs a;
+  for (int i = 0; i < MAX_KP; ++i) a.v[i] = i < k ? host_vals[i] : 0;
+  set_active_kernel<<<1, MAX_KP, 0, s>>>(active_dev, a, k);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // active pathway -> dense position map for the own columns
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)

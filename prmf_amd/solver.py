@@ -135,7 +135,18 @@ class PrmfEngine(object):
         self._check(self.lib.prmf_set_active(self.ctx, _ptr(a), self._stream()))
 
     def invalidate_factors(self):
+        self._factor_key = None
         self._check(self.lib.prmf_invalidate_factors(self.ctx))
+
+    def product(self, which):
+        """Dense copy of the product the last sweep left in the slabs (validation only):
+        "xv" -> P = X V (m x k) between phase_u and phase_q, "xtu" -> Q = X^T U (n x k) after phase_q."""
+        torch = self.torch
+        rows = self.m if which == "xv" else self.n
+        out = torch.empty((rows, self.k), dtype=torch.float32, device="cuda:%d" % self.device)
+        self._check(self.lib.prmf_debug_slab_sum(self.ctx, 0 if which == "xv" else 1, C.c_void_p(out.data_ptr()),
+                                                 self._stream()))
+        return out
 
     # -- the hot path ----------------------------------------------------------
     def _check_factors(self, U, V):
@@ -146,11 +157,29 @@ class PrmfEngine(object):
             if tuple(t.shape) != shape:
                 raise ValueError("%s has shape %s != %s" % (name, tuple(t.shape), shape))
 
+    def _bind_factors(self, U, V):
+        """The library caches the packed V and V^T V of the factors it last updated and keys that cache on
+        the raw device pointers only.  A different tensor can live at the same address (torch's caching
+        allocator hands freed blocks out again) and a caller can edit V in place, so the cache is kept only
+        when U and V are the very tensor objects of the previous call and their version counters have not
+        moved (the library writes through raw pointers: `_version` changes on caller edits only)."""
+        import weakref
+        key = (U.data_ptr(), U._version, V.data_ptr(), V._version)
+        prev = getattr(self, "_factor_key", None)
+        same = (prev is not None and prev[0] == key and prev[1]() is U and prev[2]() is V)
+        if not same:
+            self.invalidate_factors()
+        self._factor_key = (key, weakref.ref(U), weakref.ref(V))
+        self._bound = (U, V)      # keep the tensors alive while the library holds their pointers
+
     def step(self, U, V, n_steps, gamma, delta, tradeoff=None):
         """n_steps iterations in place on device tensors U (m x k), V (n x k).
         Returns (list of objective dicts, one per iteration; (gamma, delta) for
-        the next call)."""
+        the next call).  Contract: U and V are updated in place through their raw
+        pointers; the factors cached inside the library (packed V, V^T V) are reused
+        only when the same tensor objects come back unmodified (`_bind_factors`)."""
         self._check_factors(U, V)
+        self._bind_factors(U, V)
         obj = np.zeros((max(n_steps, 1), _capi.PRMF_OBJ_STRIDE))
         gd = np.zeros(2)
         t = -1.0 if tradeoff is None else float(tradeoff)
@@ -190,7 +219,7 @@ class PrmfEngine(object):
 
     def begin(self, U, V, gamma, delta, tradeoff=None):
         self._check_factors(U, V)
-        self._bound = (U, V)      # keep the tensors alive while the library holds their pointers
+        self._bind_factors(U, V)
         t = -1.0 if tradeoff is None else float(tradeoff)
         self._check(self.lib.prmf_begin(self.ctx, C.c_void_p(U.data_ptr()), C.c_void_p(V.data_ptr()),
                                         float(gamma), float(delta), t, self._stream()))
@@ -244,7 +273,7 @@ class PrmfEngine(object):
     def step_dist(self, U, V, n_steps, gamma, delta, tradeoff=None):
         """Multi-rank `step`: the library runs phases and collectives on the stream."""
         self._check_factors(U, V)
-        self._bound = (U, V)
+        self._bind_factors(U, V)
         obj = np.zeros((max(n_steps, 1), _capi.PRMF_OBJ_STRIDE))
         gd = np.zeros(2)
         t = -1.0 if tradeoff is None else float(tradeoff)

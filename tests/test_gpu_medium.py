@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import synth
+from measure import relmax, report
 
 pytestmark = pytest.mark.gpu
 
@@ -50,6 +51,9 @@ def test_medium_vs_oracle_and_deterministic(m, n, k, x_dtype):
     tr = []
     Ur, Vr, od = orc.nmf_manifold_vec_update(case["X"], case["U0"], case["V0"], active, n_steps=steps,
                                              gamma=case["gamma"], delta=case["delta"], trace=tr)
+    U, V, objs = outs[0]
+    report("medium_vs_oracle[%dx%d-k%d-%s]" % (m, n, k, x_dtype), steps=steps, rel_U=rel(U, Ur), rel_V=rel(V, Vr),
+           **{"rel_" + key: relmax([a[key] for a in objs], [b[key] for b in tr]) for key in ("recon", "manifold", "ignore", "fro", "obj")})
     for U, V, objs in outs:
         assert np.isfinite(U).all() and np.isfinite(V).all()
         assert rel(U, Ur) < 1e-4 and rel(V, Vr) < 1e-4
@@ -112,8 +116,10 @@ def test_full_size_c3_properties(workload, x_dtype):
         R = Xd[r0:r0 + 5000].double() - U[r0:r0 + 5000].double() @ Vd.T
         acc += float((R * R).sum())
     recon = math.sqrt(acc)
-    assert abs(objs[-1]["recon"] - recon) <= 1e-4 * recon, (objs[-1]["recon"], recon)
     fro = float((U.double() ** 2).sum())
+    report("full_size_properties[%s-%s]" % (workload, x_dtype), rel_recon=abs(objs[-1]["recon"] - recon) / recon,
+           rel_fro=abs(objs[-1]["fro"] - fro) / fro)
+    assert abs(objs[-1]["recon"] - recon) <= 1e-4 * recon, (objs[-1]["recon"], recon)
     assert abs(objs[-1]["fro"] - fro) <= 1e-5 * fro
     assert objs[-1]["obj"] == pytest.approx(objs[-1]["recon"] + objs[-1]["gamma"] * objs[-1]["manifold"]
                                             + objs[-1]["delta"] * objs[-1]["ignore"] + objs[-1]["fro"], rel=1e-12)

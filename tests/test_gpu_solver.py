@@ -9,14 +9,24 @@ import numpy as np
 import pytest
 
 import synth
+from measure import rel, relmax, report
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# Tolerances.  State is float32 against the float64 reference: ~1e-6 drift after hundreds of iterations on
+# U and V, the bar is 1e-4.  Scalars parsed from obj.txt are printed by the reference with
+# 5 decimals ("%.5f"): a value like manifold = 0.00215 carries 3 significant digits, so a scalar v from obj.txt is
+# compared with |got - ref| <= TOL_OBJ * |ref| + OBJ_TXT_QUANTUM (half a unit of the last printed decimal, twice:
+# both sides were rounded).  U.csv / V.csv hold full-precision reprs and get the plain 1e-4 bar.
+TOL_FACTOR = 1e-4
+TOL_OBJ = 1e-4
+OBJ_TXT_QUANTUM = 1.0e-5
 
-def rel(a, b):
-    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
-    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+def obj_txt_errors(vals, ref):
+    """per key: |got - ref| minus the print quantum, relative to |ref| (<= TOL_OBJ passes)"""
+    return {key: max(0.0, abs(vals[key] - ref[key]) - OBJ_TXT_QUANTUM) / max(abs(ref[key]), 1e-12) for key in ref}
 
 
 def engine_for(case, x_dtype="f32", **kw):
@@ -42,7 +52,12 @@ def test_tradeoff_variant_vs_reference(golden_dir):
     nst = 7
     objs, gd = eng.step(U, V, nst, case["gamma"], case["delta"], tradeoff=float(g["tradeoff"]))
     got = np.array([[o[k] for k in ["recon", "manifold", "ignore", "fro", "gamma", "delta", "obj"]] for o in objs])
-    assert np.allclose(got, g["obj"][:nst], rtol=5e-4)
+    # the feedback gamma = (1 - t) recon / (t manifold) divides by a manifold term of 1e-3..1e-5 that is itself a
+    # difference of nearly equal sums: float32 V carries ~1e-7 into it, amplified step by step (gamma x2..x100 per
+    # step here).  Measured drift is reported; the bound is per step, loosening with the amplification.
+    err = [relmax(got[i], g["obj"][i]) for i in range(nst)]
+    report("tradeoff_variant_vs_reference", per_step=err, gd=relmax(gd, g["obj"][nst][4:6]))
+    assert max(err[:4]) < 1e-4 and max(err) < 5e-4
     assert np.allclose(gd, g["obj"][nst][4:6], rtol=5e-4)        # gamma/delta handed to step nst+1
     objs5, _ = eng.step(U, V, 0, 1.0, 1.0)                        # n_steps = 0 is a no-op
     assert objs5 == []
@@ -88,10 +103,10 @@ def _graphs(c):
     return [runner.relabel_nodes(nx.read_graphml(fp).to_undirected(), "name") for fp in c["manifolds"]]
 
 
-@pytest.mark.parametrize("name,tradeoff", [("g6_api.npz", None)])
+@pytest.mark.parametrize("name,tradeoff", [("g6_api.npz", None), ("g6_api_tradeoff.npz", 0.5)])
 def test_outer_solver_vs_reference_trace(golden_dir, tmp_path, name, tradeoff):
-    """nmf_pathway end to end: same RNG stream -> same per-round pathway assignment,
-    same final latent->pathway map, objective trace within fp32 tolerance."""
+    """nmf_pathway end to end (with and without --tradeoff, prmf_runner.py:740 / :742): same RNG stream -> same
+    per-round pathway assignment, same final latent->pathway map, objective trace within fp32 tolerance."""
     from prmf_amd.solver import nmf_pathway
     g = np.load(os.path.join(golden_dir, name))
     c = synth.cli_case(str(tmp_path), variant=1)
@@ -99,11 +114,24 @@ def test_outer_solver_vs_reference_trace(golden_dir, tmp_path, name, tradeoff):
     np.random.seed(1)
     U, V, od = nmf_pathway(c["X"], _graphs(c), nodelist=c["nodelist_ids"], gamma=1.0, tradeoff=tradeoff,
                            k_latent=6, round_log=rounds, trace=trace)
+    tr = np.array([t["obj"] for t in trace])
+    ncmp = min(len(tr), len(g["trace"]))
+    e_tr = relmax(tr[:ncmp], g["trace"][:ncmp])
+    eu, ev = rel(U, g["U"]), rel(V, g["V"])
+    report("outer_solver_vs_reference_trace[%s]" % name, iterations=len(tr), ref_iterations=len(g["trace"]),
+           rel_trace=e_tr, rel_U=eu, rel_V=ev, rel_obj=relmax([od[k] for k in ("recon", "manifold", "ignore", "fro", "obj")],
+                                                              g["obj"][[0, 1, 2, 3, 6]]))
     assert np.array_equal(np.array(rounds), g["rounds"])
-    assert np.allclose([t["obj"] for t in trace], g["trace"], rtol=1e-4)
+    assert len(tr) == len(g["trace"])
     l2p = od["latent_to_pathway_data"]
     assert [int(l2p[k][0][0]) for k in sorted(l2p)] == list(g["final_map"])
-    assert rel(U, g["U"]) < 1e-3 and rel(V, g["V"]) < 1e-3
+    if tradeoff is None:
+        assert e_tr < TOL_OBJ and eu < TOL_FACTOR and ev < TOL_FACTOR
+    else:
+        # 1000 iterations of the gamma = delta = recon / manifold feedback: the manifold term (5e-3, a difference of
+        # nearly equal sums over the support) carries float32 noise of V into gamma every step; the run still takes
+        # the reference's 100 rounds and lands on its final map, factors and objective to 3 digits
+        assert e_tr < 5e-3 and eu < 5e-3 and ev < 5e-3
     with pytest.raises(ValueError):
         nmf_pathway(c["X"], _graphs(c), nodelist=c["nodelist_ids"], k_latent=6, U_init=np.ones((3, 6)))
 
@@ -127,27 +155,39 @@ def _read_obj(fp):
     return vals, mapping
 
 
-@pytest.mark.parametrize("variant,tag", [(1, "g6"), (2, "g7")])
-def test_cli_outputs_vs_reference(golden_dir, tmp_path, variant, tag):
+def _trace_of(stdout):
+    return np.array([float(l.split()[1]) for l in stdout.splitlines() if len(l.split()) == 2 and l.split()[0].isdigit()])
+
+
+@pytest.mark.parametrize("variant,tag,norm", [(1, "g6", "nonorm"), (2, "g7", "nonorm"), (1, "g6", "norm"), (2, "g7", "norm")])
+def test_cli_outputs_vs_reference(golden_dir, tmp_path, variant, tag, norm):
+    """The reference's two CLI test inputs, with --no-normalize (70 iterations) and with the default
+    quantile normalisation (370 / 320 iterations): stdout trace, obj.txt, mapping, U.csv, V.csv."""
     import pandas as pd
-    g = np.load(os.path.join(golden_dir, tag + "_nonorm.npz"))
+    g = np.load(os.path.join(golden_dir, "%s_%s.npz" % (tag, norm)))
     c = synth.cli_case(str(tmp_path), variant=variant)
     out = str(tmp_path / "out")
     os.makedirs(out)
     stdout = _cli(["--data", c["data"], "--manifolds"] + c["manifolds"] +
                   ["--node-attribute", "name", "--nodelist", c["nodelist"], "--outdir", out, "--delimiter", "\t",
-                   "--seed", "1", "--no-normalize"], str(tmp_path))
+                   "--seed", "1"] + (["--no-normalize"] if norm == "nonorm" else []), str(tmp_path))
     assert "Printing manifold node representation in nodelist:" in stdout and "norm(X) = " in stdout
     vals, mapping = _read_obj(os.path.join(out, "obj.txt"))
     ref = json.loads(str(g["obj_txt"]))
     assert list(vals) == list(ref)                               # same keys, same order
-    for key in ref:
-        assert abs(vals[key] - ref[key]) <= 2e-4 * max(abs(ref[key]), 1e-3), key
-    assert mapping == json.loads(str(g["mapping"]))
+    trace = _trace_of(stdout)
     U = pd.read_csv(os.path.join(out, "U.csv"))
     V = pd.read_csv(os.path.join(out, "V.csv"), index_col=0)
+    eo = obj_txt_errors(vals, ref)
+    ncmp = min(len(trace), len(g["trace"]))
+    eu, ev, et = rel(U.to_numpy(), g["U"]), rel(V.to_numpy(), g["V"]), relmax(trace[:ncmp], g["trace"][:ncmp])
+    report("cli_outputs_vs_reference[%s_%s]" % (tag, norm), iterations=len(trace), ref_iterations=len(g["trace"]),
+           rel_trace=et, rel_U=eu, rel_V=ev, obj_txt=eo)
+    assert len(trace) == len(g["trace"])
+    assert mapping == json.loads(str(g["mapping"]))
     assert list(U.columns) == ["LV%d" % i for i in range(6)] and list(V.index) == c["nodelist_ids"]
-    assert rel(U.to_numpy(), g["U"]) < 1e-3 and rel(V.to_numpy(), g["V"]) < 1e-3
+    assert max(eo.values()) < TOL_OBJ, eo
+    assert et < TOL_OBJ and eu < TOL_FACTOR and ev < TOL_FACTOR
     head = open(os.path.join(out, "V.csv")).readline().strip()
     assert head == '"","LV0","LV1","LV2","LV3","LV4","LV5"'       # QUOTE_NONNUMERIC contract
     if variant == 2:
@@ -177,20 +217,22 @@ def test_cli_more_variants_vs_reference(golden_dir, tmp_path, tag):
     stdout = _cli(["--data", c["data"], "--manifolds"] + man + extra +
                   ["--node-attribute", "name", "--nodelist", c["nodelist"], "--outdir", out, "--delimiter", "\t",
                    "--seed", "1", "--no-normalize"], str(tmp_path))
-    trace = np.array([float(l.split()[1]) for l in stdout.splitlines()
-                      if len(l.split()) == 2 and l.split()[0].isdigit()])
+    trace = _trace_of(stdout)
     ref_trace = g["trace"]
-    assert len(trace) == len(ref_trace)
-    assert np.allclose(trace, ref_trace, rtol=2e-4)
     vals, mapping = _read_obj(os.path.join(out, "obj.txt"))
     ref = json.loads(str(g["obj_txt"]))
     assert list(vals) == list(ref)
-    for key in ref:
-        assert abs(vals[key] - ref[key]) <= 2e-4 * max(abs(ref[key]), 1e-3), key
-    assert mapping == json.loads(str(g["mapping"]))
     U = pd.read_csv(os.path.join(out, "U.csv")).to_numpy()
     V = pd.read_csv(os.path.join(out, "V.csv"), index_col=0).to_numpy()
-    assert rel(U, g["U"]) < 2e-3 and rel(V, g["V"]) < 2e-3
+    eo = obj_txt_errors(vals, ref)
+    ncmp = min(len(trace), len(ref_trace))
+    eu, ev, et = rel(U, g["U"]), rel(V, g["V"]), relmax(trace[:ncmp], ref_trace[:ncmp])
+    report("cli_more_variants_vs_reference[%s]" % tag, iterations=len(trace), ref_iterations=len(ref_trace),
+           rel_trace=et, rel_U=eu, rel_V=ev, obj_txt=eo)
+    assert len(trace) == len(ref_trace)
+    assert mapping == json.loads(str(g["mapping"]))
+    assert max(eo.values()) < TOL_OBJ, eo
+    assert et < TOL_OBJ and eu < TOL_FACTOR and ev < TOL_FACTOR
     if tag == "g10_init":
         got = [os.path.basename(x) for x in open(os.path.join(out, "init_pathways.txt")).read().split("\n")]
         assert got == json.loads(str(g["init_pathways"]))
@@ -209,9 +251,62 @@ def test_cli_npy_input(golden_dir, tmp_path):
                                                            "--outdir", out, "--seed", "1", "--no-normalize"], str(tmp_path))
     vals, mapping = _read_obj(os.path.join(out, "obj.txt"))
     ref = json.loads(str(g["obj_txt"]))
-    for key in ref:
-        assert abs(vals[key] - ref[key]) <= 2e-4 * max(abs(ref[key]), 1e-3), key
+    eo = obj_txt_errors(vals, ref)
+    report("cli_npy_input", obj_txt=eo)
+    assert max(eo.values()) < TOL_OBJ, eo
     assert mapping == json.loads(str(g["mapping"]))
+
+
+@pytest.mark.parametrize("variant,tag", [(1, "g6"), (2, "g7")])
+def test_cli_header_inferred_nodelist(golden_dir, tmp_path, variant, tag):
+    """No --nodelist: the gene ids come from the data file's header (prmf_runner.py:955-975); the reference's
+    own test (test_inferred_nodelist_1.py:55-56) expects the obj.txt of the explicit-nodelist run."""
+    g = np.load(os.path.join(golden_dir, tag + "_header.npz"))
+    g_explicit = np.load(os.path.join(golden_dir, tag + "_nonorm.npz"))
+    c = synth.cli_case(str(tmp_path), variant=variant)
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    _cli(["--data", c["data_header"], "--manifolds"] + c["manifolds"] + ["--node-attribute", "name", "--outdir", out,
+                                                                         "--delimiter", "\t", "--seed", "1", "--no-normalize"],
+         str(tmp_path))
+    vals, mapping = _read_obj(os.path.join(out, "obj.txt"))
+    ref = json.loads(str(g["obj_txt"]))
+    assert list(vals) == list(ref)
+    eo = obj_txt_errors(vals, ref)
+    report("cli_header_inferred_nodelist[%s]" % tag, obj_txt=eo)
+    assert max(eo.values()) < TOL_OBJ, eo
+    assert mapping == json.loads(str(g["mapping"]))
+    assert json.loads(str(g["obj_txt"])) == json.loads(str(g_explicit["obj_txt"]))     # what the reference's test asserts
+
+
+def test_cli_embeds_graph_only_genes(golden_dir, tmp_path):
+    """Header lists only the measured genes; the pathways name six more.  The CLI must append them to the
+    nodelist and zero-embed X (prmf_runner.py:962-972, prmf.embed_arr): V.csv then has 1006 rows in the
+    reference's order and the graph-only genes sit at float32 eps."""
+    import pandas as pd
+    g = np.load(os.path.join(golden_dir, "g7_measured.npz"))
+    c = synth.cli_case(str(tmp_path), variant=2)
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    stdout = _cli(["--data", c["data_header_measured"], "--manifolds"] + c["manifolds"] +
+                  ["--node-attribute", "name", "--outdir", out, "--delimiter", "\t", "--seed", "1", "--no-normalize"],
+                  str(tmp_path))
+    vals, mapping = _read_obj(os.path.join(out, "obj.txt"))
+    ref = json.loads(str(g["obj_txt"]))
+    V = pd.read_csv(os.path.join(out, "V.csv"), index_col=0)
+    trace = _trace_of(stdout)
+    ref_index = json.loads(str(g["V_index"]))
+    assert sorted(V.index) == sorted(ref_index)
+    Vr = pd.DataFrame(g["V"], index=ref_index).loc[list(V.index)].to_numpy()    # graph-only genes are appended from a set
+    eo = obj_txt_errors(vals, ref)
+    ncmp = min(len(trace), len(g["trace"]))
+    ev, et = rel(V.to_numpy(), Vr), relmax(trace[:ncmp], g["trace"][:ncmp])
+    report("cli_embeds_graph_only_genes", iterations=len(trace), rel_trace=et, rel_V=ev, obj_txt=eo)
+    assert len(trace) == len(g["trace"])
+    assert mapping == json.loads(str(g["mapping"]))
+    assert max(eo.values()) < TOL_OBJ and et < TOL_OBJ and ev < TOL_FACTOR
+    extra = [x for x in V.index if int(x[4:]) >= 1000]
+    assert len(extra) == 6 and np.allclose(V.loc[extra].to_numpy(), np.finfo(np.float32).eps)
 
 
 def test_cli_config1_plumbing(golden_dir, tmp_path):
@@ -227,11 +322,12 @@ def test_cli_config1_plumbing(golden_dir, tmp_path):
     vals, mapping = _read_obj(os.path.join(out, "obj.txt"))
     ref = json.loads(str(g["obj_txt"]))
     assert list(vals) == list(ref)
-    for key in ref:
-        assert abs(vals[key] - ref[key]) <= 5e-4 * max(abs(ref[key]), 1e-3), key
-    assert mapping == json.loads(str(g["mapping"]))
+    eo = obj_txt_errors(vals, ref)
     err = np.loadtxt(os.path.join(out, "test_error.csv"), delimiter=",")
-    assert err.shape == (20,) and np.allclose(err, g["test_error"], rtol=5e-3)
+    report("cli_config1_plumbing", obj_txt=eo, rel_test_error=relmax(err, g["test_error"]))
+    assert max(eo.values()) < TOL_OBJ, eo
+    assert mapping == json.loads(str(g["mapping"]))
+    assert err.shape == (20,) and np.allclose(err, g["test_error"], rtol=1e-4)
 
 
 @pytest.mark.parametrize("m,n,k,x_dtype", [(37, 500, 8, "f32"), (64, 1000, 13, "f32"), (50, 2000, 64, "f32"),
