@@ -79,9 +79,26 @@ struct prmf_ctx {
   double* colres = nullptr;           // [kc][2]
   double* vpartial = nullptr;         // [v_update_blocks][kc+1]
   int vblocks = 0;
+  int wpt_u = 1, wpt_v = 1;           // waves per tile in the fused epilogues (cooperative slab sum)
   bool fused_u = false, fused_v = false, gram_v_done = false;
   // fused_u / fused_v: MFMA epilogues (k % 4 == 0; the V one when there is one column block: single rank or replicated mode)
   bool graph_done = false;            // the pathway terms of this iteration were already computed in phase_u (merged launch)
+
+  // Deferred objective + sweep prologues (single rank, fused epilogues, tradeoff off; `lazy` is decided per batch in
+  // prmf_begin).  The iteration is then 4 launches: sweep X V [prologue: V^T V reduce + column norms / <Q,V> of the
+  // previous iteration] -> U epilogue -> sweep X^T U [prologue: U^T U reduce + pathway terms] -> V epilogue; what the
+  // objective record needs is kept per iteration in the rings below and evaluated for the whole batch in prmf_end.
+  bool lazy = false;
+  bool gv_pending = false;            // the V epilogue's V^T V partials / per-wave sums are not reduced yet
+  bool batch_open = false;
+  bool dist_driver = false;           // inside prmf_step_dist: collectives sit between the phases, keep the eager sequence
+  int nparts_u = 0, nparts_v = 0;     // Gram partials the U / V side writes per iteration
+  double* Gu_keep = nullptr;          // [MAX_RECORDS][k*k]
+  double* Gv_keep = nullptr;          // [MAX_RECORDS][k*k]
+  double* colnorm2_ring = nullptr;    // [MAX_RECORDS][k]
+  double* cross_ring = nullptr;       // [MAX_RECORDS]
+  double* colres_ring = nullptr;      // [MAX_RECORDS][k][2]
+  float* vsup_ring = nullptr;         // [MAX_RECORDS][k][max_support]   (allocated with the pathway library)
 
   // hyper-parameters + records
   double* hyper = nullptr;            // device: gamma, delta, tradeoff
@@ -206,6 +223,7 @@ int prepare(prmf_ctx* c, hipStream_t s) {
   HIP_TRY(c, launch_pack_factor(fv, c->pack_dtype, c->NT, c->Kpad_x, c->Vp, s));
   HIP_TRY(c, launch_gram(fv, c->gram_partial, c->Gv, s));
   c->prepared = true;
+  c->gv_pending = false;
   return PRMF_OK;
 }
 
@@ -237,6 +255,42 @@ int ensure_own_comm(prmf_ctx* c) {
   }
   c->own_comm = true;
   return PRMF_OK;
+}
+
+// prologue that closes iteration `it` of the batch on the V side (it < 0: results go to the spare ring slot)
+SweepPrologue post_prologue(prmf_ctx* c, int it) {
+  const int slot = it >= 0 ? it : MAX_RECORDS;
+  SweepPrologue p;
+  p.kind = PROLOGUE_POST;
+  p.gram_partial = (const float*)c->gram_partial;
+  p.nparts = c->nparts_v;
+  p.k = c->k;
+  p.G = c->Gv;
+  p.G_keep = c->Gv_keep + (size_t)slot * c->k * c->k;
+  p.vpartial = c->vpartial;
+  p.nwaves = c->vblocks;
+  p.colnorm2 = c->colnorm2_ring + (size_t)slot * c->k;
+  p.cross = c->cross_ring + slot;
+  return p;
+}
+
+SweepPrologue mid_prologue(prmf_ctx* c, int it) {
+  SweepPrologue p;
+  p.kind = PROLOGUE_MID;
+  p.gram_partial = (const float*)c->gram_partial;
+  p.nparts = c->nparts_u;
+  p.k = c->k;
+  p.G = c->gram_buf;
+  p.G_keep = c->Gu_keep + (size_t)it * c->k * c->k;
+  p.lib = c->lib;
+  p.active = c->active_dev;
+  p.col0 = 0;
+  p.ncols = c->k;
+  p.V = c->V;
+  p.hyper = c->hyper;
+  p.gnum = c->gnum;
+  p.gden = c->gden;
+  return p;
 }
 
 }  // namespace
@@ -329,12 +383,21 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, &c->pos, (size_t)n * c->kc, false))) return bail(rc);
   c->fused_u = (k % 4 == 0) && !getenv("PRMF_NO_FUSED_EPILOGUE");
   c->fused_v = c->fused_u && c->lr == 1;
-  c->vblocks = c->fused_v ? v_epilogue_waves(n) : v_update_blocks(n);
+  c->wpt_u = epilogue_wpt(c->Kpad_xt, c->plan_xv.max_seg, c->NT);
+  c->wpt_v = epilogue_wpt(c->Kpad_x, c->plan_xtu.max_seg, c->NT);
+  c->vblocks = c->fused_v ? v_epilogue_waves(n, c->wpt_v) : v_update_blocks(n);
   if ((rc = dev_alloc(c, &c->vpartial, (size_t)c->vblocks * (c->kc + 1)))) return bail(rc);
   if ((rc = dev_alloc(c, &c->colres, (size_t)c->kc * 2))) return bail(rc);
   if ((rc = dev_alloc(c, &c->hyper, 4))) return bail(rc);
   if ((rc = dev_alloc(c, &c->records, (size_t)MAX_RECORDS * PRMF_OBJ_STRIDE))) return bail(rc);
   if ((rc = dev_alloc(c, &c->colnorm, (size_t)k))) return bail(rc);
+  if (nranks == 1) {
+    if ((rc = dev_alloc(c, &c->Gu_keep, (size_t)(MAX_RECORDS + 1) * k * k, false))) return bail(rc);
+    if ((rc = dev_alloc(c, &c->Gv_keep, (size_t)(MAX_RECORDS + 1) * k * k, false))) return bail(rc);
+    if ((rc = dev_alloc(c, &c->colnorm2_ring, (size_t)(MAX_RECORDS + 1) * k))) return bail(rc);
+    if ((rc = dev_alloc(c, &c->cross_ring, (size_t)MAX_RECORDS + 1))) return bail(rc);
+    if ((rc = dev_alloc(c, &c->colres_ring, (size_t)MAX_RECORDS * k * 2))) return bail(rc);
+  }
   if (hipHostMalloc((void**)&c->hyper_host, 4 * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&c->records_host, (size_t)MAX_RECORDS * PRMF_OBJ_STRIDE * sizeof(double)) != hipSuccess) {
     fail(c, PRMF_ERR_HIP, "hipHostMalloc failed");
@@ -391,6 +454,12 @@ int prmf_destroy(prmf_ctx* c) {
   dev_free(c->hyper);
   dev_free(c->records);
   dev_free(c->colnorm);
+  dev_free(c->Gu_keep);
+  dev_free(c->Gv_keep);
+  dev_free(c->colnorm2_ring);
+  dev_free(c->cross_ring);
+  dev_free(c->colres_ring);
+  dev_free(c->vsup_ring);
   dev_free(c->scores_dev);
   if (c->hyper_host) (void)hipHostFree(c->hyper_host);
   if (c->records_host) (void)hipHostFree(c->records_host);
@@ -458,6 +527,7 @@ int prmf_set_pathway_library(prmf_ctx* c, int P, const int64_t* sup_ptr, const i
   dev_free(c->gnum); c->gnum = nullptr;
   dev_free(c->gden); c->gden = nullptr;
   dev_free(c->obj_scratch); c->obj_scratch = nullptr;
+  dev_free(c->vsup_ring); c->vsup_ring = nullptr;
   c->have_lib = false;
   c->have_active = false;
 
@@ -498,6 +568,7 @@ int prmf_set_pathway_library(prmf_ctx* c, int P, const int64_t* sup_ptr, const i
   if ((rc = dev_alloc(c, &c->gnum, (size_t)c->kc * max_sup))) return rc;
   if ((rc = dev_alloc(c, &c->gden, (size_t)c->kc * max_sup))) return rc;
   if ((rc = dev_alloc(c, &c->obj_scratch, (size_t)c->kc * max_sup))) return rc;
+  if (c->nranks == 1 && (rc = dev_alloc(c, &c->vsup_ring, (size_t)MAX_RECORDS * c->k * max_sup))) return rc;
   c->have_lib = true;
   return PRMF_OK;
 }
@@ -508,6 +579,9 @@ int prmf_set_active(prmf_ctx* c, const int32_t* k_to_lapl, void* stream) {
   int rc;
   if ((rc = set_device(c))) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if (c->batch_open && c->cursor > 0)
+    return fail(c, PRMF_ERR_STATE, "prmf_set_active between prmf_begin and prmf_end: the objective records of the %d iterations run so far "
+                                   "are evaluated in prmf_end with the active pathways", c->cursor);
   for (int i = 0; i < c->k; ++i)
     if (k_to_lapl[i] < 0 || k_to_lapl[i] >= c->lib.P) return fail(c, PRMF_ERR_ARG, "latent %d: pathway %d out of range", i, k_to_lapl[i]);
   // the k indices travel as kernel arguments: no staging buffer, no stream synchronisation
@@ -575,6 +649,11 @@ int prmf_begin(prmf_ctx* c, float* dU, float* dV, double gamma, double delta, do
   c->graph_done = false;
   c->mid_pending = c->post_pending = false;
   if (!c->prepared && (rc = prepare(c, s))) return rc;
+  // objective deferred to prmf_end + reductions folded into the sweeps: single rank, fused MFMA epilogues, default
+  // 4-wave sweep workgroups, tradeoff feedback off (with it on, gamma/delta of step t+1 need the record of step t)
+  c->lazy = c->nranks == 1 && c->m > 0 && c->fused_u && c->fused_v && !(tradeoff >= 0.0) && c->plan_xv.nw == 4 &&
+            c->plan_xtu.nw == 4 && c->vsup_ring && !c->dist_driver && !getenv("PRMF_NO_LAZY_OBJECTIVE");
+  c->batch_open = true;
   return PRMF_OK;
 }
 
@@ -587,12 +666,31 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (c->m > 0) {
     const bool timing = (c->flags & PRMF_FLAG_TIMING) != 0;
+    if (c->lazy && c->gv_pending && c->cursor == 0) {   // cannot happen through prmf_begin/prmf_end; keep V^T V right anyway
+      HIP_TRY(c, launch_prologue_alone(post_prologue(c, -1), s));
+      c->gv_pending = false;
+    }
+    SweepPrologue pro;
+    if (c->lazy && c->gv_pending) pro = post_prologue(c, c->cursor - 1);
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 0], s));
     // P = X V                                             (prmf_runner.py:420)
-    HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xv, c->X, c->ldx, c->m, c->Vp, c->NT, c->slabs, c->slab_stride_p, s, c->split_f32));
+    HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xv, c->X, c->ldx, c->m, c->Vp, c->NT, c->slabs, c->slab_stride_p, s, c->split_f32,
+                           pro.kind != PROLOGUE_NONE ? &pro : nullptr));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 1], s));
     // U <- U * P / (U Gv + U)                              (:421-422)
     FactorView fu{c->U, (int)c->m, c->k, c->k, 0};
+    if (c->lazy) {
+      c->gv_pending = false;
+      bool gram_done = false;
+      HIP_TRY(c, launch_u_epilogue(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP,
+                                   c->Gv, c->pack_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, c->wpt_u, s));
+      c->nparts_u = epilogue_blocks(c->Kpad_xt, c->wpt_u);
+      if (!gram_done) {                // k > 64: the epilogue has no registers left for the Gram tiles
+        HIP_TRY(c, launch_gram_partials(fu, (float*)c->gram_partial, s));
+        c->nparts_u = gram_blocks(fu.rows);
+      }
+      return PRMF_OK;                  // U^T U is reduced, and the pathway terms are computed, by the X^T U sweep's prologue
+    }
     if (c->post_pending) {            // V^T V (and gamma/delta) of the previous iteration come from the aux stream
       HIP_TRY(c, hipStreamWaitEvent(s, c->ev_post, 0));
       c->post_pending = false;
@@ -600,7 +698,7 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
     if (c->fused_u) {
       bool gram_done = false;
       HIP_TRY(c, launch_u_epilogue(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP,
-                                   c->Gv, c->pack_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, s));
+                                   c->Gv, c->pack_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, c->wpt_u, s));
       if (gram_done) {
         // one launch: reduce (this rank's) U^T U and compute the pathway terms of the own columns
         // (they depend on the old V and gamma/delta only); next to the X^T U sweep when driven internally
@@ -610,7 +708,7 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
           HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
           ms = c->aux;
         }
-        HIP_TRY(c, launch_mid((const float*)c->gram_partial, epilogue_blocks(c->Kpad_xt), c->k, c->gram_buf, c->lib,
+        HIP_TRY(c, launch_mid((const float*)c->gram_partial, epilogue_blocks(c->Kpad_xt, c->wpt_u), c->k, c->gram_buf, c->lib,
                               c->active_dev, c->col0, c->ncols, c->V, c->hyper, c->gnum, c->gden, ms));
         if (ms != s) {
           HIP_TRY(c, hipEventRecord(c->ev_mid, c->aux));
@@ -643,7 +741,10 @@ int prmf_phase_q(prmf_ctx* c, void* stream) {
   if (c->m > 0) {
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 2], s));
     // Q = X^T U_new                                       (:424)
-    HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xtu, c->XT, c->ldxt, c->n, c->Up, c->NT, c->slabs, c->slab_stride_q, s, c->split_f32));
+    SweepPrologue pro;
+    if (c->lazy) pro = mid_prologue(c, c->cursor);
+    HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xtu, c->XT, c->ldxt, c->n, c->Up, c->NT, c->slabs, c->slab_stride_q, s, c->split_f32,
+                           c->lazy ? &pro : nullptr));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 3], s));
     // the replicated multi-rank mode all-reduces Q, so it needs the summed dense form even on the fused path
     if (!c->fused_v || c->replicated)
@@ -664,6 +765,21 @@ int prmf_phase_v(prmf_ctx* c, void* stream) {
     HIP_TRY(c, hipStreamWaitEvent(s, c->ev_mid, 0));
     c->mid_pending = false;
   }
+  if (c->lazy) {
+    // pathway terms and U^T U came from the sweep's prologue; the objective pieces are deferred to prmf_end
+    HIP_TRY(c, launch_v_epilogue(c->V, c->n, c->k, c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP,
+                                 c->gram_buf, c->pos, c->gnum, c->gden, c->lib.max_support, c->pack_dtype, c->Vp, c->Kpad_x,
+                                 c->vpartial, (float*)c->gram_partial, &c->gram_v_done, nullptr,
+                                 c->vsup_ring + (size_t)c->cursor * c->k * c->lib.max_support, c->wpt_v, s));
+    c->nparts_v = epilogue_blocks(c->Kpad_x, c->wpt_v);
+    if (!c->gram_v_done) {
+      FactorView fv{c->V, (int)c->n, c->k, c->k, 0};
+      HIP_TRY(c, launch_gram_partials(fv, (float*)c->gram_partial, s));
+      c->nparts_v = gram_blocks(fv.rows);
+    }
+    c->gv_pending = true;
+    return PRMF_OK;
+  }
   // sparse pathway terms on the OLD V                    (:431-438)
   if (!c->graph_done)
     HIP_TRY(c, launch_graph_terms(c->lib, c->active_dev, c->col0, c->ncols, c->V, c->k, c->hyper, c->gnum, c->gden, s));
@@ -675,7 +791,7 @@ int prmf_phase_v(prmf_ctx* c, void* stream) {
     HIP_TRY(c, launch_v_epilogue(c->V, c->n, c->k, c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP,
                                  c->gram_buf, c->pos, c->gnum, c->gden, c->lib.max_support, c->pack_dtype, c->Vp, c->Kpad_x,
                                  c->vpartial, (float*)c->gram_partial, &c->gram_v_done,
-                                 c->replicated ? c->q_recv : nullptr, s));
+                                 c->replicated ? c->q_recv : nullptr, nullptr, c->wpt_v, s));
     if (!c->gram_v_done)   // otherwise the objective pieces ride along with the V^T V reduction in phase_post
       HIP_TRY(c, launch_objective_terms(c->lib, c->active_dev, 0, c->k, c->k, c->n, c->V, c->vpartial, c->vblocks, c->colres,
                                         c->obj_scratch, extras, s));
@@ -694,6 +810,10 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
   if ((rc = set_device(c))) return rc;
   if (c->cursor >= MAX_RECORDS) return fail(c, PRMF_ERR_STATE, "more than %d iterations between prmf_begin and prmf_end", MAX_RECORDS);
   hipStream_t s = (hipStream_t)stream;
+  if (c->lazy) {                       // nothing to launch: the next X V sweep (or prmf_end) closes this iteration
+    c->cursor++;
+    return PRMF_OK;
+  }
   FactorView fv{c->V, (int)c->n, c->k, c->k, 0};
   if (!c->fused_v) {
     if (c->fused_u) {
@@ -721,7 +841,7 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
       HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
       ps = c->aux;
     }
-    HIP_TRY(c, launch_post((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x), c->k, c->Gv, c->lib, c->active_dev, c->V,
+    HIP_TRY(c, launch_post((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x, c->wpt_v), c->k, c->Gv, c->lib, c->active_dev, c->V,
                            c->vpartial, c->vblocks, c->colres, c->obj_scratch, ps));
     HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->lr, c->v_send_floats, c->extras_off, c->norm_x_sq,
                                c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, c->vpartial, c->vblocks, c->colres, ps));
@@ -748,6 +868,18 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
   if (c->mid_pending) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_mid, 0));
   if (c->post_pending) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_post, 0));
   c->mid_pending = c->post_pending = false;
+  if (c->lazy) {
+    if (c->gv_pending) {               // no sweep follows the last iteration: its V side is closed by a launch of its own
+      HIP_TRY(c, launch_prologue_alone(post_prologue(c, c->cursor - 1), s));
+      c->gv_pending = false;
+    }
+    // the objective records of the whole batch (prmf_runner.py:336-372), two launches
+    HIP_TRY(c, launch_objective_all(c->lib, c->active_dev, c->k, c->cursor, c->colnorm2_ring, c->vsup_ring, c->colres_ring,
+                                    c->obj_scratch, s));
+    HIP_TRY(c, launch_records_all(c->Gu_keep, c->Gv_keep, c->k, c->cursor, c->cross_ring, c->colres_ring, c->norm_x_sq, c->hyper,
+                                  c->records, s));
+  }
+  c->batch_open = false;
   if (n_steps > 0)
     HIP_TRY(c, hipMemcpyAsync(c->records_host, c->records + (size_t)(c->cursor - n_steps) * PRMF_OBJ_STRIDE,
                               (size_t)n_steps * PRMF_OBJ_STRIDE * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -856,8 +988,8 @@ int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma,
   int done = 0, rc;
   struct Internal {
     prmf_ctx* c;
-    explicit Internal(prmf_ctx* c_) : c(c_) { c->internal_driver = true; }
-    ~Internal() { c->internal_driver = false; }
+    explicit Internal(prmf_ctx* c_) : c(c_) { c->internal_driver = c->dist_driver = true; }
+    ~Internal() { c->internal_driver = c->dist_driver = false; }
   } internal(c);
   while (done < n_steps) {
     const int batch = n_steps - done < MAX_RECORDS ? n_steps - done : MAX_RECORDS;

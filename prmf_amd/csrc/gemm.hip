@@ -27,6 +27,7 @@
 // A goes straight from global memory to registers (streamed once, never shared
 // between waves: no LDS round trip), PF chunks ahead of the MFMAs.
 #include "kernels.h"
+#include "prologue.h"
 
 #include <cstdlib>
 
@@ -292,13 +293,22 @@ __global__ void __launch_bounds__(64 * NW, (MODE == 2 && NT == 2 && NW == 4) ? 2
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
              const uint4* __restrict__ Bp, int npanels, int g_begin, int ngroups /* chunk pairs [g_begin, g_begin+ngroups) of every row */,
              int nx, int pmax, int seg_base, float* __restrict__ slabs, int64_t slab_stride,
-             unsigned long long* __restrict__ stamps /* debug, may be null */) {
+             unsigned long long* __restrict__ stamps /* debug, may be null */, const SweepPrologue pro) {
   if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x] = wall_clock64();
   constexpr int NTHR = 64 * NW;
   constexpr int BCH = MODE == 1 ? 512 * NT : 256 * NT;   // uint4 per packed chunk (64 bf16 or 32 f32 elements of the reduction)
   constexpr int BPT = (BCH + NTHR - 1) / NTHR;      // uint4 staged per thread per chunk (last one may be partial)
   __shared__ u32x4 sB[BDB ? 2 : 1][BCH];
   __shared__ u32x4 sA[NW][MT * 256];                // per wave: MT tiles of 32 rows x 128 B
+
+  // the small reductions between the epilogue before this sweep and the one after it (prologue.h); the LDS
+  // scratch is the A tile area (>= 16 KiB with 4 waves x 64 rows), untouched until the main loop's own prologue
+  if constexpr (NW == 4) {
+    if (pro.kind != PROLOGUE_NONE) {
+      run_sweep_prologue(pro, reinterpret_cast<char*>(&sA[0][0]), (int)sizeof(sA));
+      __syncthreads();
+    }
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -534,11 +544,11 @@ unsigned long long* g_sweep_stamps = nullptr;   // debug: per-workgroup start/en
 
 template <int MODE, int NW, bool BDB, int MTV>
 static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda16, int64_t M_store, const void* Bp,
-                                  int NT, float* slabs, int64_t slab_stride, hipStream_t s) {
+                                  int NT, float* slabs, int64_t slab_stride, hipStream_t s, const SweepPrologue& pro) {
 #define PRMF_LAUNCH(NTV)                                                                                       \
   sweep_kernel<MODE, MTV, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), 0, s>>>(                                  \
       (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, 0, p.ngroups, p.nx, p.pmax, 0, slabs, slab_stride, \
-      g_sweep_stamps)
+      g_sweep_stamps, pro)
   switch (NT) {
     case 1: PRMF_LAUNCH(1); break;
     case 2: PRMF_LAUNCH(2); break;
@@ -551,12 +561,15 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
 }
 
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
-                       const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s, bool split) {
+                       const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s, bool split,
+                       const SweepPrologue* prologue) {
   const int64_t lda16 = lda * elem_bytes(x_dtype) / 16;
+  const SweepPrologue pro = prologue ? *prologue : SweepPrologue{};
+  if (pro.kind != PROLOGUE_NONE && (p.nw != 4 || pro.nparts > GRAM_MAX_PARTS)) return hipErrorInvalidValue;
   const int mode = x_dtype == 1 ? 1 : (split ? 2 : 0);
   // default shape: 4 waves x 64 rows; factor double-buffered at k <= 64
   if (p.mt == 2 && p.nw == 4 && p.bdb == (NT <= 2)) {
-#define PRMF_GO(MODEV, BDBV) return launch_sweep_nt<MODEV, 4, BDBV, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)
+#define PRMF_GO(MODEV, BDBV) return launch_sweep_nt<MODEV, 4, BDBV, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro)
     if (NT <= 2) {
       if (mode == 1) PRMF_GO(1, true);
       if (mode == 2) PRMF_GO(2, true);
@@ -570,22 +583,38 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
   if (mode == 2) return hipErrorInvalidValue;      // the split form exists for the default shape only
   // other shapes (tests, experiments): PRMF_SWEEP_NW / _MT / _BDB
   if (p.mt == 2 && NT > 2)
-    return mode == 1 ? launch_sweep_nt<1, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)
-                     : launch_sweep_nt<0, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
+    return mode == 1 ? launch_sweep_nt<1, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro)
+                     : launch_sweep_nt<0, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
   if (p.mt == 2) {
     if (mode == 1)
-      return p.nw == 8 ? launch_sweep_nt<1, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)
-                       : launch_sweep_nt<1, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
-    return p.nw == 8 ? launch_sweep_nt<0, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)
-                     : launch_sweep_nt<0, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s);
+      return p.nw == 8 ? launch_sweep_nt<1, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro)
+                       : launch_sweep_nt<1, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
+    return p.nw == 8 ? launch_sweep_nt<0, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro)
+                     : launch_sweep_nt<0, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
   }
 #define PRMF_DISPATCH(MD)                                                                                               \
-  (p.nw == 8 ? (p.bdb ? launch_sweep_nt<MD, 8, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)      \
-                      : launch_sweep_nt<MD, 8, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s))    \
-             : (p.bdb ? launch_sweep_nt<MD, 4, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)      \
-                      : launch_sweep_nt<MD, 4, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s)))
+  (p.nw == 8 ? (p.bdb ? launch_sweep_nt<MD, 8, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro)      \
+                      : launch_sweep_nt<MD, 8, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro))    \
+             : (p.bdb ? launch_sweep_nt<MD, 4, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro)      \
+                      : launch_sweep_nt<MD, 4, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro)))
   return mode == 1 ? PRMF_DISPATCH(1) : PRMF_DISPATCH(0);
 #undef PRMF_DISPATCH
+}
+
+// the prologue work without a sweep behind it (end of a batch)
+__global__ void __launch_bounds__(256) prologue_alone_kernel(const SweepPrologue pro) {
+  __shared__ __attribute__((aligned(16))) char lds[16 * 1024];
+  run_sweep_prologue(pro, lds, (int)sizeof(lds));
+}
+
+hipError_t launch_prologue_alone(const SweepPrologue& p, hipStream_t s) {
+  if (p.kind == PROLOGUE_NONE) return hipSuccess;
+  if (p.nparts > GRAM_MAX_PARTS) return hipErrorInvalidValue;
+  int jobs = gram_reduce_jobs(p.k * p.k);
+  const int extra = p.kind == PROLOGUE_POST ? p.k + 1 : p.ncols;
+  if (jobs < extra) jobs = extra;
+  prologue_alone_kernel<<<jobs, 256, 0, s>>>(p);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------

@@ -36,6 +36,45 @@ struct FactorView {
   int64_t blk_stride;
 };
 
+// Pathway library on the device (prmf_set_pathway_library): all P pathways concatenated
+struct PathwayLibDev {
+  int P;
+  int max_support;
+  int max_nnz;              // most adjacency entries of one pathway
+  int64_t total_support, total_nnz;
+  const int64_t* sup_ptr;   // [P+1]
+  const int32_t* sup_idx;   // [total_support] gene index
+  const double* sup_deg;    // D_ii
+  const double* sup_dis;    // L_ii^-1/2 or 0     (normalize_laplacian, prmf_runner.py:56-65)
+  const int64_t* row_ptr;   // [total_support+1]
+  const int32_t* col_local; // [nnz] support-local column
+  const double* w;          // [nnz]
+};
+
+// Work a sweep launch does in its first microseconds for the epilogues around it (prologue.h).
+enum { PROLOGUE_NONE = 0, PROLOGUE_POST = 1, PROLOGUE_MID = 2 };
+struct SweepPrologue {
+  int kind = PROLOGUE_NONE;
+  // both kinds: float64 reduction of `nparts` per-workgroup Gram partials [k*k] -> G (and the iteration's kept copy)
+  const float* gram_partial = nullptr;
+  int nparts = 0, k = 0;
+  double* G = nullptr;
+  double* G_keep = nullptr;
+  // PROLOGUE_POST (before X V; closes the PREVIOUS iteration): column norms^2 of V_new and <Q, V_new>
+  const double* vpartial = nullptr;     // [nwaves][k+1] from the V epilogue
+  int nwaves = 0;
+  double* colnorm2 = nullptr;           // [k]
+  double* cross = nullptr;              // [1]
+  // PROLOGUE_MID (before X^T U): pathway terms of the V update on the old V
+  PathwayLibDev lib{};
+  const int32_t* active = nullptr;
+  int col0 = 0, ncols = 0;
+  const float* V = nullptr;
+  const double* hyper = nullptr;
+  float* gnum = nullptr;
+  float* gden = nullptr;
+};
+
 // ---------------------------------------------------------------------------
 // gemm.hip
 // ---------------------------------------------------------------------------
@@ -58,7 +97,10 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus);
 extern unsigned long long* g_sweep_stamps;   // debug only
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
                        const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s,
-                       bool split = false /* f32 X as three bf16 pieces, packedB in the bf16 hi/lo layout */);
+                       bool split = false /* f32 X as three bf16 pieces, packedB in the bf16 hi/lo layout */,
+                       const SweepPrologue* prologue = nullptr /* only with 4-wave workgroups (plan.nw == 4) */);
+// the same prologue work as a stand-alone launch (end of a batch: no sweep follows)
+hipError_t launch_prologue_alone(const SweepPrologue& p, hipStream_t s);
 hipError_t launch_copy_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols,
                            void* dst, int64_t ld_dst, hipStream_t s);
 hipError_t launch_transpose_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols,
@@ -67,40 +109,40 @@ hipError_t launch_transpose_pad(int x_dtype, const void* src, int64_t ld_src, in
 // ---------------------------------------------------------------------------
 // update.hip
 // ---------------------------------------------------------------------------
-struct PathwayLibDev {
-  int P;
-  int max_support;
-  int max_nnz;              // most adjacency entries of one pathway
-  int64_t total_support, total_nnz;
-  const int64_t* sup_ptr;   // [P+1]
-  const int32_t* sup_idx;   // [total_support] gene index
-  const double* sup_deg;    // D_ii
-  const double* sup_dis;    // L_ii^-1/2 or 0     (normalize_laplacian, prmf_runner.py:56-65)
-  const int64_t* row_ptr;   // [total_support+1]
-  const int32_t* col_local; // [nnz] support-local column
-  const double* w;          // [nnz]
-};
 
 // U <- U * (P / (U Gv + U)), P = sum of `splits` slabs     (prmf_runner.py:420-422)
 hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                            int64_t slab_stride, int KP, const double* Gv, hipStream_t s);
 // fused U epilogue (k % 4 == 0): slab sum + U (V^T V) on the f32 MFMA + update + fragment packing
 // (*gram_done: the kernel also wrote epilogue_blocks(Kpad) per-workgroup partials of F_new^T F_new)
-int epilogue_blocks(int64_t rows);
+int epilogue_wpt(int64_t rows, int max_seg, int NT);   // waves sharing a tile's slab sum (1, 2, 4)
+int epilogue_blocks(int64_t rows, int wpt = 1);
 hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
-                             float* gram_partial, bool* gram_done, hipStream_t s);
+                             float* gram_partial, bool* gram_done, int wpt, hipStream_t s);
 hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G, hipStream_t s);
 // fused single-rank V epilogue (k % 4 == 0): in place, + packing + per-wave partials [waves][k+1]
-int v_epilogue_waves(int64_t n);
+int v_epilogue_waves(int64_t n, int wpt = 1);
 hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gu, const int32_t* pos, const float* gnum,
                              const float* gden, int max_support, int x_dtype, void* packed, int64_t Kpad,
                              double* partial, float* gram_partial, bool* gram_done,
-                             const float* qdense /* null: sum the slabs; else Q [n][k], already summed */, hipStream_t s);
+                             const float* qdense /* null: sum the slabs; else Q [n][k], already summed */,
+                             float* vsup /* null, or [k][max_support]: V_new on the active supports (deferred objective) */,
+                             int wpt, hipStream_t s);
+// Deferred objective (single rank, tradeoff off): all iterations of a batch in two launches at prmf_end.
+//   colnorm2 [iters][k], vsup [iters][k][max_support] -> colres [iters][k][2] (manifold, ignore of the normalised column)
+hipError_t launch_objective_all(const PathwayLibDev& lib, const int32_t* active_dev, int k, int iters, const double* colnorm2,
+                                const float* vsup, double* colres, double* scratch /* [k][max_support], large supports only */,
+                                hipStream_t s);
+//   Gu_keep / Gv_keep [iters][k*k], cross [iters], colres -> records [iters][8]   (gamma, delta constant over the batch)
+hipError_t launch_records_all(const double* Gu_keep, const double* Gv_keep, int k, int iters, const double* cross,
+                              const double* colres, double norm_x_sq, const double* hyper, double* records, hipStream_t s);
 // partial Gram: per-wave partials -> partial[gram_blocks][k*k]; reduce -> G (double)
 int gram_blocks(int64_t rows);
 hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStream_t s);
+// only the gram_blocks(f.rows) per-workgroup partials [k*k] floats (the reduction happens in a sweep's prologue)
+hipError_t launch_gram_partials(const FactorView& f, float* partial, hipStream_t s);
 // Q slabs -> q_send[nranks][n][kc]
 hipError_t launch_slab_sum_blocks(const float* slabs, const uint32_t* segmask, int panel_rows, int64_t slab_stride, int KP,
                                   int64_t n, int k, int kc, int nranks, float* q_send, hipStream_t s);

@@ -9,6 +9,7 @@
 //   U update :420-422   V update :424-444   objective :336-372
 //   normalize_laplacian :56-65   restrict scoring :115-127
 #include "kernels.h"
+#include "prologue.h"
 
 namespace prmf {
 
@@ -21,21 +22,6 @@ __device__ __forceinline__ int64_t slab_index(int64_t row, int col, int NT) {
   const int rr = (int)(row & 31);
   const int lane = (col & 31) + 32 * ((rr >> 2) & 1);
   return ((((tile * NT + (col >> 5)) * 4 + (rr >> 3)) * 64 + lane) << 2) + (rr & 3);
-}
-
-// deterministic block-wide sum of one double per thread (256 threads)
-__device__ __forceinline__ double block_sum_256(double v, double* red /* [256] shared */) {
-  const int tid = threadIdx.x;
-  red[tid] = v;
-  __syncthreads();
-#pragma unroll
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) red[tid] += red[tid + s];
-    __syncthreads();
-  }
-  double r = red[0];
-  __syncthreads();
-  return r;
 }
 
 // ---------------------------------------------------------------------------
@@ -186,43 +172,16 @@ __global__ void __launch_bounds__(256) gram_mfma_kernel(FactorView f, float* __r
     }
 }
 
-// G[e] = sum over the workgroup partials in float64, fixed order: 8 threads per entry,
-// thread `sub` sums partials sub, sub+8, ... with 4 independent loads in flight, the 8
-// sub-sums are then combined in order.
-__device__ __forceinline__ void gram_reduce_body(const float* __restrict__ partial, int nparts, int kk2,
-                                                 double* __restrict__ G, int vblock, double (*red)[32]) {
-  const int el = threadIdx.x & 31, sub = threadIdx.x >> 5;
-  const int e = vblock * 32 + el;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  if (e < kk2) {
-    int b = sub;
-    for (; b + 24 < nparts; b += 32) {
-      const float v0 = partial[(int64_t)b * kk2 + e], v1 = partial[(int64_t)(b + 8) * kk2 + e];
-      const float v2 = partial[(int64_t)(b + 16) * kk2 + e], v3 = partial[(int64_t)(b + 24) * kk2 + e];
-      s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
-    }
-    for (; b < nparts; b += 8) s0 += (double)partial[(int64_t)b * kk2 + e];
-  }
-  red[sub][el] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (sub == 0 && e < kk2) {
-    double t = red[0][el];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) t += red[j][el];
-    G[e] = t;
-  }
-}
-
+// reduce per-workgroup Gram partials into G (float64, fixed order: prologue.h)
 __global__ void __launch_bounds__(256) gram_reduce_kernel(const float* __restrict__ partial, int nparts, int kk2,
                                                           double* __restrict__ G) {
-  __shared__ double red[8][32];
-  gram_reduce_body(partial, nparts, kk2, G, blockIdx.x, red);
+  __shared__ double red[256];
+  gram_reduce_job(partial, nparts, kk2, G, nullptr, blockIdx.x, red);
 }
 
-hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStream_t s) {
+hipError_t launch_gram_partials(const FactorView& f, float* pf, hipStream_t s) {
   const int nparts = gram_blocks(f.rows);
   const int NT = (f.cols + 31) / 32;
-  float* pf = reinterpret_cast<float*>(partial);
   switch (NT) {
     case 1: gram_mfma_kernel<1><<<nparts, 256, 0, s>>>(f, pf); break;
     case 2: gram_mfma_kernel<2><<<nparts, 256, 0, s>>>(f, pf); break;
@@ -230,8 +189,16 @@ hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStrea
     case 4: gram_mfma_kernel<4><<<nparts, 256, 0, s>>>(f, pf); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStream_t s) {
+  const int nparts = gram_blocks(f.rows);
+  float* pf = reinterpret_cast<float*>(partial);
+  hipError_t e = launch_gram_partials(f, pf, s);
+  if (e != hipSuccess) return e;
   const int kk2 = f.cols * f.cols;
-  gram_reduce_kernel<<<(kk2 + 31) / 32, 256, 0, s>>>(pf, nparts, kk2, G);
+  gram_reduce_kernel<<<gram_reduce_jobs(kk2), 256, 0, s>>>(pf, nparts, kk2, G);
   return hipGetLastError();
 }
 
@@ -384,6 +351,41 @@ __device__ __forceinline__ void load_slab_tile(const float* __restrict__ slabs, 
   }
 }
 
+// Cooperative slab sum.  With few tiles and many segments per tile (small matrices: a 5000-row X V has 157 tiles of
+// 26 segments each) one wave per tile walks a chain of dependent load batches on a handful of CUs.  `wpt` = 2 or 4
+// waves then share a tile: wave `sub` sums the segments whose ordinal (in slab-index order) is congruent to sub,
+// the sub-sums meet in LDS and the tile's leader wave (sub 0) adds them in sub order -- a fixed order again.
+__device__ __forceinline__ uint32_t my_segments(uint32_t mask, int wpt, int sub) {
+  if (wpt == 1) return mask;
+  uint32_t mine = 0;
+  int ord = 0;
+  for (uint32_t mk = mask; mk; mk &= mk - 1, ++ord)
+    if (ord % wpt == sub) mine |= mk & (0u - mk);
+  return mine;
+}
+
+// comb: [4 waves][NT*16][64] floats.  Every wave of the workgroup calls this (two barriers).
+template <int NT>
+__device__ __forceinline__ void combine_tile_sums(float (&p)[NT][16], int wpt, int sub, int wave, int lane, float* comb) {
+  if (wpt == 1) return;
+  float* mine = comb + (size_t)wave * (NT * 16 * 64);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mine[(t * 16 + i) * 64 + lane] = p[t][i];
+  __syncthreads();
+  if (sub == 0) {
+    for (int j = 1; j < wpt; ++j) {
+      const float* o = comb + (size_t)(wave + j) * (NT * 16 * 64);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p[t][i] += o[(t * 16 + i) * 64 + lane];
+    }
+  }
+  __syncthreads();
+}
+
 // Gram partial of the tile in C/D layout (see gram_mfma_kernel): g[p] += tile^T tile
 template <int NT>
 __device__ __forceinline__ void gram_accumulate(const float (&un)[NT][16], f32x16 (&g)[NT * (NT + 1) / 2]) {
@@ -428,15 +430,17 @@ template <int NT, bool BF16, bool GRAM>
 __global__ void __launch_bounds__(256, NT <= 2 ? 2 : 1)
 u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs, const uint32_t* __restrict__ segmask,
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gv, void* __restrict__ packed,
-                  int64_t ntiles_pack, float* __restrict__ gram_partial) {
+                  int64_t ntiles_pack, float* __restrict__ gram_partial, int wpt /* waves per tile: 1, 2 or 4 */) {
   constexpr int KP = 32 * NT, NP = NT * (NT + 1) / 2;
+  constexpr int COMB = NT <= 2 ? 4 * NT * 16 * 64 : 1;              // cooperative slab sums exist for k <= 64
   __shared__ float Gs[KP * KP];
-  __shared__ float red[GRAM ? 4 : 1][16][64];
+  __shared__ float red_store[(GRAM ? 4 * 16 * 64 : 1) > COMB ? (GRAM ? 4 * 16 * 64 : 1) : COMB];   // Gram reduction | slab-sum exchange
+  float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(red_store);
   stage_gram<NT>(Gv, k, 0, k, Gs);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
-  const int64_t wstride = (int64_t)gridDim.x * 4;
+  const int tpw = 4 / wpt, sub = wave % wpt, tslot = wave / wpt;
   f32x16 g[GRAM ? NP : 1];
   if constexpr (GRAM) {
 #pragma unroll
@@ -444,13 +448,14 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
 #pragma unroll
       for (int i = 0; i < 16; ++i) g[p][i] = 0.f;
   }
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles_pack; tile += wstride) {
+  // uniform trip count over the workgroup (the cooperative sum has barriers): a slot past the end does nothing
+  for (int64_t base = (int64_t)blockIdx.x * tpw; base < ntiles_pack; base += (int64_t)gridDim.x * tpw) {
+    const int64_t tile = base + tslot;
     const int64_t row0 = tile * 32;
-    float un[NT][16];
-    if (row0 < m) {
-      // issue every load of the tile first (A layout, C/D layout, slabs), then the MFMA chain
-      float ua[16 * NT], uu[NT][16], p[NT][16];
-      load_slab_tile<NT>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, p);
+    const bool live = tile < ntiles_pack && row0 < m;
+    // issue every load of the tile first (A layout, C/D layout, slabs), then the MFMA chain
+    float p[NT][16], ua[16 * NT], uu[NT][16];
+    if (live && sub == 0) {
       load_tile_a_layout<NT>(U, m, k, row0, lane, ua);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -461,6 +466,19 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
           uu[t][i] = U[(row < m ? row : m - 1) * k + colc];
         }
       }
+    }
+    if constexpr (NT <= 2) {
+      if (wpt > 1) {
+        if (live) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, p);
+        else load_slab_tile<NT>(slabs, slab_stride, 0u, tile, lane, p);
+        combine_tile_sums<NT>(p, wpt, sub, wave, lane, red_store);
+        if (sub != 0) continue;
+      }
+    }
+    if (tile >= ntiles_pack) continue;
+    float un[NT][16];
+    if (row0 < m) {
+      if (wpt == 1) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, p);
       f32x16 den[NT];
       tile_times_gram<NT>(ua, lane, Gs, den);
 #pragma unroll
@@ -490,23 +508,35 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
   if constexpr (GRAM) gram_block_store<NT>(g, k, gram_partial + (int64_t)blockIdx.x * k * k, red);
 }
 
-int epilogue_blocks(int64_t rows) {
-  int64_t tiles = (rows + 31) / 32;
-  int64_t blocks = (tiles + 3) / 4;
+// waves that share one 32-row tile in the fused epilogues (see my_segments): as many as keep the launch within the
+// chip's 2048 resident waves and leave every wave at least one slab segment
+int epilogue_wpt(int64_t rows, int max_seg, int NT) {
+  if (NT > 2) return 1;
+  const int64_t tiles = (rows + 31) / 32;
+  int w = 1;
+  while (w < 4 && tiles * (2 * w) <= 2048 && 2 * w <= max_seg) w *= 2;
+  return w;
+}
+
+int epilogue_blocks(int64_t rows, int wpt) {
+  const int64_t tiles = (rows + 31) / 32;
+  const int tpw = 4 / (wpt < 1 ? 1 : wpt);
+  int64_t blocks = (tiles + tpw - 1) / tpw;
   if (blocks > 512) blocks = 512;
   return (int)(blocks < 1 ? 1 : blocks);
 }
 
 hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
-                             float* gram_partial, bool* gram_done, hipStream_t s) {
+                             float* gram_partial, bool* gram_done, int wpt, hipStream_t s) {
   const int NT = KP / 32;
   const int64_t ntiles = Kpad / 32;          // every tile of the packed buffer is (re)written, zero beyond m
-  const int grid = epilogue_blocks(Kpad);
+  if (NT > 2) wpt = 1;
+  const int grid = epilogue_blocks(Kpad, wpt);
   *gram_done = NT <= 2;
 #define PRMF_UEP(NTV, GR)                                                                                          \
-  if (x_dtype == 1) u_epilogue_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial); \
-  else u_epilogue_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial)
+  if (x_dtype == 1) u_epilogue_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial, wpt); \
+  else u_epilogue_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial, wpt)
   switch (NT) {
     case 1: PRMF_UEP(1, true); break;
     case 2: PRMF_UEP(2, true); break;
@@ -527,15 +557,18 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gu, const int32_t* __restrict__ pos,
                   const float* __restrict__ gnum, const float* __restrict__ gden, int max_support,
                   void* __restrict__ packed, int64_t ntiles_pack, double* __restrict__ partial /*[waves][k+1]*/,
-                  float* __restrict__ gram_partial) {
+                  float* __restrict__ gram_partial, float* __restrict__ vsup /* null or [k][max_support]: V_new on the supports */,
+                  int wpt /* waves per tile (cooperative slab sum, see my_segments): 1, 2 or 4; 1 with DENSE */) {
   constexpr int KP = 32 * NT, NP = NT * (NT + 1) / 2;
+  constexpr int COMB = (NT <= 2 && !DENSE) ? 4 * NT * 16 * 64 : 1;
   __shared__ float Gs[KP * KP];
-  __shared__ float red[GRAM ? 4 : 1][16][64];
+  __shared__ float red_store[(GRAM ? 4 * 16 * 64 : 1) > COMB ? (GRAM ? 4 * 16 * 64 : 1) : COMB];   // Gram reduction | slab-sum exchange
+  float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(red_store);
   stage_gram<NT>(Gu, k, 0, k, Gs);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
-  const int64_t wstride = (int64_t)gridDim.x * 4;
+  const int tpw = 4 / wpt, sub = wave % wpt, tslot = wave / wpt;
   double colsq[NT], cross = 0.0;
 #pragma unroll
   for (int t = 0; t < NT; ++t) colsq[t] = 0.0;
@@ -546,12 +579,39 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
 #pragma unroll
       for (int i = 0; i < 16; ++i) g[p][i] = 0.f;
   }
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles_pack; tile += wstride) {
+  // uniform trip count over the workgroup (the cooperative sum has barriers): a slot past the end does nothing
+  for (int64_t base = (int64_t)blockIdx.x * tpw; base < ntiles_pack; base += (int64_t)gridDim.x * tpw) {
+    const int64_t tile = base + tslot;
     const int64_t row0 = tile * 32;
+    const bool live = tile < ntiles_pack && row0 < n;
+    // every load of the tile is issued before the MFMA chain: V in both layouts, the position map, the slabs
+    float ua[16 * NT], vv[NT][16], q[NT][16];
+    int ps[NT][16];
+    if (live && sub == 0) {
+      load_tile_a_layout<NT>(V, n, k, row0, lane, ua);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = 32 * t + c, colc = col < k ? col : k - 1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const int64_t rc = row < n ? row : n - 1;
+          vv[t][i] = V[rc * k + colc];
+          ps[t][i] = pos[rc * k + colc];
+        }
+      }
+    }
+    if constexpr (NT <= 2 && !DENSE) {
+      if (wpt > 1) {
+        if (live) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, q);
+        else load_slab_tile<NT>(slabs, slab_stride, 0u, tile, lane, q);
+        combine_tile_sums<NT>(q, wpt, sub, wave, lane, red_store);
+        if (sub != 0) continue;
+      }
+    }
+    if (tile >= ntiles_pack) continue;
     float vn[NT][16];
     if (row0 < n) {
-      float ua[16 * NT], vv[NT][16], q[NT][16];
-      int ps[NT][16];
       if constexpr (DENSE) {
         // Q already summed over segments and ranks (replicated multi-rank V update): row-major [n][k]
 #pragma unroll
@@ -564,31 +624,10 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
           }
         }
       } else {
-        load_slab_tile<NT>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);   // 4 segments per round trip: no faster
-      }
-      load_tile_a_layout<NT>(V, n, k, row0, lane, ua);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int col = 32 * t + c, colc = col < k ? col : k - 1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const int64_t rc = row < n ? row : n - 1;
-          vv[t][i] = V[rc * k + colc];
-        }
+        if (wpt == 1) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);
       }
       f32x16 den[NT];
       tile_times_gram<NT>(ua, lane, Gs, den);
-      // the position map is loaded after the MFMA chain, into the registers the A-layout tile has freed
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int col = 32 * t + c, colc = col < k ? col : k - 1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          ps[t][i] = pos[(row < n ? row : n - 1) * k + colc];
-        }
-      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int col = 32 * t + c;
@@ -606,6 +645,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
             r2 = vv[t][i] * (num / d);
             if (r2 < PRMF_EPS) r2 = PRMF_EPS;
             V[row * k + col] = r2;
+            if (vsup && ps[t][i] >= 0) vsup[(int64_t)col * max_support + ps[t][i]] = r2;   // for the deferred objective
             colsq[t] += (double)r2 * (double)r2;
             cross += (double)q[t][i] * (double)r2;
           }
@@ -634,20 +674,24 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
   if constexpr (GRAM) gram_block_store<NT>(g, k, gram_partial + (int64_t)blockIdx.x * k * k, red);
 }
 
-int v_epilogue_waves(int64_t n) { return epilogue_blocks(round_up(n, K_PAD)) * 4; }
+int v_epilogue_waves(int64_t n, int wpt) { return epilogue_blocks(round_up(n, K_PAD), wpt) * 4; }
 
 hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gu, const int32_t* pos, const float* gnum,
                              const float* gden, int max_support, int x_dtype, void* packed, int64_t Kpad,
-                             double* partial, float* gram_partial, bool* gram_done, const float* qdense, hipStream_t s) {
+                             double* partial, float* gram_partial, bool* gram_done, const float* qdense, float* vsup, int wpt,
+                             hipStream_t s) {
   const int NT = KP / 32;
   const int64_t ntiles = Kpad / 32;
-  // the grid must match v_epilogue_waves(n): every partial row is written by exactly one wave
-  const int grid = epilogue_blocks(Kpad);
+  // `wpt` must be the value the caller sized `partial` with (v_epilogue_waves): every partial row is written by
+  // exactly one wave; the dense-Q form has no slabs to share and runs one wave per tile on the same grid
+  if (NT > 2) wpt = 1;
+  const int grid = epilogue_blocks(Kpad, wpt);
+  const int kwpt = qdense ? 1 : wpt;
   *gram_done = NT <= 2;
   const float* qsrc = qdense ? qdense : slabs;
 #define PRMF_VEP2(NTV, GR, BF, DN)                                                                                  \
-  v_epilogue_kernel<NTV, BF, GR, DN><<<grid, 256, 0, s>>>(V, n, k, qsrc, segmask, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial)
+  v_epilogue_kernel<NTV, BF, GR, DN><<<grid, 256, 0, s>>>(V, n, k, qsrc, segmask, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial, vsup, kwpt)
 #define PRMF_VEP(NTV, GR)                                                                                           \
   if (x_dtype == 1) { if (qdense) PRMF_VEP2(NTV, GR, true, true); else PRMF_VEP2(NTV, GR, true, false); }           \
   else { if (qdense) PRMF_VEP2(NTV, GR, false, true); else PRMF_VEP2(NTV, GR, false, false); }
@@ -733,7 +777,7 @@ hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G
 
 hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G, hipStream_t s) {
   const int kk2 = k * k;
-  gram_reduce_kernel<<<(kk2 + 31) / 32, 256, 0, s>>>(partial, nparts, kk2, G);
+  gram_reduce_kernel<<<gram_reduce_jobs(kk2), 256, 0, s>>>(partial, nparts, kk2, G);
   return hipGetLastError();
 }
 
@@ -835,33 +879,6 @@ hipError_t launch_build_pos(const PathwayLibDev& lib, const int32_t* active_dev,
 // once into LDS, the CSR rows (support-local column indices) then read LDS only.
 // ---------------------------------------------------------------------------
 template <bool USE_LDS>
-__device__ __forceinline__ void graph_terms_body(const PathwayLibDev& lib, const int32_t* __restrict__ active, int col0, int c,
-                                                 const float* __restrict__ V, int k, const double* __restrict__ hyper,
-                                                 float* __restrict__ gnum, float* __restrict__ gden, float* vs) {
-  const int kk = col0 + c;
-  const int p = active[kk];
-  const int64_t s0 = lib.sup_ptr[p];
-  const int ns = (int)(lib.sup_ptr[p + 1] - s0);
-  const double gamma = hyper[0], delta = hyper[1];
-  if (USE_LDS) {
-    for (int s = threadIdx.x; s < ns; s += 256) vs[s] = V[(int64_t)lib.sup_idx[s0 + s] * k + kk];
-    __syncthreads();
-  }
-  for (int s = threadIdx.x; s < ns; s += 256) {
-    const double v = USE_LDS ? (double)vs[s] : (double)V[(int64_t)lib.sup_idx[s0 + s] * k + kk];
-    double wv = 0.0;
-    for (int64_t e = lib.row_ptr[s0 + s]; e < lib.row_ptr[s0 + s + 1]; ++e) {
-      const int cl = lib.col_local[e];
-      const double vc = USE_LDS ? (double)vs[cl] : (double)V[(int64_t)lib.sup_idx[s0 + cl] * k + kk];
-      wv += lib.w[e] * vc;
-    }
-    const double vp1 = v + 1.0;
-    gnum[(int64_t)c * lib.max_support + s] = (float)(gamma * wv + delta / (vp1 * vp1));
-    gden[(int64_t)c * lib.max_support + s] = (float)(gamma * (lib.sup_deg[s0 + s] * v));
-  }
-}
-
-template <bool USE_LDS>
 __global__ void __launch_bounds__(256)
 graph_terms_kernel(PathwayLibDev lib, const int32_t* __restrict__ active, int col0, const float* __restrict__ V, int k,
                    const double* __restrict__ hyper, float* __restrict__ gnum, float* __restrict__ gden) {
@@ -877,8 +894,8 @@ mid_kernel(const float* __restrict__ gram_partial, int nparts, int k, double* __
            const int32_t* __restrict__ active, int col0, const float* __restrict__ V, const double* __restrict__ hyper,
            float* __restrict__ gnum, float* __restrict__ gden) {
   extern __shared__ __attribute__((aligned(16))) float vs[];
-  __shared__ double red[8][32];
-  if ((int)blockIdx.x < nred) gram_reduce_body(gram_partial, nparts, k * k, Gu, blockIdx.x, red);
+  __shared__ double red[256];
+  if ((int)blockIdx.x < nred) gram_reduce_job(gram_partial, nparts, k * k, Gu, nullptr, blockIdx.x, red);
   else graph_terms_body<USE_LDS>(lib, active, col0, blockIdx.x - nred, V, k, hyper, gnum, gden, vs);
 }
 
@@ -886,7 +903,7 @@ mid_kernel(const float* __restrict__ gram_partial, int nparts, int k, double* __
 hipError_t launch_mid(const float* gram_partial, int nparts, int k, double* Gu, const PathwayLibDev& lib,
                       const int32_t* active_dev, int col0, int ncols, const float* V, const double* hyper, float* gnum,
                       float* gden, hipStream_t s) {
-  const int nred = (k * k + 31) / 32;
+  const int nred = gram_reduce_jobs(k * k);
   const size_t lds = (size_t)lib.max_support * sizeof(float);
   if (lds <= 64 * 1024) mid_kernel<true><<<nred + ncols, 256, lds, s>>>(gram_partial, nparts, k, Gu, nred, lib, active_dev, col0, V, hyper, gnum, gden);
   else mid_kernel<false><<<nred + ncols, 256, 0, s>>>(gram_partial, nparts, k, Gu, nred, lib, active_dev, col0, V, hyper, gnum, gden);
@@ -1076,14 +1093,14 @@ post_kernel(const float* __restrict__ gram_partial, int nparts, int k, double* _
             const int32_t* __restrict__ active, const float* __restrict__ V, const double* __restrict__ partial, int nblocks,
             double* __restrict__ colres, double* __restrict__ scratch) {
   __shared__ double red[256];
-  if ((int)blockIdx.x < nred) gram_reduce_body(gram_partial, nparts, k * k, Gv, blockIdx.x, reinterpret_cast<double (*)[32]>(red));
+  if ((int)blockIdx.x < nred) gram_reduce_job(gram_partial, nparts, k * k, Gv, nullptr, blockIdx.x, red);
   else objective_col_body(lib, active, 0, k, blockIdx.x - nred, V, partial, nblocks, colres, scratch, red);
 }
 
 hipError_t launch_post(const float* gram_partial, int nparts, int k, double* Gv, const PathwayLibDev& lib,
                        const int32_t* active_dev, const float* V, const double* partial, int nblocks, double* colres,
                        double* scratch, hipStream_t s) {
-  const int nred = (k * k + 31) / 32;
+  const int nred = gram_reduce_jobs(k * k);
   post_kernel<<<nred + k, 256, 0, s>>>(gram_partial, nparts, k, Gv, nred, lib, active_dev, V, partial, nblocks, colres, scratch);
   return hipGetLastError();
 }
@@ -1212,6 +1229,113 @@ hipError_t launch_finalize(const double* Gu, const double* Gv, int k, const floa
                            const double* loc_partial, int loc_nblocks, const double* loc_colres, hipStream_t s) {
   finalize_kernel<<<1, 256, 0, s>>>(Gu, Gv, k, v_recv, nranks, blk_stride, extras_off, norm_x_sq, hyper, record,
                                     loc_partial, loc_nblocks, loc_colres);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Deferred objective (single rank, tradeoff off).  Nothing of the objective record (:336-372) feeds the next
+// update unless the tradeoff feedback is on, so the iterations only KEEP what the record needs -- U^T U and
+// V^T V (reduced anyway), <Q, V_new>, the column norms and V_new on the active supports (a few hundred KB per
+// iteration) -- and the whole batch is evaluated here in two launches at prmf_end.  Same arithmetic, same
+// reduction orders as objective_col_body / finalize_kernel: the records are bit-identical to the per-iteration form.
+// ---------------------------------------------------------------------------
+template <bool USE_LDS>
+__global__ void __launch_bounds__(256)
+objective_all_kernel(PathwayLibDev lib, const int32_t* __restrict__ active, int k, const double* __restrict__ colnorm2,
+                     const float* __restrict__ vsup, double* __restrict__ colres, double* __restrict__ scratch, int it0) {
+  extern __shared__ double y_lds[];
+  __shared__ double red[256];
+  const int c = blockIdx.x, it = it0 + blockIdx.y, tid = threadIdx.x;
+  const double inv = 1.0 / sqrt(colnorm2[(int64_t)it * k + c]);
+  const int p = active[c];
+  const int64_t s0 = lib.sup_ptr[p];
+  const int ns = (int)(lib.sup_ptr[p + 1] - s0);
+  double* y = USE_LDS ? y_lds : scratch + (int64_t)c * lib.max_support;
+  const float* vs = vsup + ((int64_t)it * k + c) * lib.max_support;
+  double ign = 0.0;
+  for (int s = tid; s < ns; s += 256) {
+    const double vh = (double)vs[s] * inv;
+    y[s] = vh * lib.sup_dis[s0 + s];
+    ign += 1.0 / (vh + 1.0);
+  }
+  __threadfence_block();
+  __syncthreads();
+  double man = 0.0;
+  for (int s = tid; s < ns; s += 256) {
+    const double ys = y[s];
+    double wy = 0.0;
+    for (int64_t e = lib.row_ptr[s0 + s]; e < lib.row_ptr[s0 + s + 1]; ++e) wy += lib.w[e] * y[lib.col_local[e]];
+    man += ys * (lib.sup_deg[s0 + s] * ys - wy);
+  }
+  man = block_sum_256(man, red);
+  ign = block_sum_256(ign, red);
+  if (tid == 0) {
+    colres[((int64_t)it * k + c) * 2] = man;
+    colres[((int64_t)it * k + c) * 2 + 1] = ign;
+  }
+}
+
+hipError_t launch_objective_all(const PathwayLibDev& lib, const int32_t* active_dev, int k, int iters, const double* colnorm2,
+                                const float* vsup, double* colres, double* scratch, hipStream_t s) {
+  if (iters <= 0) return hipSuccess;
+  const size_t lds = (size_t)lib.max_support * sizeof(double);
+  if (lds <= 48 * 1024) {
+    objective_all_kernel<true><<<dim3(k, iters), 256, lds, s>>>(lib, active_dev, k, colnorm2, vsup, colres, scratch, 0);
+  } else {
+    // supports too large for LDS: one iteration per launch through the [k][max_support] global scratch
+    for (int it = 0; it < iters; ++it)
+      objective_all_kernel<false><<<dim3(k, 1), 256, 0, s>>>(lib, active_dev, k, colnorm2, vsup, colres, scratch, it);
+  }
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256)
+records_all_kernel(const double* __restrict__ Gu_keep, const double* __restrict__ Gv_keep, int k, const double* __restrict__ cross,
+                   const double* __restrict__ colres, double norm_x_sq, const double* __restrict__ hyper,
+                   double* __restrict__ records) {
+  __shared__ double red[4][256];
+  const int tid = threadIdx.x, it = blockIdx.x;
+  const double* Gu = Gu_keep + (int64_t)it * k * k;
+  const double* Gv = Gv_keep + (int64_t)it * k * k;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};   // <Gu,Gv>, trace Gu, manifold, ignore
+  for (int i = tid; i < k * k; i += 256) acc[0] += Gu[i] * Gv[i];
+  for (int a = tid; a < k; a += 256) acc[1] += Gu[a * k + a];
+  for (int c = tid; c < k; c += 256) {
+    acc[2] += colres[((int64_t)it * k + c) * 2];
+    acc[3] += colres[((int64_t)it * k + c) * 2 + 1];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[j][tid] = acc[j];
+  __syncthreads();
+#pragma unroll
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[j][tid] += red[j][tid + s];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double gg = red[0][0], fro = red[1][0], man = red[2][0], ign = red[3][0];
+    const double gamma = hyper[0], delta = hyper[1];
+    const double recon_sq = norm_x_sq - 2.0 * cross[it] + gg;
+    const double recon = sqrt(recon_sq > 0.0 ? recon_sq : 0.0);
+    double* record = records + (int64_t)it * 8;
+    record[0] = recon;
+    record[1] = man;
+    record[2] = ign;
+    record[3] = fro;
+    record[4] = gamma;
+    record[5] = delta;
+    record[6] = recon + gamma * man + delta * ign + fro;
+    record[7] = recon_sq;
+  }
+}
+
+hipError_t launch_records_all(const double* Gu_keep, const double* Gv_keep, int k, int iters, const double* cross,
+                              const double* colres, double norm_x_sq, const double* hyper, double* records, hipStream_t s) {
+  if (iters <= 0) return hipSuccess;
+  records_all_kernel<<<iters, 256, 0, s>>>(Gu_keep, Gv_keep, k, cross, colres, norm_x_sq, hyper, records);
   return hipGetLastError();
 }
 

@@ -69,3 +69,34 @@ def test_sweep_variants(env, k, x_dtype, monkeypatch):
         monkeypatch.setenv(key, val)
     case = synth.small_case(seed=23, m=900, n=1700, k=k, P=6, order=60, bf16_x=(x_dtype == "bf16"))
     check(case, x_dtype, steps=4)
+
+
+def test_deferred_objective_equals_per_iteration_form(monkeypatch):
+    """The default single-rank iteration is 4 launches: the Gram / column reductions and the pathway terms ride in
+    the sweeps' prologues and the objective records of a batch are evaluated in prmf_end.  PRMF_NO_LAZY_OBJECTIVE=1
+    keeps the per-iteration launches (mid / post / finalize).  Same arithmetic in the same order: U, V and every
+    record must be bit-identical -- also across a call boundary and with k = 13 (unfused path: no difference at all)."""
+    import torch
+    from prmf_amd import PathwayLibrary
+    from prmf_amd.solver import PrmfEngine
+    for (m, n, k, xd) in [(777, 1900, 16, "f32"), (1500, 2600, 64, "bf16"), (300, 1000, 13, "f32"), (640, 900, 128, "bf16")]:
+        case = synth.small_case(seed=5, m=m, n=n, k=k, P=6, order=90, bf16_x=(xd == "bf16"))
+        outs = []
+        for lazy in (True, False):
+            if lazy:
+                monkeypatch.delenv("PRMF_NO_LAZY_OBJECTIVE", raising=False)
+            else:
+                monkeypatch.setenv("PRMF_NO_LAZY_OBJECTIVE", "1")
+            eng = PrmfEngine(m, n, k, x_dtype=xd)
+            eng.set_x(case["X"])
+            eng.set_library(PathwayLibrary.from_edge_lists(n, case["pathways"]))
+            eng.set_active(np.arange(k) % 6)
+            U = eng.device_tensor(case["U0"], torch.float32)
+            V = eng.device_tensor(case["V0"], torch.float32)
+            o1, _ = eng.step(U, V, 4, case["gamma"], case["delta"])
+            eng.set_active((np.arange(k) + 1) % 6)                  # a new round: other pathways
+            o2, _ = eng.step(U, V, 3, case["gamma"], case["delta"])
+            outs.append((U.cpu().numpy(), V.cpu().numpy(), o1 + o2))
+            eng.close()
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (m, n, k)
+        assert outs[0][2] == outs[1][2], (m, n, k)
