@@ -453,20 +453,7 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
     const int64_t tile = base + tslot;
     const int64_t row0 = tile * 32;
     const bool live = tile < ntiles_pack && row0 < m;
-    // issue every load of the tile first (A layout, C/D layout, slabs), then the MFMA chain
-    float p[NT][16], ua[16 * NT], uu[NT][16];
-    if (live && sub == 0) {
-      load_tile_a_layout<NT>(U, m, k, row0, lane, ua);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int col = 32 * t + c, colc = col < k ? col : k - 1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          uu[t][i] = U[(row < m ? row : m - 1) * k + colc];
-        }
-      }
-    }
+    float p[NT][16];
     if constexpr (NT <= 2) {
       if (wpt > 1) {
         if (live) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, p);
@@ -478,7 +465,19 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
     if (tile >= ntiles_pack) continue;
     float un[NT][16];
     if (row0 < m) {
+      // issue every load of the tile first (slabs, A layout, C/D layout), then the MFMA chain
+      float ua[16 * NT], uu[NT][16];
       if (wpt == 1) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, p);
+      load_tile_a_layout<NT>(U, m, k, row0, lane, ua);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = 32 * t + c, colc = col < k ? col : k - 1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          uu[t][i] = U[(row < m ? row : m - 1) * k + colc];
+        }
+      }
       f32x16 den[NT];
       tile_times_gram<NT>(ua, lane, Gs, den);
 #pragma unroll
@@ -552,7 +551,7 @@ hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, con
 // (prmf_runner.py:424-444), in place, + packing + per-wave partial column sums of
 // squares and <Q, V_new> (float64) + (GRAM) V_new^T V_new partials.
 template <int NT, bool BF16, bool GRAM, bool DENSE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, NT <= 2 ? 2 : 1)
 v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ slabs /* DENSE: Q [n][k] */, const uint32_t* __restrict__ segmask,
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gu, const int32_t* __restrict__ pos,
                   const float* __restrict__ gnum, const float* __restrict__ gden, int max_support,
@@ -566,7 +565,9 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
   float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(red_store);
   stage_gram<NT>(Gu, k, 0, k, Gs);
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave index is made provably uniform: tile bases then live in scalar registers and every per-lane
+  // address is one 32-bit offset (the kernel is register-bound: 2 workgroups per CU need <= 256 VGPRs)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int c = lane & 31, h = lane >> 5;
   const int tpw = 4 / wpt, sub = wave % wpt, tslot = wave / wpt;
   double colsq[NT], cross = 0.0;
@@ -584,23 +585,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
     const int64_t tile = base + tslot;
     const int64_t row0 = tile * 32;
     const bool live = tile < ntiles_pack && row0 < n;
-    // every load of the tile is issued before the MFMA chain: V in both layouts, the position map, the slabs
-    float ua[16 * NT], vv[NT][16], q[NT][16];
-    int ps[NT][16];
-    if (live && sub == 0) {
-      load_tile_a_layout<NT>(V, n, k, row0, lane, ua);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int col = 32 * t + c, colc = col < k ? col : k - 1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const int64_t rc = row < n ? row : n - 1;
-          vv[t][i] = V[rc * k + colc];
-          ps[t][i] = pos[rc * k + colc];
-        }
-      }
-    }
+    float q[NT][16];
     if constexpr (NT <= 2 && !DENSE) {
       if (wpt > 1) {
         if (live) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, q);
@@ -626,32 +611,59 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
       } else {
         if (wpt == 1) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);
       }
+      float ua[16 * NT];
+      load_tile_a_layout<NT>(V, n, k, row0, lane, ua);
+      // C/D-layout accesses of this tile: uniform tile base + 32-bit element offset (rows past n re-read the last row)
+      float* const Vt = V + row0 * k;
+      const int32_t* const pt = pos + row0 * k;
+      const int last = (int)((n - row0 < 32 ? n - row0 : 32) - 1);
+      auto cd_off = [&](int t, int i) -> unsigned {
+        const int rr = (i & 3) + 8 * (i >> 2) + 4 * h, col = 32 * t + c;
+        return (unsigned)((rr < last ? rr : last) * k + (col < k ? col : k - 1));
+      };
       f32x16 den[NT];
       tile_times_gram<NT>(ua, lane, Gs, den);
+      // The element-wise update, one 32-column half at a time (register budget: q, den, the new tile and the Gram
+      // accumulators stay live; V in C/D layout, the position map and the gathered pathway terms are per half).
+      // The pathway terms are gathered BRANCH-FREE: entries off the support (98% of them) read element 0 and are
+      // masked out.  As `if (ps >= 0) num += gnum[...]` every (register, column-tile) pair with one supported lane
+      // became its own exec-masked block with a load and an immediate use: ~20 dependent memory round trips per tile.
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int col = 32 * t + c;
+        __builtin_amdgcn_sched_barrier(0);
+        float vv[16], gn[16], gd[16];
+        int ps[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          vv[i] = Vt[cd_off(t, i)];
+          ps[i] = pt[cd_off(t, i)];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const unsigned goff = ps[i] >= 0 ? (unsigned)col * (unsigned)max_support + (unsigned)ps[i] : 0u;
+          gn[i] = gnum[goff];
+          gd[i] = gden[goff];
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          float r2 = 0.f;
-          if (row < n && col < k) {
-            float num = q[t][i], d = den[t][i];
-            if (ps[t][i] >= 0) {
-              num += gnum[(int64_t)col * max_support + ps[t][i]];
-              d += gden[(int64_t)col * max_support + ps[t][i]];
-            }
-            if (d < PRMF_EPS) d = PRMF_EPS;
-            r2 = vv[t][i] * (num / d);
-            if (r2 < PRMF_EPS) r2 = PRMF_EPS;
-            V[row * k + col] = r2;
-            if (vsup && ps[t][i] >= 0) vsup[(int64_t)col * max_support + ps[t][i]] = r2;   // for the deferred objective
-            colsq[t] += (double)r2 * (double)r2;
-            cross += (double)q[t][i] * (double)r2;
-          }
+          const bool on = ps[i] >= 0;
+          const bool valid = row < n && col < k;
+          const float num = q[t][i] + (on ? gn[i] : 0.f);
+          float d = den[t][i] + (on ? gd[i] : 0.f);
+          if (d < PRMF_EPS) d = PRMF_EPS;
+          float r2 = vv[i] * (num / d);
+          if (r2 < PRMF_EPS) r2 = PRMF_EPS;
+          if (!valid) r2 = 0.f;
+          if (valid) Vt[cd_off(t, i)] = r2;
+          if (vsup && on && valid) vsup[(unsigned)col * (unsigned)max_support + (unsigned)ps[i]] = r2;   // for the deferred objective
+          colsq[t] += (double)r2 * (double)r2;
+          cross += (double)(valid ? q[t][i] : 0.f) * (double)r2;
           vn[t][i] = r2;
         }
       }
+      if constexpr (NT > 1) __builtin_amdgcn_sched_barrier(0);
       if constexpr (GRAM) gram_accumulate<NT>(vn, g);
     } else {
 #pragma unroll

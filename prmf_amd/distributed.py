@@ -89,6 +89,8 @@ class DistributedPrmf(object):
             native = self.world > 1 and dist.get_backend(group) == "nccl" and hasattr(engine, "comm_init")
         self.native = False
         if native:
+            # engine.comm_init decides collectively: it either succeeds on every rank or raises on every rank, so the
+            # fallback below is taken by all ranks together (never a mix of nccl* calls and torch.distributed calls)
             try:
                 engine.comm_init(group)
                 self.native = True

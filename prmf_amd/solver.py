@@ -248,22 +248,39 @@ class PrmfEngine(object):
     # -- collectives inside the library (RCCL on the stream; no per-iteration host work) ----
     def comm_init(self, group=None):
         """Create this rank's RCCL communicator inside the library: rank 0 draws the
-        unique id, torch.distributed broadcasts the 128 bytes, every rank joins."""
+        unique id, torch.distributed broadcasts the 128 bytes, every rank joins.
+
+        Every decision is taken COLLECTIVELY so that no rank ends up inside ncclCommInitRank (or later inside
+        prmf_step_dist's nccl* calls) while another one has fallen back: (1) every rank checks that the library can
+        bind RCCL at all and the flags are MIN-reduced before anything else; (2) after ncclCommInitRank the result
+        flags are MIN-reduced again.  Any failure raises PrmfError on EVERY rank."""
         torch = self.torch
         idbuf = np.zeros(_capi.PRMF_COMM_ID_BYTES, dtype=np.uint8)
         if self.nranks == 1:
             self._check_create(self.lib.prmf_comm_unique_id(_ptr(idbuf)))
-        else:
-            import torch.distributed as dist
-            if dist.get_rank(group) == 0:
-                self._check_create(self.lib.prmf_comm_unique_id(_ptr(idbuf)))
-            on_gpu = dist.get_backend(group) == "nccl"
-            t = torch.from_numpy(idbuf)
-            if on_gpu:
-                t = t.to("cuda:%d" % self.device)
-            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            idbuf = t.cpu().numpy().copy()
-        self._check(self.lib.prmf_comm_init(self.ctx, _ptr(idbuf)))
+            self._check(self.lib.prmf_comm_init(self.ctx, _ptr(idbuf)))
+            self._native_comm = True
+            return
+        import torch.distributed as dist
+        on_gpu = dist.get_backend(group) == "nccl"
+        cdev = "cuda:%d" % self.device if on_gpu else "cpu"
+
+        def all_ok(local_ok, what):
+            flag = torch.tensor([1 if local_ok else 0], dtype=torch.int32, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 0:
+                raise _capi.PrmfError(_capi.PRMF_ERR_UNSUPPORTED,
+                                      "%s failed on at least one rank (this rank: %s); no rank uses the in-library collectives"
+                                      % (what, "ok" if local_ok else self.lib.prmf_last_error(None).decode()))
+
+        scratch = np.zeros(_capi.PRMF_COMM_ID_BYTES, dtype=np.uint8)
+        rc = self.lib.prmf_comm_unique_id(_ptr(idbuf if dist.get_rank(group) == 0 else scratch))   # binds librccl
+        all_ok(rc == _capi.PRMF_OK, "binding RCCL (prmf_comm_unique_id)")
+        t = torch.from_numpy(idbuf).to(cdev)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        idbuf = t.cpu().numpy().copy()
+        rc = self.lib.prmf_comm_init(self.ctx, _ptr(idbuf))
+        all_ok(rc == _capi.PRMF_OK, "prmf_comm_init (ncclCommInitRank)")
         self._native_comm = True
 
     def _check_create(self, rc):
