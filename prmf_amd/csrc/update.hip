@@ -641,7 +641,8 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const unsigned goff = ps[i] >= 0 ? (unsigned)col * (unsigned)max_support + (unsigned)ps[i] : 0u;
+          // columns past k read the position map of column k - 1 (cd_off clamps): clamp the column here too
+          const unsigned goff = ps[i] >= 0 ? (unsigned)(col < k ? col : k - 1) * (unsigned)max_support + (unsigned)ps[i] : 0u;
           gn[i] = gnum[goff];
           gd[i] = gden[goff];
         }
