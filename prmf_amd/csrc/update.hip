@@ -425,6 +425,50 @@ __device__ __forceinline__ void gram_block_store(const f32x16 (&g)[NT * (NT + 1)
     }
 }
 
+// Per-round form of the workgroup Gram partial.  Carrying the NP x 16 accumulator registers of gram_accumulate
+// across the tile loop costs 48 registers at k = 64 for the whole kernel -- with them the fused epilogues need
+// 300 registers and one workgroup per CU (or spill).  Here the tile's Gram is formed in fresh accumulators (live only
+// after the update), summed over the 4 waves through LDS in wave order, and added to a running total of 4 floats per
+// 32x32 block per thread (thread (wave, lane) keeps registers i = 4 wave .. 4 wave + 3 of every block).
+// Every wave of the workgroup calls this once per loop round (2 barriers per block).
+template <int NT>
+__device__ __forceinline__ void gram_round(const f32x16 (&gt)[NT * (NT + 1) / 2], float (&gtot)[NT * (NT + 1) / 2][4],
+                                           float (*red)[16][64], int wave, int lane) {
+  constexpr int NP = NT * (NT + 1) / 2;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][i][lane] = gt[p][i];
+    __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const int i = 4 * wave + ii;
+      gtot[p][ii] += ((red[0][i][lane] + red[1][i][lane]) + red[2][i][lane]) + red[3][i][lane];
+    }
+    __syncthreads();
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void gram_total_store(const float (&gtot)[NT * (NT + 1) / 2][4], int k, float* __restrict__ out,
+                                                 int wave, int lane) {
+  const int c = lane & 31, h = lane >> 5;
+  int p = 0;
+#pragma unroll
+  for (int t1 = 0; t1 < NT; ++t1)
+#pragma unroll
+    for (int t2 = t1; t2 < NT; ++t2, ++p)
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = 4 * wave + ii;
+        const int a = 32 * t1 + (i & 3) + 8 * (i >> 2) + 4 * h, b = 32 * t2 + c;
+        if (a < k && b < k) {
+          out[a * k + b] = gtot[p][ii];
+          if (t1 != t2) out[b * k + a] = gtot[p][ii];
+        }
+      }
+}
+
 // GRAM: also accumulate F_new^T F_new (per-workgroup partial [k*k] floats at gram_partial[blockIdx])
 template <int NT, bool BF16, bool GRAM>
 __global__ void __launch_bounds__(256, NT <= 2 ? 2 : 1)
@@ -438,46 +482,49 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
   float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(red_store);
   stage_gram<NT>(Gv, k, 0, k, Gs);
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave index is made provably uniform: tile bases then live in scalar registers
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int c = lane & 31, h = lane >> 5;
   const int tpw = 4 / wpt, sub = wave % wpt, tslot = wave / wpt;
-  f32x16 g[GRAM ? NP : 1];
-  if constexpr (GRAM) {
+  float gtot[GRAM ? NP : 1][4];
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
+  for (int p = 0; p < (GRAM ? NP : 1); ++p)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) g[p][i] = 0.f;
-  }
-  // uniform trip count over the workgroup (the cooperative sum has barriers): a slot past the end does nothing
+    for (int ii = 0; ii < 4; ++ii) gtot[p][ii] = 0.f;
+  // uniform trip count over the workgroup (the cooperative sum and the Gram round have barriers)
   for (int64_t base = (int64_t)blockIdx.x * tpw; base < ntiles_pack; base += (int64_t)gridDim.x * tpw) {
     const int64_t tile = base + tslot;
     const int64_t row0 = tile * 32;
     const bool live = tile < ntiles_pack && row0 < m;
+    const bool lead = tile < ntiles_pack && sub == 0;            // this wave finishes the tile
     float p[NT][16];
     if constexpr (NT <= 2) {
       if (wpt > 1) {
         if (live) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, p);
         else load_slab_tile<NT>(slabs, slab_stride, 0u, tile, lane, p);
         combine_tile_sums<NT>(p, wpt, sub, wave, lane, red_store);
-        if (sub != 0) continue;
       }
     }
-    if (tile >= ntiles_pack) continue;
     float un[NT][16];
-    if (row0 < m) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) un[t][i] = 0.f;
+    if (lead && live) {
       // issue every load of the tile first (slabs, A layout, C/D layout), then the MFMA chain
       float ua[16 * NT], uu[NT][16];
       if (wpt == 1) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, p);
       load_tile_a_layout<NT>(U, m, k, row0, lane, ua);
+      float* const Ut = U + row0 * k;
+      const int last = (int)((m - row0 < 32 ? m - row0 : 32) - 1);
+      auto cd_off = [&](int t, int i) -> unsigned {
+        const int rr = (i & 3) + 8 * (i >> 2) + 4 * h, col = 32 * t + c;
+        return (unsigned)((rr < last ? rr : last) * k + (col < k ? col : k - 1));
+      };
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int col = 32 * t + c, colc = col < k ? col : k - 1;
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          uu[t][i] = U[(row < m ? row : m - 1) * k + colc];
-        }
-      }
+        for (int i = 0; i < 16; ++i) uu[t][i] = Ut[cd_off(t, i)];
       f32x16 den[NT];
       tile_times_gram<NT>(ua, lane, Gs, den);
 #pragma unroll
@@ -486,25 +533,27 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          float r2 = 0.f;
-          if (row < m && col < k) {
-            const float d = den[t][i] + uu[t][i];             // U (V^T V) + U      (prmf_runner.py:421)
-            r2 = uu[t][i] * ((d != 0.f) ? p[t][i] / d : 1.f);  // 0/0 := 1           (:422)
-            U[row * k + col] = r2;
-          }
+          const bool valid = row < m && col < k;
+          const float d = den[t][i] + uu[t][i];                      // U (V^T V) + U      (prmf_runner.py:421)
+          float r2 = uu[t][i] * ((d != 0.f) ? p[t][i] / d : 1.f);    // 0/0 := 1           (:422)
+          if (!valid) r2 = 0.f;
+          if (valid) Ut[cd_off(t, i)] = r2;
           un[t][i] = r2;
         }
       }
-      if constexpr (GRAM) gram_accumulate<NT>(un, g);
-    } else {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) un[t][i] = 0.f;
     }
-    pack_tile_from_cd<NT, BF16>(un, row0, lane, packed);
+    if (lead) pack_tile_from_cd<NT, BF16>(un, row0, lane, packed);   // tiles past m are packed as zeros
+    if constexpr (GRAM) {
+      f32x16 gt[NP];
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gt[q][i] = 0.f;
+      if (lead && live) gram_accumulate<NT>(un, gt);
+      gram_round<NT>(gt, gtot, red, wave, lane);
+    }
   }
-  if constexpr (GRAM) gram_block_store<NT>(g, k, gram_partial + (int64_t)blockIdx.x * k * k, red);
+  if constexpr (GRAM) gram_total_store<NT>(gtot, k, gram_partial + (int64_t)blockIdx.x * k * k, wave, lane);
 }
 
 // waves that share one 32-row tile in the fused epilogues (see my_segments): as many as keep the launch within the
@@ -573,46 +622,31 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
   double colsq[NT], cross = 0.0;
 #pragma unroll
   for (int t = 0; t < NT; ++t) colsq[t] = 0.0;
-  f32x16 g[GRAM ? NP : 1];
-  if constexpr (GRAM) {
+  float gtot[GRAM ? NP : 1][4];
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
+  for (int p = 0; p < (GRAM ? NP : 1); ++p)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) g[p][i] = 0.f;
-  }
-  // uniform trip count over the workgroup (the cooperative sum has barriers): a slot past the end does nothing
+    for (int ii = 0; ii < 4; ++ii) gtot[p][ii] = 0.f;
+  // uniform trip count over the workgroup (the cooperative sum and the Gram round have barriers)
   for (int64_t base = (int64_t)blockIdx.x * tpw; base < ntiles_pack; base += (int64_t)gridDim.x * tpw) {
     const int64_t tile = base + tslot;
     const int64_t row0 = tile * 32;
     const bool live = tile < ntiles_pack && row0 < n;
+    const bool lead = tile < ntiles_pack && sub == 0;            // this wave finishes the tile
     float q[NT][16];
     if constexpr (NT <= 2 && !DENSE) {
       if (wpt > 1) {
         if (live) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, q);
         else load_slab_tile<NT>(slabs, slab_stride, 0u, tile, lane, q);
         combine_tile_sums<NT>(q, wpt, sub, wave, lane, red_store);
-        if (sub != 0) continue;
       }
     }
-    if (tile >= ntiles_pack) continue;
     float vn[NT][16];
-    if (row0 < n) {
-      if constexpr (DENSE) {
-        // Q already summed over segments and ranks (replicated multi-rank V update): row-major [n][k]
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int col = 32 * t + c, colc = col < k ? col : k - 1;
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            q[t][i] = slabs[(row < n ? row : n - 1) * k + colc];
-          }
-        }
-      } else {
-        if (wpt == 1) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);
-      }
-      float ua[16 * NT];
-      load_tile_a_layout<NT>(V, n, k, row0, lane, ua);
+      for (int i = 0; i < 16; ++i) vn[t][i] = 0.f;
+    if (lead && live) {
       // C/D-layout accesses of this tile: uniform tile base + 32-bit element offset (rows past n re-read the last row)
       float* const Vt = V + row0 * k;
       const int32_t* const pt = pos + row0 * k;
@@ -621,17 +655,29 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
         const int rr = (i & 3) + 8 * (i >> 2) + 4 * h, col = 32 * t + c;
         return (unsigned)((rr < last ? rr : last) * k + (col < k ? col : k - 1));
       };
+      if constexpr (DENSE) {
+        // Q already summed over segments and ranks (replicated multi-rank V update): row-major [n][k]
+        const float* const Qt = slabs + row0 * k;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) q[t][i] = Qt[cd_off(t, i)];
+      } else {
+        if (wpt == 1) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);
+      }
+      float ua[16 * NT];
+      load_tile_a_layout<NT>(V, n, k, row0, lane, ua);
       f32x16 den[NT];
       tile_times_gram<NT>(ua, lane, Gs, den);
-      // The element-wise update, one 32-column half at a time (register budget: q, den, the new tile and the Gram
-      // accumulators stay live; V in C/D layout, the position map and the gathered pathway terms are per half).
+      // The element-wise update, one 32-column half at a time (register budget: q, den and the new tile stay live;
+      // V in C/D layout, the position map and the gathered pathway terms are per half).
       // The pathway terms are gathered BRANCH-FREE: entries off the support (98% of them) read element 0 and are
       // masked out.  As `if (ps >= 0) num += gnum[...]` every (register, column-tile) pair with one supported lane
-      // became its own exec-masked block with a load and an immediate use: ~20 dependent memory round trips per tile.
+      // became its own exec-masked block with a load and an immediate use: a chain of dependent memory round trips.
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int col = 32 * t + c;
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NT > 1) __builtin_amdgcn_sched_barrier(0);
         float vv[16], gn[16], gd[16];
         int ps[16];
 #pragma unroll
@@ -664,15 +710,17 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
           vn[t][i] = r2;
         }
       }
-      if constexpr (NT > 1) __builtin_amdgcn_sched_barrier(0);
-      if constexpr (GRAM) gram_accumulate<NT>(vn, g);
-    } else {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) vn[t][i] = 0.f;
     }
-    pack_tile_from_cd<NT, BF16>(vn, row0, lane, packed);
+    if (lead) pack_tile_from_cd<NT, BF16>(vn, row0, lane, packed);   // tiles past n are packed as zeros
+    if constexpr (GRAM) {
+      f32x16 gt[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gt[p][i] = 0.f;
+      if (lead && live) gram_accumulate<NT>(vn, gt);
+      gram_round<NT>(gt, gtot, red, wave, lane);
+    }
   }
   // per-wave partials: column sums from the two half-waves, cross over all lanes (fixed order)
   double* out = partial + ((int64_t)blockIdx.x * 4 + wave) * (k + 1);
@@ -684,7 +732,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) cross += __shfl_xor(cross, off);
   if (lane == 0) out[k] = cross;
-  if constexpr (GRAM) gram_block_store<NT>(g, k, gram_partial + (int64_t)blockIdx.x * k * k, red);
+  if constexpr (GRAM) gram_total_store<NT>(gtot, k, gram_partial + (int64_t)blockIdx.x * k * k, wave, lane);
 }
 
 int v_epilogue_waves(int64_t n, int wpt) { return epilogue_blocks(round_up(n, K_PAD), wpt) * 4; }
