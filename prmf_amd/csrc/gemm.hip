@@ -248,6 +248,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PRMF_LOADS_FIRST 1
 #endif
 constexpr bool LOADS_FIRST = PRMF_LOADS_FIRST != 0;
+#ifndef PRMF_B_GLDS
+#define PRMF_B_GLDS 1
+#endif
+// The packed factor chunk goes L2 -> LDS by LDS-DMA where it is double-buffered (k <= 64): no staging registers and no
+// ds_write pass for the 16 KiB per chunk every workgroup stages (tools/stream_ladder2.hip priced that hop at 8% of the sweep)
+constexpr bool B_GLDS = PRMF_B_GLDS != 0;
 
 template <int MT>
 __device__ __forceinline__ void load_a_chunk(u32x4 (&dst)[MT][4], const unsigned (&voff)[MT][4], const uint4* base) {
@@ -268,6 +274,19 @@ __device__ __forceinline__ void load_b_chunk(u32x4 (&dst)[NB], const uint4* base
 #pragma unroll
   for (int i = 0; i < NB; ++i)
     if ((i + 1) * NTHREADS <= BCH || tid + NTHREADS * i < BCH) dst[i] = b[tid + NTHREADS * i];
+}
+
+// The same slice assignment as load_b_chunk / store_b_chunk, but global memory -> LDS directly (LDS-DMA,
+// global_load_lds_dwordx4): no staging registers, no ds_write pass.  The LDS destination of a wave instruction is a
+// wave-uniform base + 16 B x lane, which is exactly the linear image of the packed chunk.  BCH must be a multiple of
+// the thread count (true for every bf16-packed chunk: 512 NT uint4; f32-packed: 256 NT).
+template <int NB, int NTHREADS, int BCH>
+__device__ __forceinline__ void glds_b_chunk(u32x4* sb, const uint4* base, int tid, int wave) {
+  static_assert(BCH % NTHREADS == 0, "LDS-DMA staging needs whole slices");
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    __builtin_amdgcn_global_load_lds((const void*)(base + tid + NTHREADS * i),
+                                     (__attribute__((address_space(3))) void*)(sb + wave * 64 + NTHREADS * i), 16, 0, 0);
 }
 
 template <int NB, int NTHREADS, int BCH>
@@ -310,7 +329,8 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
     }
   }
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  constexpr bool GLDS = B_GLDS && BDB && (BCH % NTHR == 0);
 
   // Balanced, XCD-aware persistent decomposition.  The launch has one workgroup per
   // resident slot.  The reduction range (ngroups chunk pairs) is cut into `nx` slices
@@ -377,9 +397,10 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   u32x4 bs[BPT];
 
   // prologue: B(0), A(0) -> LDS
-  load_b_chunk<BPT, NTHR, BCH>(bs, bbase, tid);
+  if constexpr (GLDS) glds_b_chunk<BPT, NTHR, BCH>(sB[0], bbase, tid, wave);
+  else load_b_chunk<BPT, NTHR, BCH>(bs, bbase, tid);
   load_a_chunk<MT>(a, avoff, abase);
-  store_b_chunk<BPT, NTHR, BCH>(sB[0], bs, tid);
+  if constexpr (!GLDS) store_b_chunk<BPT, NTHR, BCH>(sB[0], bs, tid);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -390,21 +411,25 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int cn = min(c + u + 1, last);
+      // LDS-DMA form: B(c+1) lands in the other LDS buffer while B(c) is read (last read of that buffer: chunk c-1,
+      // which every wave finished before the barrier that ended it); it is complete before the barrier below, which
+      // waits vmcnt(0) (the A registers are consumed right before it)
+      if constexpr (GLDS) glds_b_chunk<BPT, NTHR, BCH>(sB[u ^ 1], bbase + (int64_t)cn * BCH, tid, wave);
       if constexpr (LOADS_FIRST && MODE != 2) {
         // the next chunk's loads are in flight while this chunk is computed from LDS
-        load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
+        if constexpr (!GLDS) load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
         load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
         __builtin_amdgcn_sched_barrier(0);
       }
       sweep_compute<MODE, MT, NT>(acc, acc_lo, myA, sB[BDB ? u : 0], lane);
       if constexpr (!(LOADS_FIRST && MODE != 2)) {
-        load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
+        if constexpr (!GLDS) load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
         load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
       } else {
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (!BDB) __syncthreads();          // everyone has finished reading B(c)
-      store_b_chunk<BPT, NTHR, BCH>(sB[BDB ? (u ^ 1) : 0], bs, tid);
+      if constexpr (!GLDS) store_b_chunk<BPT, NTHR, BCH>(sB[BDB ? (u ^ 1) : 0], bs, tid);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
