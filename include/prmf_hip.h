@@ -169,7 +169,7 @@ typedef struct prmf_comm_sizes {
  *   PRMF_DIST_REPLICATED (default for nranks > 1): every rank updates all of V.
  *       phase_u; all_reduce(gram, float64 sum); phase_q; all_reduce(q_send, float32 sum, in place;
  *       q_recv aliases q_send, n*k floats); phase_v; phase_post.  v_send / v_recv are not exchanged.
- *   PRMF_DIST_COLUMN_SHARDED (PRMF_FLAG_COLUMN_SHARDED at creation, or PRMF_DIST_MODE=colshard): rank r
+ *   PRMF_DIST_COLUMN_SHARDED (PRMF_FLAG_COLUMN_SHARDED at creation): rank r
  *       updates latent columns [r*kc, (r+1)*kc) and their pathway Laplacians.
  *       phase_u; all_reduce(gram); phase_q; reduce_scatter(q_send -> q_recv, sum); phase_v;
  *       all_gather(v_send -> v_recv); phase_post. */
@@ -268,6 +268,12 @@ int prmf_get_sweep_info(const prmf_ctx* ctx, prmf_sweep_info* out);
  * timing enabled (PRMF_FLAG_TIMING at creation or prmf_set_timing). */
 #define PRMF_FLAG_TIMING 0x1u
 #define PRMF_FLAG_COLUMN_SHARDED 0x2u   /* nranks > 1: shard the V update by latent columns (see prmf_comm_sizes) */
+/* Single rank, tradeoff off: by default the iteration is 4 launches (the k x k reductions and the pathway terms run as
+ * prologues of the two sweeps) and the objective records of all iterations since prmf_begin are evaluated in prmf_end
+ * from per-iteration state kept on the device -- same arithmetic, bit-identical records.  This flag keeps the
+ * per-iteration evaluation (three more launches per iteration): the form the tradeoff feedback (prmf_runner.py:542-548)
+ * and the multi-rank phases always use. */
+#define PRMF_FLAG_EAGER_OBJECTIVE 0x4u
 /* Switch the per-launch event timing on or off after creation (bench.py times its
  * throughput run without events and a second short run with them). */
 int prmf_set_timing(prmf_ctx* ctx, int enabled);

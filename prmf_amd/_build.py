@@ -56,5 +56,32 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, defines):
+    """Experimental build with extra -D flags -> prmf_amd/lib/variants/libprmf_hip_<name>.so (tools/ab_sweep.py)."""
+    vdir = os.path.join(LIBDIR, "variants")
+    objdir = os.path.join(vdir, "obj_" + name)
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+    out = os.path.join(vdir, "libprmf_hip_%s.so" % name)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        r = subprocess.run([cc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s" % r.stderr)
+    return out
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # python -m prmf_amd._build --variant NAME DEF1=1 DEF2=0 ...
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

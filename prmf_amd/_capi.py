@@ -15,6 +15,7 @@ PRMF_X_F32, PRMF_X_BF16 = 0, 1
 PRMF_OBJ_STRIDE = 8
 PRMF_FLAG_TIMING = 0x1
 PRMF_FLAG_COLUMN_SHARDED = 0x2
+PRMF_FLAG_EAGER_OBJECTIVE = 0x4
 PRMF_DIST_COLUMN_SHARDED, PRMF_DIST_REPLICATED = 0, 1
 PRMF_COMM_ID_BYTES = 128
 OBJ_KEYS = ("recon", "manifold", "ignore", "fro", "gamma", "delta", "obj")
@@ -84,7 +85,9 @@ def load(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    # PRMF_HIP_LIB: another build of the SAME library (tools/ab_sweep.py compares kernel variants in one GPU session);
+    # it is still libprmf_hip -- there is no other implementation to fall back to
+    p = path or os.environ.get("PRMF_HIP_LIB") or LIB_PATH
     # PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64.  libprmf_hip.so
     # must share that HIP runtime instance (torch owns the device buffers and the
     # stream), so torch is always loaded first: the dynamic loader then resolves our

@@ -117,17 +117,12 @@ struct prmf_ctx {
   double ms_xv = 0, ms_xtu = 0, ms_total = 0;
   int timed_iters = 0;
 
-  // The small kernels between the sweeps (Gram reductions, pathway terms, objective pieces, record) are not on
-  // the sweeps' dependency chain: inside prmf_step / prmf_step_dist they CAN run on `aux` next to the following
-  // sweep, joined where their results are first read (U epilogue: V^T V; V epilogue: U^T U + pathway terms;
-  // prmf_end: records).  Measured: each cross-stream event edge costs about 5 us, four per iteration:
-  // +0.8% at 50000x20000 k=64 (27 us hidden), neutral at 25000x25000 k=128, -15% at 5000x10000 k=16 -- so it
-  // is OFF by default (PRMF_OVERLAP_SMALL=1 turns it on).  The multi-rank step uses `aux` for the k x k
-  // all-reduce either way.  Never used by the caller-driven phase interface, whose collectives run on the
-  // caller's stream between the phase calls.
+  // Auxiliary stream: in the multi-rank step the latency-bound k x k all-reduce of U^T U runs here next to the
+  // X^T U sweep and is joined before phase_v (prmf_step_dist).  (Round 1 could also move the single-rank small
+  // kernels here; every cross-stream event edge cost ~5 us, more than it hid -- they are sweep prologues now.)
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_post = nullptr;
-  bool internal_driver = false, overlap_small = false;
+  bool internal_driver = false;
   bool mid_pending = false, post_pending = false;
 
   // RCCL (resolved at run time, see prmf_comm_init)
@@ -327,10 +322,6 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   c->rank = rank;
   c->flags = flags;
   c->replicated = nranks > 1 && !(flags & PRMF_FLAG_COLUMN_SHARDED);
-  if (const char* e = getenv("PRMF_DIST_MODE")) {
-    if (!std::strcmp(e, "colshard")) c->replicated = false;
-    else if (!std::strcmp(e, "replicated")) c->replicated = nranks > 1;
-  }
   c->lr = c->replicated ? 1 : nranks;
   c->kc = (k + c->lr - 1) / c->lr;
   c->col0 = (c->replicated ? 0 : rank) * c->kc;
@@ -350,14 +341,15 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { fail(c, PRMF_ERR_HIP, "hipGetDeviceProperties failed"); return bail(PRMF_ERR_HIP); }
   const int n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  c->plan_xv = plan_gemm(x_dtype, m_local > 0 ? m_local : 1, c->Kpad_x, c->NT, n_cus);
-  c->plan_xtu = plan_gemm(x_dtype, n, c->Kpad_xt, c->NT, n_cus);
-  // f32 X at k <= 64 (default workgroup shape): the sweep splits every f32 value of X exactly into three bf16 pieces
-  // in registers and runs the bf16 MFMA against the hi/lo-packed factor (5 products, cross terms in their own
-  // accumulators) instead of the f32 MFMA at 1/16 of the rate: 0.75 vs 1.05 ms per sweep at 50000 x 20000, and a smaller
-  // error (P = X V: rms 2.9e-7 against 7.4e-7, no bias).  PRMF_F32_SPLIT=0 keeps the f32 MFMA.
-  c->split_f32 = x_dtype == PRMF_X_F32 && c->NT <= 2 && c->plan_xv.mt == 2 && c->plan_xv.nw == 4 && c->plan_xv.bdb &&
-                 !(getenv("PRMF_F32_SPLIT") && atoi(getenv("PRMF_F32_SPLIT")) == 0);
+  SweepTuning tune;                                     // the library's only tuning hook, for the decomposition test
+  if (const char* e = getenv("PRMF_SWEEP_XCD")) tune.force_slices = atoi(e);
+  c->plan_xv = plan_gemm(x_dtype, m_local > 0 ? m_local : 1, c->Kpad_x, c->NT, n_cus, tune);
+  c->plan_xtu = plan_gemm(x_dtype, n, c->Kpad_xt, c->NT, n_cus, tune);
+  // f32 X at k <= 64: the sweep splits every f32 value of X exactly into three bf16 pieces in registers and runs the
+  // bf16 MFMA against the hi/lo-packed factor (5 products, cross terms in their own accumulators) instead of the f32
+  // MFMA at 1/16 of the rate: 0.75 vs 1.05 ms per sweep at 50000 x 20000, and a smaller error (P = X V: rms 2.9e-7
+  // against 7.4e-7, no bias).  k > 64 keeps the f32 MFMA (two accumulator sets do not fit the registers).
+  c->split_f32 = x_dtype == PRMF_X_F32 && c->NT <= 2;
   c->pack_dtype = c->split_f32 ? PRMF_X_BF16 : x_dtype;
   // slabs are written as whole 32-row tiles of whole panels (fragment order, no row masking)
   c->slab_stride_p = (int64_t)c->plan_xv.panels * c->plan_xv.panel_rows * c->KP;
@@ -381,7 +373,7 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, &c->Gv, (size_t)k * k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->active_dev, (size_t)k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->pos, (size_t)n * c->kc, false))) return bail(rc);
-  c->fused_u = (k % 4 == 0) && !getenv("PRMF_NO_FUSED_EPILOGUE");
+  c->fused_u = (k % 4 == 0);
   c->fused_v = c->fused_u && c->lr == 1;
   c->wpt_u = epilogue_wpt(c->Kpad_xt, c->plan_xv.max_seg, c->NT);
   c->wpt_v = epilogue_wpt(c->Kpad_x, c->plan_xtu.max_seg, c->NT);
@@ -410,7 +402,6 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
     fail(c, PRMF_ERR_HIP, "aux stream / events could not be created");
     return bail(PRMF_ERR_HIP);
   }
-  if (const char* e = getenv("PRMF_OVERLAP_SMALL")) c->overlap_small = atoi(e) != 0;
   if ((flags & PRMF_FLAG_TIMING) && (rc = prmf_set_timing(c, 1))) return bail(rc);
   *out = c;
   return PRMF_OK;
@@ -652,7 +643,7 @@ int prmf_begin(prmf_ctx* c, float* dU, float* dV, double gamma, double delta, do
   // objective deferred to prmf_end + reductions folded into the sweeps: single rank, fused MFMA epilogues, default
   // 4-wave sweep workgroups, tradeoff feedback off (with it on, gamma/delta of step t+1 need the record of step t)
   c->lazy = c->nranks == 1 && c->m > 0 && c->fused_u && c->fused_v && !(tradeoff >= 0.0) && c->plan_xv.nw == 4 &&
-            c->plan_xtu.nw == 4 && c->vsup_ring && !c->dist_driver && !getenv("PRMF_NO_LAZY_OBJECTIVE");
+            c->plan_xtu.nw == 4 && c->vsup_ring && !c->dist_driver && !(c->flags & PRMF_FLAG_EAGER_OBJECTIVE);
   c->batch_open = true;
   return PRMF_OK;
 }
@@ -703,17 +694,8 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
         // one launch: reduce (this rank's) U^T U and compute the pathway terms of the own columns
         // (they depend on the old V and gamma/delta only); next to the X^T U sweep when driven internally
         hipStream_t ms = s;
-        if (c->internal_driver && c->overlap_small) {
-          HIP_TRY(c, hipEventRecord(c->ev_fork, s));
-          HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-          ms = c->aux;
-        }
         HIP_TRY(c, launch_mid((const float*)c->gram_partial, epilogue_blocks(c->Kpad_xt, c->wpt_u), c->k, c->gram_buf, c->lib,
                               c->active_dev, c->col0, c->ncols, c->V, c->hyper, c->gnum, c->gden, ms));
-        if (ms != s) {
-          HIP_TRY(c, hipEventRecord(c->ev_mid, c->aux));
-          c->mid_pending = true;
-        }
         c->graph_done = true;
         return PRMF_OK;
       }
@@ -836,19 +818,10 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
     // V^T V, the objective pieces and the record are first read by the NEXT iteration's U epilogue (and by
     // prmf_end): next to the following X V sweep when driven internally
     hipStream_t ps = s;
-    if (c->internal_driver && c->overlap_small) {
-      HIP_TRY(c, hipEventRecord(c->ev_fork, s));
-      HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-      ps = c->aux;
-    }
     HIP_TRY(c, launch_post((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x, c->wpt_v), c->k, c->Gv, c->lib, c->active_dev, c->V,
                            c->vpartial, c->vblocks, c->colres, c->obj_scratch, ps));
     HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->lr, c->v_send_floats, c->extras_off, c->norm_x_sq,
                                c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, c->vpartial, c->vblocks, c->colres, ps));
-    if (ps != s) {
-      HIP_TRY(c, hipEventRecord(c->ev_post, c->aux));
-      c->post_pending = true;
-    }
     c->cursor++;
     return PRMF_OK;
   }
@@ -984,7 +957,7 @@ int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma,
   if (n_steps < 0) return fail(c, PRMF_ERR_ARG, "n_steps < 0");
   hipStream_t s = (hipStream_t)stream;
   const RcclApi& N = rccl();
-  const bool overlap = c->aux && !(getenv("PRMF_DIST_OVERLAP") && atoi(getenv("PRMF_DIST_OVERLAP")) == 0);
+  const bool overlap = c->aux != nullptr;
   int done = 0, rc;
   struct Internal {
     prmf_ctx* c;

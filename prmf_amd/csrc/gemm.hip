@@ -21,15 +21,14 @@
 //   C   per-split partial slabs [split][M][KP] f32, summed by the consumer kernel
 //       in a fixed order (deterministic; no atomics).
 //
-// Wave tiling (wave64): each wave owns MT 32-row tiles x NT 32-column tiles of
-// accumulators (v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32).  The A
-// fragment of lane (r = lane&31, h = lane>>5) is 16 contiguous bytes of row r, so
-// A goes straight from global memory to registers (streamed once, never shared
-// between waves: no LDS round trip), PF chunks ahead of the MFMAs.
+// Wave tiling (wave64): a workgroup is 4 waves x 64 rows; each wave owns MT = 2 32-row tiles x NT 32-column tiles of
+// accumulators (v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32), so every B fragment read from LDS feeds two MFMAs.
+// A is loaded line-complete (8 rows x 128 B per wave instruction, non-temporal), one chunk ahead of the MFMAs, and
+// bounced through a wave-private XOR-swizzled LDS tile from which the 16-B A fragments are read (see "A path" below:
+// fragment-shaped global loads were 22% slower).  B is staged once per workgroup per chunk through registers into LDS.
 #include "kernels.h"
 #include "prologue.h"
 
-#include <cstdlib>
 
 namespace prmf {
 
@@ -248,12 +247,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PRMF_LOADS_FIRST 1
 #endif
 constexpr bool LOADS_FIRST = PRMF_LOADS_FIRST != 0;
-#ifndef PRMF_B_GLDS
-#define PRMF_B_GLDS 1
-#endif
-// The packed factor chunk goes L2 -> LDS by LDS-DMA where it is double-buffered (k <= 64): no staging registers and no
-// ds_write pass for the 16 KiB per chunk every workgroup stages (tools/stream_ladder2.hip priced that hop at 8% of the sweep)
-constexpr bool B_GLDS = PRMF_B_GLDS != 0;
 
 template <int MT>
 __device__ __forceinline__ void load_a_chunk(u32x4 (&dst)[MT][4], const unsigned (&voff)[MT][4], const uint4* base) {
@@ -274,19 +267,6 @@ __device__ __forceinline__ void load_b_chunk(u32x4 (&dst)[NB], const uint4* base
 #pragma unroll
   for (int i = 0; i < NB; ++i)
     if ((i + 1) * NTHREADS <= BCH || tid + NTHREADS * i < BCH) dst[i] = b[tid + NTHREADS * i];
-}
-
-// The same slice assignment as load_b_chunk / store_b_chunk, but global memory -> LDS directly (LDS-DMA,
-// global_load_lds_dwordx4): no staging registers, no ds_write pass.  The LDS destination of a wave instruction is a
-// wave-uniform base + 16 B x lane, which is exactly the linear image of the packed chunk.  BCH must be a multiple of
-// the thread count (true for every bf16-packed chunk: 512 NT uint4; f32-packed: 256 NT).
-template <int NB, int NTHREADS, int BCH>
-__device__ __forceinline__ void glds_b_chunk(u32x4* sb, const uint4* base, int tid, int wave) {
-  static_assert(BCH % NTHREADS == 0, "LDS-DMA staging needs whole slices");
-#pragma unroll
-  for (int i = 0; i < NB; ++i)
-    __builtin_amdgcn_global_load_lds((const void*)(base + tid + NTHREADS * i),
-                                     (__attribute__((address_space(3))) void*)(sb + wave * 64 + NTHREADS * i), 16, 0, 0);
 }
 
 template <int NB, int NTHREADS, int BCH>
@@ -329,8 +309,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
     }
   }
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-  constexpr bool GLDS = B_GLDS && BDB && (BCH % NTHR == 0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // Balanced, XCD-aware persistent decomposition.  The launch has one workgroup per
   // resident slot.  The reduction range (ngroups chunk pairs) is cut into `nx` slices
@@ -397,10 +376,9 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   u32x4 bs[BPT];
 
   // prologue: B(0), A(0) -> LDS
-  if constexpr (GLDS) glds_b_chunk<BPT, NTHR, BCH>(sB[0], bbase, tid, wave);
-  else load_b_chunk<BPT, NTHR, BCH>(bs, bbase, tid);
+  load_b_chunk<BPT, NTHR, BCH>(bs, bbase, tid);
   load_a_chunk<MT>(a, avoff, abase);
-  if constexpr (!GLDS) store_b_chunk<BPT, NTHR, BCH>(sB[0], bs, tid);
+  store_b_chunk<BPT, NTHR, BCH>(sB[0], bs, tid);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -411,25 +389,21 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int cn = min(c + u + 1, last);
-      // LDS-DMA form: B(c+1) lands in the other LDS buffer while B(c) is read (last read of that buffer: chunk c-1,
-      // which every wave finished before the barrier that ended it); it is complete before the barrier below, which
-      // waits vmcnt(0) (the A registers are consumed right before it)
-      if constexpr (GLDS) glds_b_chunk<BPT, NTHR, BCH>(sB[u ^ 1], bbase + (int64_t)cn * BCH, tid, wave);
       if constexpr (LOADS_FIRST && MODE != 2) {
         // the next chunk's loads are in flight while this chunk is computed from LDS
-        if constexpr (!GLDS) load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
+        load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
         load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
         __builtin_amdgcn_sched_barrier(0);
       }
       sweep_compute<MODE, MT, NT>(acc, acc_lo, myA, sB[BDB ? u : 0], lane);
       if constexpr (!(LOADS_FIRST && MODE != 2)) {
-        if constexpr (!GLDS) load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
+        load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
         load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
       } else {
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (!BDB) __syncthreads();          // everyone has finished reading B(c)
-      if constexpr (!GLDS) store_b_chunk<BPT, NTHR, BCH>(sB[BDB ? (u ^ 1) : 0], bs, tid);
+      store_b_chunk<BPT, NTHR, BCH>(sB[BDB ? (u ^ 1) : 0], bs, tid);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -466,39 +440,27 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x + 1] = wall_clock64();
 }
 
-struct SweepVariant { int nw; bool bdb; int wgs_per_cu; int mt; };
-// k <= 64 (NT <= 2): 4 waves x 64 rows per workgroup (two 32-row MFMA tiles per wave share every B fragment
-// read: half the LDS traffic per byte of X of the 8 x 32 shape; measured at 50000x20000 k=64 0.336/0.343 ms
-// against 0.347/0.352, at 5000x10000 k=16 f32 +5%), B double-buffered, 2 workgroups per CU.
-// k > 64: the same 4 x 64-row shape with the factor single-buffered (k = 128: 32 KiB of A tiles + 32 KiB of factor,
-// two workgroups per CU, 110 VGPRs + 128 accumulator registers; 25000x25000 k=128: 0.337 ms against 0.355 for
-// 8 waves x 32 rows, where the 8 waves read 256 KiB of factor fragments from LDS per 32 KiB of X).
-static SweepVariant sweep_variant(int NT) {
-  SweepVariant r{4, NT <= 2, 2, 2};
-  if (const char* e = getenv("PRMF_SWEEP_MT")) r.mt = atoi(e) == 2 ? 2 : 1;
-  if (const char* e = getenv("PRMF_SWEEP_NW")) r.nw = atoi(e) == 4 ? 4 : 8;
-  if (const char* e = getenv("PRMF_SWEEP_BDB")) r.bdb = atoi(e) != 0;
-  if (r.mt == 2 && NT > 2) { r.nw = 4; r.bdb = false; }
-  const int lds_kib = r.nw * 4 * r.mt + (r.bdb ? 2 : 1) * 8 * NT;
-  r.wgs_per_cu = 160 / lds_kib;
-  if (r.wgs_per_cu * r.nw > 16 / r.mt) r.wgs_per_cu = 16 / r.mt / r.nw;   // register-limited: 4 (MT=1) or 2 (MT=2) waves per SIMD
-  if (r.wgs_per_cu < 1) r.wgs_per_cu = 1;
-  if (const char* e = getenv("PRMF_SWEEP_WGS_PER_CU")) r.wgs_per_cu = atoi(e) > 0 ? atoi(e) : r.wgs_per_cu;
-  return r;
-}
+// The one workgroup shape (alternatives measured and retired: 8 waves x 32 rows -- twice the LDS fragment traffic per
+// byte of X, 3% slower at k = 64 and 5% at k = 128; 32-row wave tiles with 3 workgroups per CU -- 11% slower at k = 128;
+// 4 waves x 128 rows, one workgroup per CU -- 10% slower at k = 64; the factor chunk staged by LDS-DMA
+// (global_load_lds_dwordx4) instead of through registers -- 8% slower at k = 64, 14% at k = 16:
+// profiles/r02_ab_factor_lds_dma.txt; one or three workgroups per CU -- 35% / 12% slower at 5000 x 10000):
+//   4 waves x 64 rows (MT = 2), two workgroups per CU;
+//   k <= 64: factor chunk double-buffered in LDS (32 KiB of A tiles + 2 x 8 NT KiB), one barrier per chunk;
+//   k  > 64: factor chunk single-buffered (k = 128: 32 + 32 KiB, 116 VGPRs + 128 accumulator registers), two barriers.
+constexpr int SWEEP_NW = 4, SWEEP_MT = 2, SWEEP_WGS_PER_CU = 2;
 
-GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus) {
+GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, const SweepTuning& tune) {
   GemmPlan p;
-  const SweepVariant v = sweep_variant(NT);
-  p.nw = v.nw;
-  p.bdb = v.bdb;
-  p.mt = v.mt;
-  p.panel_rows = v.nw * 32 * v.mt;
+  p.nw = SWEEP_NW;
+  p.bdb = NT <= 2;
+  p.mt = SWEEP_MT;
+  p.panel_rows = SWEEP_NW * 32 * SWEEP_MT;
   p.panels = (int)(round_up(M, p.panel_rows) / p.panel_rows);
   p.nchunks = (int)(Kpad / chunk_elems(x_dtype));          // even (K_PAD)
   p.ngroups = p.nchunks / 2;
   // one workgroup per resident slot (a multiple of 8: one share per XCD), but at least 4 units (8 chunks) each
-  int64_t G = (int64_t)n_cus * v.wgs_per_cu;
+  int64_t G = (int64_t)n_cus * SWEEP_WGS_PER_CU;
   const int64_t total_units = (int64_t)p.panels * p.ngroups;
   if (G > total_units / 4) G = total_units / 4;
   G = G / 8 * 8;
@@ -513,16 +475,12 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus) {
     // X*V (5.1 MB factor) is fastest unsliced (0.35-0.375 vs 0.40-0.42: the extra segments cost more).
     const double factor_mb = (double)Kpad * 32.0 * NT * 4.0 / (1024.0 * 1024.0);
     if (factor_mb > 6.0) {
-      double slice_mb = 3.5;
-      if (const char* e = getenv("PRMF_SWEEP_SLICE_MB")) slice_mb = atof(e) > 0 ? atof(e) : slice_mb;
+      const double slice_mb = 3.5;      // 8 slices (2 MB each) were bimodal: 0.355 / 0.413 ms
       p.nx = 2;
       while (p.nx < 8 && factor_mb / p.nx > slice_mb) p.nx *= 2;
       while (p.nx > 1 && units_per_wg < 0.5 * ((double)p.ngroups / p.nx)) p.nx /= 2;
     }
-    if (const char* e = getenv("PRMF_SWEEP_XCD")) {
-      const int f = atoi(e);
-      if (f == 1 || f == 2 || f == 4 || f == 8) p.nx = f;
-    }
+    if (tune.force_slices == 1 || tune.force_slices == 2 || tune.force_slices == 4 || tune.force_slices == 8) p.nx = tune.force_slices;
   }
   if (G < 1) G = 1;
   // which slabs does every panel receive?  simulate the kernel's decomposition for one launch
@@ -574,12 +532,18 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
   sweep_kernel<MODE, MTV, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), 0, s>>>(                                  \
       (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, 0, p.ngroups, p.nx, p.pmax, 0, slabs, slab_stride, \
       g_sweep_stamps, pro)
-  switch (NT) {
-    case 1: PRMF_LAUNCH(1); break;
-    case 2: PRMF_LAUNCH(2); break;
-    case 3: PRMF_LAUNCH(3); break;
-    case 4: PRMF_LAUNCH(4); break;
-    default: return hipErrorInvalidValue;
+  if constexpr (BDB) {
+    switch (NT) {
+      case 1: PRMF_LAUNCH(1); break;
+      case 2: PRMF_LAUNCH(2); break;
+      default: return hipErrorInvalidValue;
+    }
+  } else {
+    switch (NT) {
+      case 3: PRMF_LAUNCH(3); break;
+      case 4: PRMF_LAUNCH(4); break;
+      default: return hipErrorInvalidValue;
+    }
   }
 #undef PRMF_LAUNCH
   return hipGetLastError();
@@ -591,39 +555,17 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
   const int64_t lda16 = lda * elem_bytes(x_dtype) / 16;
   const SweepPrologue pro = prologue ? *prologue : SweepPrologue{};
   if (pro.kind != PROLOGUE_NONE && (p.nw != 4 || pro.nparts > GRAM_MAX_PARTS)) return hipErrorInvalidValue;
+  // arithmetic: 1 = bf16 X x hi/lo bf16 factor; 2 = f32 X split into three bf16 pieces (k <= 64); 0 = f32 MFMA (f32 X, k > 64)
   const int mode = x_dtype == 1 ? 1 : (split ? 2 : 0);
-  // default shape: 4 waves x 64 rows; factor double-buffered at k <= 64
-  if (p.mt == 2 && p.nw == 4 && p.bdb == (NT <= 2)) {
-#define PRMF_GO(MODEV, BDBV) return launch_sweep_nt<MODEV, 4, BDBV, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro)
-    if (NT <= 2) {
-      if (mode == 1) PRMF_GO(1, true);
-      if (mode == 2) PRMF_GO(2, true);
-      PRMF_GO(0, true);
-    }
-    if (mode == 1) PRMF_GO(1, false);
-    if (mode == 2) PRMF_GO(2, false);
-    PRMF_GO(0, false);
-#undef PRMF_GO
+  if (p.nw != SWEEP_NW || p.mt != SWEEP_MT || p.bdb != (NT <= 2)) return hipErrorInvalidValue;
+  if (NT <= 2) {
+    if (mode == 1) return launch_sweep_nt<1, SWEEP_NW, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
+    if (mode == 2) return launch_sweep_nt<2, SWEEP_NW, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
+    return hipErrorInvalidValue;       // f32 X at k <= 64 always takes the split form
   }
-  if (mode == 2) return hipErrorInvalidValue;      // the split form exists for the default shape only
-  // other shapes (tests, experiments): PRMF_SWEEP_NW / _MT / _BDB
-  if (p.mt == 2 && NT > 2)
-    return mode == 1 ? launch_sweep_nt<1, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro)
-                     : launch_sweep_nt<0, 4, false, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
-  if (p.mt == 2) {
-    if (mode == 1)
-      return p.nw == 8 ? launch_sweep_nt<1, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro)
-                       : launch_sweep_nt<1, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
-    return p.nw == 8 ? launch_sweep_nt<0, 8, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro)
-                     : launch_sweep_nt<0, 4, true, 2>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
-  }
-#define PRMF_DISPATCH(MD)                                                                                               \
-  (p.nw == 8 ? (p.bdb ? launch_sweep_nt<MD, 8, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro)      \
-                      : launch_sweep_nt<MD, 8, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro))    \
-             : (p.bdb ? launch_sweep_nt<MD, 4, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro)      \
-                      : launch_sweep_nt<MD, 4, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro)))
-  return mode == 1 ? PRMF_DISPATCH(1) : PRMF_DISPATCH(0);
-#undef PRMF_DISPATCH
+  if (mode == 1) return launch_sweep_nt<1, SWEEP_NW, false, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
+  if (mode == 0) return launch_sweep_nt<0, SWEEP_NW, false, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
+  return hipErrorInvalidValue;
 }
 
 // the prologue work without a sweep behind it (end of a batch)

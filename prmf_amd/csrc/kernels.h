@@ -93,7 +93,11 @@ struct GemmPlan {
   int max_seg = 1;          // slabs allocated: nx * pmax
   std::vector<uint32_t> segmask;   // [panels] bit s set <=> slab s holds a segment of this panel
 };
-GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus);
+// Test hooks, read from the environment ONCE per prmf_create (capi.hip) -- the planner itself takes no knobs.
+struct SweepTuning {
+  int force_slices = 0;     // PRMF_SWEEP_XCD = 1 | 2 | 4 | 8: force the number of reduction slices (decomposition-equivalence test)
+};
+GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, const SweepTuning& tune);
 extern unsigned long long* g_sweep_stamps;   // debug only
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
                        const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s,

@@ -104,7 +104,7 @@ hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const
 // order (deterministic).
 // ---------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int GRAM_MAX_BLOCKS = 128;
+constexpr int GRAM_MAX_BLOCKS = 256;   // one 32-row tile per wave up to 32768 rows (nparts <= GRAM_MAX_PARTS = 512)
 int gram_blocks(int64_t rows) {            // number of per-workgroup partials the launch writes
   int64_t tiles = (rows + 31) / 32;
   int64_t blocks = (tiles + 3) / 4;

@@ -44,7 +44,8 @@ class PrmfEngine(object):
     updates all of V from the all-reduced X^T U) or "colshard" (the V update is
     sharded by latent columns: reduce-scatter + all-gather)."""
 
-    def __init__(self, m_local, n, k, x_dtype="f32", device=None, nranks=1, rank=0, timing=False, dist_mode=None):
+    def __init__(self, m_local, n, k, x_dtype="f32", device=None, nranks=1, rank=0, timing=False, dist_mode=None,
+                 eager_objective=False):
         self.torch = _torch()
         self.lib = _capi.load()
         torch = self.torch
@@ -60,6 +61,8 @@ class PrmfEngine(object):
             raise ValueError("dist_mode must be 'replicated' or 'colshard'")
         if dist_mode == "colshard":
             flags |= _capi.PRMF_FLAG_COLUMN_SHARDED
+        if eager_objective:       # per-iteration objective launches instead of the deferred evaluation (prmf_hip.h)
+            flags |= _capi.PRMF_FLAG_EAGER_OBJECTIVE
         rc = self.lib.prmf_create(C.byref(self.ctx), self.device, self.m, self.n, self.k, self.x_dtype,
                                   self.nranks, self.rank, flags)
         if rc != _capi.PRMF_OK:

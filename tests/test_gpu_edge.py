@@ -1,6 +1,5 @@
-"""Edge shapes and every sweep variant of the HIP path against the oracle: one sample, one gene block,
-one latent factor, a pathway of two nodes, fewer rows than a wave tile, and the workgroup shapes that the
-library only picks for other k (forced through the PRMF_SWEEP_* knobs)."""
+"""Edge shapes of the HIP path against the oracle: one sample, one gene block, one latent factor, a pathway of
+two nodes, fewer rows than a wave tile; and the deferred objective against the per-iteration form."""
 import numpy as np
 import pytest
 
@@ -54,26 +53,9 @@ def test_tiny_and_ragged_shapes(m, n, k, P, order, x_dtype):
     check(case, x_dtype)
 
 
-@pytest.mark.parametrize("env", [
-    {"PRMF_SWEEP_NW": "8", "PRMF_SWEEP_MT": "1"},
-    {"PRMF_SWEEP_NW": "8", "PRMF_SWEEP_MT": "2"},
-    {"PRMF_SWEEP_NW": "4", "PRMF_SWEEP_MT": "1"},
-    {"PRMF_SWEEP_NW": "4", "PRMF_SWEEP_MT": "2", "PRMF_SWEEP_BDB": "0"},
-    {"PRMF_NO_FUSED_EPILOGUE": "1"},
-    {"PRMF_OVERLAP_SMALL": "1"},          # small kernels on the auxiliary stream next to the sweeps
-    {"PRMF_F32_SPLIT": "0"},              # f32 X on the f32 MFMA instead of the three-piece bf16 split
-])
-@pytest.mark.parametrize("k,x_dtype", [(16, "f32"), (64, "bf16")])
-def test_sweep_variants(env, k, x_dtype, monkeypatch):
-    for key, val in env.items():
-        monkeypatch.setenv(key, val)
-    case = synth.small_case(seed=23, m=900, n=1700, k=k, P=6, order=60, bf16_x=(x_dtype == "bf16"))
-    check(case, x_dtype, steps=4)
-
-
-def test_deferred_objective_equals_per_iteration_form(monkeypatch):
+def test_deferred_objective_equals_per_iteration_form():
     """The default single-rank iteration is 4 launches: the Gram / column reductions and the pathway terms ride in
-    the sweeps' prologues and the objective records of a batch are evaluated in prmf_end.  PRMF_NO_LAZY_OBJECTIVE=1
+    the sweeps' prologues and the objective records of a batch are evaluated in prmf_end.  PRMF_FLAG_EAGER_OBJECTIVE
     keeps the per-iteration launches (mid / post / finalize).  Same arithmetic in the same order: U, V and every
     record must be bit-identical -- also across a call boundary and with k = 13 (unfused path: no difference at all)."""
     import torch
@@ -83,11 +65,7 @@ def test_deferred_objective_equals_per_iteration_form(monkeypatch):
         case = synth.small_case(seed=5, m=m, n=n, k=k, P=6, order=90, bf16_x=(xd == "bf16"))
         outs = []
         for lazy in (True, False):
-            if lazy:
-                monkeypatch.delenv("PRMF_NO_LAZY_OBJECTIVE", raising=False)
-            else:
-                monkeypatch.setenv("PRMF_NO_LAZY_OBJECTIVE", "1")
-            eng = PrmfEngine(m, n, k, x_dtype=xd)
+            eng = PrmfEngine(m, n, k, x_dtype=xd, eager_objective=not lazy)
             eng.set_x(case["X"])
             eng.set_library(PathwayLibrary.from_edge_lists(n, case["pathways"]))
             eng.set_active(np.arange(k) % 6)
