@@ -9,7 +9,9 @@ BASELINE.json's target is quoted on (c3: X 50000 x 20000 bf16, k = 64, 300 tree
 pathways).  X, U, V are resident in HBM before the timed
 region.  With N > 1 (launched by torch.distributed.run, one rank per GPU) the
 SAME global problem is row-sharded over the ranks (strong scaling); per iteration the
-k x k Gram U^T U and the n x k product X^T U are all-reduced over RCCL.  Rank 0 prints one JSON line.
+k x k Gram U^T U is all-reduced and the n x k product X^T U is reduce-scattered by owner column block, the V update is
+sharded by latent column and V is all-gathered (--dist-mode colshard, the default), or X^T U is all-reduced and every
+rank updates all of V (--dist-mode replicated); RCCL issued inside the library.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -37,6 +39,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed --steps block (median reported)")
+    ap.add_argument("--dist-mode", default="colshard", choices=["colshard", "replicated"],
+                    help="N > 1: how the V update is shared.  colshard (default; BASELINE.json's wording): the k latent "
+                         "columns and their pathway Laplacians are sharded -- reduce-scatter of X^T U by owner column "
+                         "block, own-column V update, all-gather of V.  replicated: all-reduce of X^T U, every rank "
+                         "updates all of V.")
     return ap.parse_args()
 
 
@@ -159,7 +166,8 @@ def main():
     tdt = torch.bfloat16 if x_dtype == "bf16" else torch.float32
     lo, hi = syn.shard_rows(m, world, rank)
     Xd = syn.x_rows_torch(torch, dev, args.seed, n, k, lo, hi, tdt)
-    eng = PrmfEngine(hi - lo, n, k, x_dtype=x_dtype, device=local_rank, nranks=world, rank=rank)
+    eng = PrmfEngine(hi - lo, n, k, x_dtype=x_dtype, device=local_rank, nranks=world, rank=rank,
+                     dist_mode=args.dist_mode if world > 1 else None)
     cdev = dev if backend == "nccl" else "cpu"         # where the tiny control tensors of the collectives live
     nsq = torch.tensor([eng.local_norm_sq(Xd)], dtype=torch.float64, device=cdev)
     if world > 1:
@@ -264,6 +272,15 @@ def main():
                                 "iteration_frac": bytes_iter / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS})
         out["reps"] = {"n": len(rep_s), "ms_per_step_median": 1e3 * elapsed / args.steps,
                        "ms_per_step_min": 1e3 * rep_s[0] / args.steps, "ms_per_step_max": 1e3 * rep_s[-1] / args.steps}
+        if world > 1:
+            ci = eng.comm_info()
+            out["distributed"] = {
+                "mode": ci["mode"], "collectives": "in-library RCCL (prmf_step_dist)" if runner.native else "host-driven (torch.distributed)",
+                "rccl_comm_world_size": ci["comm_nranks"], "torch_world_size": world,
+                "exchanges_per_iteration": (["all_reduce U^T U (k*k f64, side stream)", "reduce_scatter X^T U (n*k/N f32 per rank)",
+                                             "all_gather V (n*k/N f32 per rank)"] if ci["mode"] == "colshard" else
+                                            ["all_reduce U^T U (k*k f64, side stream)", "all_reduce X^T U (n*k f32)"]),
+                "phase_ms_rank0": dict(zip(["phase_u", "phase_q+exchange", "phase_v+exchange", "phase_post"], ci["ms_phase"]))}
         if backend != "nccl":
             out["config"]["rehearsal"] = "ranks share one GPU, exchanges staged through the host (%s): not a measurement" % backend
         if world == 1 and not args.no_cpu_baseline:

@@ -279,6 +279,21 @@ int prmf_get_sweep_info(const prmf_ctx* ctx, prmf_sweep_info* out);
 int prmf_set_timing(prmf_ctx* ctx, int enabled);
 int prmf_get_timing(const prmf_ctx* ctx, double* ms_xv, double* ms_xtu, double* ms_total);
 
+/* What the multi-rank step actually ran with (bench.py reports it): whether the collectives are issued inside the
+ * library, the size / rank RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank; -1 if the
+ * collectives are host-driven), the V-update mode, and -- with timing enabled -- the average device time per iteration
+ * of the four phases of the last prmf_step_dist batch, each including the exchange that follows it on the caller's
+ * stream: [0] phase_u, [1] phase_q + reduce-scatter / all-reduce of Q, [2] phase_v + all-gather, [3] phase_post
+ * (the k x k all-reduce runs on a side stream next to phase_q).  -1 when not measured. */
+typedef struct prmf_comm_info_t {
+  int32_t in_library;
+  int32_t comm_nranks;
+  int32_t comm_rank;
+  int32_t mode;              /* PRMF_DIST_* */
+  double ms_phase[4];
+} prmf_comm_info_t;
+int prmf_comm_info(const prmf_ctx* ctx, prmf_comm_info_t* out);
+
 #ifdef __cplusplus
 }
 #endif

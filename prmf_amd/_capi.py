@@ -36,6 +36,11 @@ class SweepInfo(C.Structure):
                 ("grid_xv", C.c_int32), ("grid_xtu", C.c_int32), ("f32_split", C.c_int32), ("reserved", C.c_int32)]
 
 
+class CommInfo(C.Structure):
+    _fields_ = [("in_library", C.c_int32), ("comm_nranks", C.c_int32), ("comm_rank", C.c_int32), ("mode", C.c_int32),
+                ("ms_phase", C.c_double * 4)]
+
+
 # every symbol include/prmf_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _i64, _d, _u = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_uint
 SIGNATURES = {
@@ -65,6 +70,7 @@ SIGNATURES = {
     "prmf_get_sweep_info": (_i, [_vp, C.POINTER(SweepInfo)]),
     "prmf_set_timing": (_i, [_vp, _i]),
     "prmf_get_timing": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)]),
+    "prmf_comm_info": (_i, [_vp, C.POINTER(CommInfo)]),
 }
 
 _lib = None

@@ -116,6 +116,9 @@ struct prmf_ctx {
   std::vector<hipEvent_t> ev;          // [MAX_RECORDS][4] with PRMF_FLAG_TIMING
   double ms_xv = 0, ms_xtu = 0, ms_total = 0;
   int timed_iters = 0;
+  std::vector<hipEvent_t> ev_phase;    // [MAX_RECORDS][5]: iteration start, after phase_u, phase_q (+ exchange), phase_v (+ exchange), phase_post
+  double ms_phase[4] = {0, 0, 0, 0};
+  int phase_timed_iters = 0;
 
   // Auxiliary stream: in the multi-rank step the latency-bound k x k all-reduce of U^T U runs here next to the
   // X^T U sweep and is joined before phase_v (prmf_step_dist).  (Round 1 could also move the single-rank small
@@ -147,6 +150,8 @@ struct RcclApi {
   ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;        // optional (reporting only)
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;     // optional
   bool ok = false;
 };
 RcclApi& rccl() {
@@ -166,6 +171,8 @@ RcclApi& rccl() {
     PRMF_SYM(ReduceScatter, "ncclReduceScatter");
     PRMF_SYM(AllGather, "ncclAllGather");
     PRMF_SYM(GetErrorString, "ncclGetErrorString");
+    PRMF_SYM(CommCount, "ncclCommCount");
+    PRMF_SYM(CommUserRank, "ncclCommUserRank");
 #undef PRMF_SYM
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.ReduceScatter && a.AllGather && a.GetErrorString;
     return a;
@@ -455,6 +462,8 @@ int prmf_destroy(prmf_ctx* c) {
   if (c->hyper_host) (void)hipHostFree(c->hyper_host);
   if (c->records_host) (void)hipHostFree(c->records_host);
   for (auto& ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : c->ev_phase)
     if (ev) (void)hipEventDestroy(ev);
   delete c;
   return PRMF_OK;
@@ -967,8 +976,12 @@ int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma,
   while (done < n_steps) {
     const int batch = n_steps - done < MAX_RECORDS ? n_steps - done : MAX_RECORDS;
     if ((rc = prmf_begin(c, dU, dV, gamma, delta, tradeoff, stream))) return rc;
+    const bool ptime = (c->flags & PRMF_FLAG_TIMING) != 0 && !c->ev_phase.empty();
     for (int i = 0; i < batch; ++i) {
+      const size_t pe = (size_t)c->cursor * 5;
+      if (ptime) HIP_TRY(c, hipEventRecord(c->ev_phase[pe + 0], s));
       if ((rc = prmf_phase_u(c, stream))) return rc;
+      if (ptime) HIP_TRY(c, hipEventRecord(c->ev_phase[pe + 1], s));
       // The k x k all-reduce is latency-bound and its result is first needed by phase_v: it runs on the side
       // stream next to the X^T U sweep (which depends only on the local U) and is joined before phase_v.
       if (c->mid_pending) {
@@ -988,18 +1001,32 @@ int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma,
       if (c->replicated) {
         // every rank gets the full Q and runs the fused single-rank V update on it: no third exchange
         NCCL_TRY(c, N.AllReduce(c->q_send, c->q_send, (size_t)c->n * c->k, ncclFloat32, ncclSum, c->comm, s));
+        if (ptime) HIP_TRY(c, hipEventRecord(c->ev_phase[pe + 2], s));
         if ((rc = prmf_phase_v(c, stream))) return rc;
       } else {
         if (c->nranks > 1 || c->q_recv != c->q_send)
           NCCL_TRY(c, N.ReduceScatter(c->q_send, c->q_recv, (size_t)c->n * c->kc, ncclFloat32, ncclSum, c->comm, s));
+        if (ptime) HIP_TRY(c, hipEventRecord(c->ev_phase[pe + 2], s));
         if ((rc = prmf_phase_v(c, stream))) return rc;
         if (c->nranks > 1 || c->v_recv != c->v_send)
           NCCL_TRY(c, N.AllGather(c->v_send, c->v_recv, (size_t)c->v_send_floats, ncclFloat32, c->comm, s));
       }
+      if (ptime) HIP_TRY(c, hipEventRecord(c->ev_phase[pe + 3], s));
       if ((rc = prmf_phase_post(c, stream))) return rc;
+      if (ptime) HIP_TRY(c, hipEventRecord(c->ev_phase[pe + 4], s));
     }
     double gd[2] = {gamma, delta};
     if ((rc = prmf_end(c, batch, obj_out ? obj_out + (size_t)done * PRMF_OBJ_STRIDE : nullptr, gd, stream))) return rc;
+    if (ptime) {                         // prmf_end has synchronised the stream
+      for (int j = 0; j < 4; ++j) c->ms_phase[j] = 0;
+      for (int i = 0; i < batch; ++i)
+        for (int j = 0; j < 4; ++j) {
+          float ms = 0;
+          HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_phase[(size_t)i * 5 + j], c->ev_phase[(size_t)i * 5 + j + 1]));
+          c->ms_phase[j] += ms;
+        }
+      c->phase_timed_iters = batch;
+    }
     gamma = gd[0];
     delta = gd[1];
     done += batch;
@@ -1008,6 +1035,19 @@ int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma,
     gamma_delta_out[0] = gamma;
     gamma_delta_out[1] = delta;
   }
+  return PRMF_OK;
+}
+
+int prmf_comm_info(const prmf_ctx* c, prmf_comm_info_t* out) {
+  if (!c || !out) return PRMF_ERR_ARG;
+  out->in_library = c->comm ? 1 : 0;
+  out->comm_nranks = out->comm_rank = -1;
+  if (c->comm && rccl().ok) {
+    if (rccl().CommCount) (void)rccl().CommCount(c->comm, &out->comm_nranks);
+    if (rccl().CommUserRank) (void)rccl().CommUserRank(c->comm, &out->comm_rank);
+  }
+  out->mode = c->replicated ? PRMF_DIST_REPLICATED : PRMF_DIST_COLUMN_SHARDED;
+  for (int j = 0; j < 4; ++j) out->ms_phase[j] = c->phase_timed_iters > 0 ? c->ms_phase[j] / c->phase_timed_iters : -1.0;
   return PRMF_OK;
 }
 
@@ -1163,6 +1203,9 @@ int prmf_set_timing(prmf_ctx* c, int enabled) {
     if ((rc = set_device(c))) return rc;
     c->ev.assign((size_t)MAX_RECORDS * 4, nullptr);
     for (auto& ev : c->ev)
+      if (hipEventCreate(&ev) != hipSuccess) return fail(c, PRMF_ERR_HIP, "hipEventCreate failed");
+    c->ev_phase.assign((size_t)MAX_RECORDS * 5, nullptr);
+    for (auto& ev : c->ev_phase)
       if (hipEventCreate(&ev) != hipSuccess) return fail(c, PRMF_ERR_HIP, "hipEventCreate failed");
   }
   if (enabled) c->flags |= PRMF_FLAG_TIMING; else c->flags &= ~PRMF_FLAG_TIMING;

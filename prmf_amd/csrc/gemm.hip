@@ -247,6 +247,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PRMF_LOADS_FIRST 1
 #endif
 constexpr bool LOADS_FIRST = PRMF_LOADS_FIRST != 0;
+#ifndef PRMF_UNIT_CHUNKS
+#define PRMF_UNIT_CHUNKS 1
+#endif
+constexpr int UNIT = PRMF_UNIT_CHUNKS;      // chunks per work unit of the balanced decomposition (1; 2 = round-1 behaviour)
 
 template <int MT>
 __device__ __forceinline__ void load_a_chunk(u32x4 (&dst)[MT][4], const unsigned (&voff)[MT][4], const uint4* base) {
@@ -285,12 +289,11 @@ __device__ __forceinline__ void store_b_chunk(u32x4* sb, const u32x4 (&src)[NB],
 // BDB = true : B double-buffered in LDS, one barrier per chunk
 // BDB = false: B single-buffered, two barriers per chunk, 16*NT KiB less LDS per
 //              workgroup -> more resident workgroups (bytes in flight) per CU
-// The host pads the reduction to an even number of chunks and gives every split an
-// even number, so the chunk loop is unrolled x2 with compile-time LDS buffer offsets.
+// The chunk loop is unrolled x2 with compile-time LDS buffer offsets; a segment may have any number of chunks.
 template <int MODE, int MT, int NT, int NW, bool BDB>
 __global__ void __launch_bounds__(64 * NW, (MODE == 2 && NT == 2 && NW == 4) ? 2 : 1)
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
-             const uint4* __restrict__ Bp, int npanels, int g_begin, int ngroups /* chunk pairs [g_begin, g_begin+ngroups) of every row */,
+             const uint4* __restrict__ Bp, int npanels, int g_begin, int ngroups /* work units (UNIT chunks each) [g_begin, g_begin+ngroups) of every row */,
              int nx, int pmax, int seg_base, float* __restrict__ slabs, int64_t slab_stride,
              unsigned long long* __restrict__ stamps /* debug, may be null */, const SweepPrologue pro) {
   if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x] = wall_clock64();
@@ -312,12 +315,12 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // Balanced, XCD-aware persistent decomposition.  The launch has one workgroup per
-  // resident slot.  The reduction range (ngroups chunk pairs) is cut into `nx` slices
+  // resident slot.  The reduction range (ngroups units of UNIT chunks) is cut into `nx` slices
   // (nx = 8: one per XCD; workgroups b, b+8, ... share an XCD and its 4 MiB L2, so
   // the nx-th of the packed factor they all stream stays L2-resident instead of
   // being re-fetched through the fabric by every workgroup -- placement is used for
   // speed only, never for correctness).  Within slice x the npanels x L_x units (a
-  // unit = one chunk pair of one row panel) are cut into gridDim.x/nx equal
+  // unit = UNIT chunks of one row panel) are cut into gridDim.x/nx equal
   // contiguous ranges in panel-major order.  A range that crosses a panel boundary is
   // processed as separate segments; the segment of panel p in slice x that is the
   // `part`-th to touch it goes to slab x*pmax + part, and the consumer sums the slabs
@@ -327,7 +330,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   const int64_t Gx = gridDim.x / nx;                             // workgroups per slice
   const int wj = (int)(blockIdx.x >> 3) * (8 / nx) + xcd / nx;   // index within the slice
   const int gs0 = g_begin + (int)((int64_t)ngroups * x / nx);
-  const int L = g_begin + (int)((int64_t)ngroups * (x + 1) / nx) - gs0;      // chunk pairs in this slice
+  const int L = g_begin + (int)((int64_t)ngroups * (x + 1) / nx) - gs0;      // units in this slice
   const int64_t T = (int64_t)npanels * L;
   int64_t unit = T * wj / Gx;
   const int64_t unit_end = L > 0 ? T * (wj + 1) / Gx : 0;
@@ -350,9 +353,8 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   const int part = (int)(wj - (((int64_t)panel * L + 1) * Gx - 1) / T);   // wj minus the first workgroup of this (panel, slice)
   const int seg = seg_base + x * pmax + part;
   unit += g1 - g0;
-  const int c0 = 2 * (gs0 + g0);
-  const int nch = 2 * (g1 - g0);
-  const int last = nch - 1;
+  const int c0 = UNIT * (gs0 + g0);
+  const int nch = UNIT * (g1 - g0);
   const int64_t prow0 = (int64_t)panel * (32 * MT * NW);            // first row of this panel
   const int64_t row0 = prow0 + wave * (32 * MT);                    // first row of this wave
 
@@ -385,30 +387,43 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
     for (int i = 0; i < 4; ++i) myA[mt * 256 + i * 64 + lane] = a[mt][i];
   __syncthreads();
 
+  // The chunk loop is unrolled x2 so that the LDS buffer offsets are compile-time constants; a segment may hold an
+  // odd number of chunks (the work unit is ONE chunk: equal shares then differ by 2.8 us of streaming, not 5.6 -- at
+  // 5000 x 10000, where a workgroup has only 12 chunks, that is 8% of the sweep), and the last chunk of a segment
+  // loads nothing (it used to re-load itself: one wasted chunk per segment).  `have` / `next` are workgroup-uniform.
   for (int c = 0; c < nch; c += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int cn = min(c + u + 1, last);
-      if constexpr (LOADS_FIRST && MODE != 2) {
-        // the next chunk's loads are in flight while this chunk is computed from LDS
-        load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
-        load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      sweep_compute<MODE, MT, NT>(acc, acc_lo, myA, sB[BDB ? u : 0], lane);
-      if constexpr (!(LOADS_FIRST && MODE != 2)) {
-        load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
-        load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
-      } else {
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if constexpr (!BDB) __syncthreads();          // everyone has finished reading B(c)
-      store_b_chunk<BPT, NTHR, BCH>(sB[BDB ? (u ^ 1) : 0], bs, tid);
+      const bool have = c + u < nch, next = c + u + 1 < nch;
+      if (have) {
+        const int cn = c + u + 1;
+        if constexpr (LOADS_FIRST && MODE != 2) {
+          // the next chunk's loads are in flight while this chunk is computed from LDS
+          if (next) {
+            load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
+            load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        sweep_compute<MODE, MT, NT>(acc, acc_lo, myA, sB[BDB ? u : 0], lane);
+        if constexpr (!(LOADS_FIRST && MODE != 2)) {
+          if (next) {
+            load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
+            load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
+          }
+        } else {
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!BDB) __syncthreads();          // everyone has finished reading B(c)
+        if (next) {
+          store_b_chunk<BPT, NTHR, BCH>(sB[BDB ? (u ^ 1) : 0], bs, tid);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) myA[mt * 256 + i * 64 + lane] = a[mt][i];
-      __syncthreads();
+            for (int i = 0; i < 4; ++i) myA[mt * 256 + i * 64 + lane] = a[mt][i];
+        }
+        __syncthreads();      // also orders this chunk's LDS reads before the next segment's prologue writes
+      }
     }
   }
 
@@ -458,14 +473,14 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
   p.panel_rows = SWEEP_NW * 32 * SWEEP_MT;
   p.panels = (int)(round_up(M, p.panel_rows) / p.panel_rows);
   p.nchunks = (int)(Kpad / chunk_elems(x_dtype));          // even (K_PAD)
-  p.ngroups = p.nchunks / 2;
-  // one workgroup per resident slot (a multiple of 8: one share per XCD), but at least 4 units (8 chunks) each
+  p.ngroups = p.nchunks / UNIT;                            // work units per row panel
+  // one workgroup per resident slot (a multiple of 8: one share per XCD), but at least 8 chunks each
   int64_t G = (int64_t)n_cus * SWEEP_WGS_PER_CU;
   const int64_t total_units = (int64_t)p.panels * p.ngroups;
-  if (G > total_units / 4) G = total_units / 4;
+  if (G > total_units * UNIT / 8) G = total_units * UNIT / 8;
   G = G / 8 * 8;
   p.nx = 1;
-  if (G >= 8 && p.ngroups >= 8) {
+  if (G >= 8 && p.ngroups * UNIT >= 16) {
     // as many slices as keep >= ~1.5 (panel, slice) pieces per workgroup: shorter segments cost
     // more in prologues and slab traffic than the L2 residency of the factor slice wins back
     const double units_per_wg = (double)total_units / (double)G;

@@ -86,7 +86,7 @@ struct GemmPlan {
   int panel_rows = 0;       // rows per panel (= rows of one workgroup tile)
   int panels = 0;           // row panels
   int nchunks = 0;          // reduction chunks per row (even)
-  int ngroups = 0;          // nchunks / 2: the work unit is (panel, chunk pair)
+  int ngroups = 0;          // work units per row panel: the unit is (panel, chunk)
   int grid = 0;             // workgroups launched: one per resident slot, equal contiguous unit ranges
   int nx = 1;               // slices of the reduction range (8 = one per XCD)
   int pmax = 1;             // most workgroups that touch one (panel, slice)

@@ -322,6 +322,14 @@ class PrmfEngine(object):
         self._check(rc)
         return out
 
+    def comm_info(self):
+        """dict: in_library, comm_nranks / comm_rank as RCCL reports them, mode, ms_phase (see prmf_hip.h)."""
+        info = _capi.CommInfo()
+        self._check(self.lib.prmf_comm_info(self.ctx, C.byref(info)))
+        return {"in_library": bool(info.in_library), "comm_nranks": int(info.comm_nranks), "comm_rank": int(info.comm_rank),
+                "mode": "replicated" if info.mode == _capi.PRMF_DIST_REPLICATED else "colshard",
+                "ms_phase": [float(x) for x in info.ms_phase]}
+
     def sweep_info(self):
         info = _capi.SweepInfo()
         self._check(self.lib.prmf_get_sweep_info(self.ctx, C.byref(info)))

@@ -134,6 +134,18 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {
   return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t c, int* count) {
+  if (!c || !count) return ncclInvalidArgument;
+  *count = c->nranks;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommUserRank(const ncclComm_t c, int* rank) {
+  if (!c || !rank) return ncclInvalidArgument;
+  *rank = c->rank;
+  return ncclSuccess;
+}
+
 const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "mock rccl error"; }
 
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t c, hipStream_t s) {

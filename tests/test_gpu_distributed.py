@@ -153,6 +153,8 @@ def _native_worker(rank, world, port, k, mode, mock, q):
         V = eng.device_tensor(case["V0"], torch.float32)
         runner = DistributedPrmf(eng, native=True)
         assert runner.native                                   # the in-library step, collectives through the mock
+        info = eng.comm_info()                                 # what bench.py reports for N > 1
+        assert info["in_library"] and info["comm_nranks"] == world and info["comm_rank"] == rank and info["mode"] == mode
         objs, gd = runner.step(U, V, 6, case["gamma"], case["delta"])
         q.put((rank, U.cpu().numpy(), V.cpu().numpy(), objs))
         eng.close()
@@ -160,7 +162,7 @@ def _native_worker(rank, world, port, k, mode, mock, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k,mode", [(64, "replicated"), (13, "replicated"), (16, "colshard")])
+@pytest.mark.parametrize("k,mode", [(64, "colshard"), (64, "replicated"), (13, "replicated"), (16, "colshard")])
 def test_in_library_step_two_ranks_through_mock_rccl(k, mode, tmp_path):
     """prmf_step_dist with TWO ranks: the collectives go through tests/native/mock_rccl.cpp (shared memory between
     the two processes, same entry points and call order as RCCL), so the library's own sequencing -- buffers, counts,
