@@ -248,9 +248,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr bool LOADS_FIRST = PRMF_LOADS_FIRST != 0;
 #ifndef PRMF_UNIT_CHUNKS
-#define PRMF_UNIT_CHUNKS 1
+#define PRMF_UNIT_CHUNKS 2
 #endif
-constexpr int UNIT = PRMF_UNIT_CHUNKS;      // chunks per work unit of the balanced decomposition (1; 2 = round-1 behaviour)
+// chunks per work unit of the balanced decomposition.  2: every segment starts on a 256-B boundary of its rows.  1 (finer
+// balance: shares differ by one 2.8 us chunk instead of two) was measured 2% SLOWER at 50000 x 20000 and no faster at
+// 5000 x 10000 or 6250 x 20000 (profiles/r02_ab_unit_chunks.txt) -- the imbalance of one unit is not what small sweeps lose.
+constexpr int UNIT = PRMF_UNIT_CHUNKS;
 
 template <int MT>
 __device__ __forceinline__ void load_a_chunk(u32x4 (&dst)[MT][4], const unsigned (&voff)[MT][4], const uint4* base) {
@@ -387,10 +390,9 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
     for (int i = 0; i < 4; ++i) myA[mt * 256 + i * 64 + lane] = a[mt][i];
   __syncthreads();
 
-  // The chunk loop is unrolled x2 so that the LDS buffer offsets are compile-time constants; a segment may hold an
-  // odd number of chunks (the work unit is ONE chunk: equal shares then differ by 2.8 us of streaming, not 5.6 -- at
-  // 5000 x 10000, where a workgroup has only 12 chunks, that is 8% of the sweep), and the last chunk of a segment
-  // loads nothing (it used to re-load itself: one wasted chunk per segment).  `have` / `next` are workgroup-uniform.
+  // The chunk loop is unrolled x2 so that the LDS buffer offsets are compile-time constants; it handles any number of
+  // chunks per segment (odd only with UNIT = 1), and the last chunk of a segment loads nothing (it used to re-load
+  // itself: one wasted chunk per segment).  `have` / `next` are workgroup-uniform.
   for (int c = 0; c < nch; c += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
