@@ -4,10 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from prmf_amd import PathwayLibrary, synthetic as syn
 from prmf_amd.solver import PrmfEngine
-m, n, k, P = 50000, 20000, 64, 300
+m, n, k, P = [int(x) for x in os.environ.get("SHAPE", "50000,20000,64,300").split(",")]
+XD = os.environ.get("XDTYPE", "bf16")
 dev = "cuda:0"
-Xd = syn.x_rows_torch(torch, dev, 0, n, k, 0, m, torch.bfloat16)
-eng = PrmfEngine(m, n, k, x_dtype="bf16")
+Xd = syn.x_rows_torch(torch, dev, 0, n, k, 0, m, torch.bfloat16 if XD == "bf16" else torch.float32)
+eng = PrmfEngine(m, n, k, x_dtype=XD, eager_objective=True)
 eng.set_x(Xd); del Xd
 eng.set_library(PathwayLibrary.from_edge_lists(n, syn.tree_pathways(n, P, 300, 0)))
 eng.set_active([kk % P for kk in range(k)])
@@ -24,12 +25,14 @@ for name, ph in (("X*V", eng.phase_u), ("X^T*U", eng.phase_q)):
     ph(); torch.cuda.synchronize()
     a = st.cpu().numpy().reshape(-1, 2); a = a[a[:, 1] > 0]
     t0 = a[:, 0].min(); start = (a[:, 0] - t0) / 100.0; end = (a[:, 1] - t0) / 100.0   # microseconds
-    print("%-6s WGs %d  start spread %.1f us | end: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f us | mean dur %.1f" % (
-        name, len(a), start.max(), end.min(), np.percentile(end, 10), np.percentile(end, 50), np.percentile(end, 90), end.max(), (end - start).mean()))
+    print("%-6s WGs %d  start: p50 %.1f p90 %.1f max %.1f us | end: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f us | mean dur %.1f" % (
+        name, len(a), np.percentile(start, 50), np.percentile(start, 90), start.max(), end.min(), np.percentile(end, 10), np.percentile(end, 50), np.percentile(end, 90), end.max(), (end - start).mean()))
     if name == "X*V":
         eng.phase_v() if False else None
 eng.lib.prmf_debug_set_stamps(None)
 
+if os.environ.get('QUICK'):
+    sys.exit(0)
 # --- are the slow workgroups the same ones every launch? (systematic => a weighted static split would fix it)
 import numpy as np
 durs = []
