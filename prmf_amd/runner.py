@@ -19,7 +19,6 @@ are always relabelled by their "name" attribute; --high-dimensional is type=bool
 (any non-empty string is True) and transposes X when m > n.
 """
 import argparse
-import copy
 import csv
 import os
 import random
@@ -145,10 +144,132 @@ def nmf_init_v(X, u):
     return v.reshape(X.shape[1], 1), res
 
 
-def main(argv=None):
-    import pandas as pd
-    from sklearn.model_selection import KFold
+# ---------------------------------------------------------------------------
+# The command line, as a pipeline of small stages over one record of parsed inputs.
+# What each stage must reproduce of the reference's `main` (script/prmf_runner.py:870-1093) is cited at the stage;
+# flags, messages, exit codes 22-25, output files and the order in which the legacy RNG streams are consumed are the
+# drop-in contract, the decomposition is this package's own.
+# ---------------------------------------------------------------------------
+class ManifoldSet(object):
+    """The pathway graphs of a run in command-line order."""
 
+    def __init__(self, paths):
+        self.paths = list(paths)
+        self.graphs = [G for G, _fp in parse_pathways(self.paths)]       # :915 (always the "name" attribute)
+        self.by_path = dict(zip(self.paths, self.graphs))
+
+    @classmethod
+    def from_args(cls, args):
+        """--manifolds xor --manifolds-file (:902-914; exit codes 22 / 23)."""
+        if (args.manifolds is None) == (args.manifolds_file is None):
+            sys.stderr.write("Exactly one of --manifolds or --manifolds-file is required.\n")
+            sys.exit(22 if args.manifolds is None else 23)
+        if args.manifolds is not None:
+            return cls(args.manifolds)
+        with open(args.manifolds_file, 'r') as fh:
+            return cls([line.rstrip() for line in fh])
+
+    def coverage(self, nodelist):
+        """Fraction of every graph's nodes that the nodelist knows (:977-996); exit code 24 if none is known at all."""
+        known = set(nodelist)
+        fracs = [sum(1 for node in G.nodes() if node in known) / G.order() for G in self.graphs]
+        if not any(fracs):
+            sys.stderr.write("Invalid manifolds. Check that the node identifiers of the manifolds are present in the nodelist. Try setting --node-attribute if the node identifier is in a graphml attribute rather than the XML node attribute 'id'\n")
+            sys.exit(24)
+        sys.stdout.write("Printing manifold node representation in nodelist:\n")
+        for fp, frac in zip(self.paths, fracs):
+            sys.stdout.write("{}: {:2.1f}%\n".format(fp, frac * 100))
+
+
+class DataMatrix(object):
+    """--data as read from disk: a frame oriented samples x genes, whether it carried row names / a header."""
+
+    def __init__(self, args):
+        import pandas as pd
+        if args.data.endswith(".npy"):
+            # extension: a binary matrix (samples x genes, no header, no row names -> --nodelist is required), for sizes
+            # where parsing 1e9 delimited numbers would dominate the run; everything downstream is unchanged
+            self.has_header = self.has_row_names = False
+            frame = pd.DataFrame(np.load(args.data, mmap_mode="r"))
+        else:
+            self.has_header = check_header(args.data, args.delimiter)                                   # :937-942
+            self.has_row_names = check_row_names(args.data, args.delimiter, self.has_header)
+            frame = pd.read_csv(args.data, sep=args.delimiter, header='infer' if self.has_header else None, nrows=None,
+                                index_col=0 if self.has_row_names else None)
+        self.samples = list(frame.index)                   # taken BEFORE the orientation step, as the reference does
+        m, n = frame.shape                                  # :946-952: --high-dimensional wants m <= n
+        if (m > n) if args.high_dimensional else (m < n):
+            frame = frame.transpose()
+        self.frame = frame
+
+    def resolve_genes(self, args, manifolds):
+        """-> (X ndarray, nodelist).  --nodelist names the columns; otherwise the header does and genes that only the
+        graphs know are appended, X zero-embedded (:957-975, prmf.embed_arr); neither: exit code 25."""
+        if args.nodelist is not None:
+            with open(args.nodelist) as fh:
+                return self.frame.to_numpy(), parse_nodelist(fh)
+        if not self.has_header:
+            sys.stderr.write("--nodelist is not provided and there is no header in <--data>\n")
+            sys.exit(25)
+        measured = list(self.frame.columns)
+        nodelist, seen = list(measured), set(measured)
+        for G in manifolds.graphs:
+            for node in G:
+                if node not in seen:
+                    nodelist.append(node)
+                    seen.add(node)
+        return embed_arr(nodelist, measured, self.frame.to_numpy()), nodelist
+
+
+def hold_out(X, samples, fraction):
+    """--cross-validation f: the first of round(1/f) contiguous folds is held out (:1002-1013)."""
+    from sklearn.model_selection import KFold
+    train, test = next(KFold(n_splits=round(1 / fraction)).split(X))
+    return X[train], X[test], [samples[i] for i in train]
+
+
+def initial_factors(args, X, manifolds, nodelist):
+    """--manifolds-init: U0 / V0 from one pathway indicator per latent factor through two NNLS solves (:1022-1064);
+    fewer than k given -> the rest drawn with random.sample, more -> np.random.choice (the reference's RNG calls)."""
+    chosen = list(args.manifolds_init)
+    if len(chosen) < args.k_latent:
+        rest = list(set(manifolds.paths) - set(chosen))
+        chosen += random.sample(rest, args.k_latent - len(chosen))
+    elif len(chosen) > args.k_latent:
+        chosen = [chosen[i] for i in np.random.choice(len(chosen), args.k_latent)]
+    us, vs = [], []
+    for fp in chosen:
+        v, on = pathway_to_vec(X, manifolds.by_path[fp], nodelist)
+        signal = v[on]
+        u, _res = nmf_init_u(X, v)
+        v_new, _res = nmf_init_v(X, u)
+        v_new[on] = signal
+        us.append(u)
+        vs.append(v_new)
+    sys.stdout.write("Using the following manifolds for initialization:\n{}\n".format("\n".join(chosen)))
+    with open(os.path.join(args.outdir, 'init_pathways.txt'), 'w') as fh:
+        fh.write("\n".join(chosen))
+    return np.concatenate(us, axis=1), np.concatenate(vs, axis=1)
+
+
+def write_outputs(args, data, manifolds, samples, nodelist, U, V, obj_data):
+    """U.csv / V.csv (QUOTE_NONNUMERIC, row index only if the input had row names, :1068-1071) and obj.txt
+    (`key = %.5f` lines, then `k -> manifold path`, :1081-1093)."""
+    import pandas as pd
+    cols = ["LV{}".format(x) for x in range(args.k_latent)]
+    pd.DataFrame(U, index=samples, columns=cols).to_csv(os.path.join(args.outdir, "U.csv"), sep=",",
+                                                        index=data.has_row_names, quoting=csv.QUOTE_NONNUMERIC)
+    pd.DataFrame(V, index=nodelist, columns=cols).to_csv(os.path.join(args.outdir, "V.csv"), sep=",", index=True,
+                                                         quoting=csv.QUOTE_NONNUMERIC)
+    with open(os.path.join(args.outdir, "obj.txt"), 'w') as fh:
+        l2p = obj_data.pop('latent_to_pathway_data', {})
+        for key, val in obj_data.items():
+            fh.write("{} = {:0.5f}\n".format(key, val))
+        for k in sorted(l2p.keys()):
+            fh.write("{} -> {}\n".format(k, manifolds.paths[l2p[k][0][0]]))
+
+
+def main(argv=None):
     parser = argparse.ArgumentParser(description="""
 MI355X implementation of Pathway-Regularized NMF (same interface as prmf_runner.py).
 
@@ -163,150 +284,32 @@ Solve an optimization problem of the form
                         help="storage type of X on the GPU (bf16 halves the HBM traffic of the sweeps; factors stay float32)")
     args = parser.parse_args(argv)
 
-    tradeoff = None if args.tradeoff == -1 else args.tradeoff
-
-    if args.manifolds is None and args.manifolds_file is None:
-        sys.stderr.write("Exactly one of --manifolds or --manifolds-file is required.\n")
-        sys.exit(22)
-    elif args.manifolds is None:
-        with open(args.manifolds_file, 'r') as fh:
-            manifold_fps = [line.rstrip() for line in fh]
-    elif args.manifolds_file is None:
-        manifold_fps = args.manifolds
-    else:
-        sys.stderr.write("Exactly one of --manifolds or --manifolds-file is required.\n")
-        sys.exit(23)
-    G_fp_pairs = parse_pathways(manifold_fps)          # :915 (always the "name" attribute)
-    fp_to_G = {fp: G for G, fp in G_fp_pairs}
-    Gs = [G for G, _ in G_fp_pairs]
-
-    if args.seed is not None:
-        seed = int(args.seed)
-        np.random.seed(seed)
-        random.seed(seed)
-
-    if args.data.endswith(".npy"):
-        # extension: a binary matrix (samples x genes, no header, no row names -> --nodelist is required), for sizes
-        # where parsing 1e9 delimited numbers would dominate the run; everything downstream is unchanged
-        has_header = has_row_names = False
-        X = pd.DataFrame(np.load(args.data, mmap_mode="r"))
-    else:
-        has_header = check_header(args.data, args.delimiter)
-        has_row_names = check_row_names(args.data, args.delimiter, has_header)
-        X = pd.read_csv(args.data, sep=args.delimiter, header='infer' if has_header else None, nrows=None,
-                        index_col=0 if has_row_names else None)
-    samples = list(X.index)
-
-    m, n = X.shape                                      # :946-952
-    if args.high_dimensional:
-        if m > n:
-            X = X.transpose()
-    else:
-        if m < n:
-            X = X.transpose()
-
-    if args.nodelist is not None:                       # :957-975
-        with open(args.nodelist) as fh:
-            nodelist = parse_nodelist(fh)
-        X = X.to_numpy()
-    elif has_header:
-        nodelist = list(X.columns)
-        seen = set(nodelist)
-        for G in Gs:
-            for node in G:
-                if node not in seen:
-                    nodelist.append(node)
-                    seen.add(node)
-        X = embed_arr(nodelist, list(X.columns), X.to_numpy())
-    else:
-        sys.stderr.write("--nodelist is not provided and there is no header in <--data>\n")
-        sys.exit(25)
-
-    nodelist_set = set(nodelist)                        # :977-996
-    fracs, all_zero = [], True
-    for G in Gs:
-        count = sum(1 for node in G.nodes() if node in nodelist_set)
-        fracs.append(count / G.order())
-        if count != 0:
-            all_zero = False
-    if all_zero:
-        sys.stderr.write("Invalid manifolds. Check that the node identifiers of the manifolds are present in the nodelist. Try setting --node-attribute if the node identifier is in a graphml attribute rather than the XML node attribute 'id'\n")
-        sys.exit(24)
-    sys.stdout.write("Printing manifold node representation in nodelist:\n")
-    for (G, fp), frac in zip(G_fp_pairs, fracs):
-        sys.stdout.write("{}: {:2.1f}%\n".format(fp, frac * 100))
-
-    U_fp = os.path.join(args.outdir, "U.csv")
-    V_fp = os.path.join(args.outdir, "V.csv")
-    obj_fp = os.path.join(args.outdir, "obj.txt")
-
-    X_test = None                                       # :1002-1013
+    manifolds = ManifoldSet.from_args(args)
+    if args.seed is not None:                              # both legacy streams, as the reference seeds them
+        np.random.seed(int(args.seed))
+        random.seed(int(args.seed))
+    data = DataMatrix(args)
+    X, nodelist = data.resolve_genes(args, manifolds)
+    manifolds.coverage(nodelist)
+    samples, X_test = data.samples, None
     if args.cross_validation is not None:
-        kf = KFold(n_splits=round(1 / args.cross_validation))
-        for train_index, test_index in kf.split(X):
-            X_test = X[test_index]
-            X = X[train_index]
-            samples = [samples[i] for i in train_index]
-            break
-
-    if not args.no_normalize:                           # :1019-1020, on the GPU (prmf_quantile_transform)
+        X, X_test, samples = hold_out(X, samples, args.cross_validation)
+    if not args.no_normalize:                              # :1019-1020, on the GPU (prmf_quantile_transform)
         from .preprocess import quantile_transform
         X = quantile_transform(X)
-
-    U_init = V_init = None                              # :1022-1064
+    U_init = V_init = None
     if args.manifolds_init is not None:
-        Gs_init = [fp_to_G[fp] for fp in args.manifolds_init]
-        init_fps = []
-        if len(args.manifolds_init) < args.k_latent:
-            non_init = list(set(manifold_fps) - set(args.manifolds_init))
-            chosen = random.sample(non_init, args.k_latent - len(args.manifolds_init))
-            init_fps = copy.copy(args.manifolds_init)
-            for fp in chosen:
-                Gs_init.append(fp_to_G[fp])
-                init_fps.append(fp)
-        elif len(args.manifolds_init) == args.k_latent:
-            init_fps = args.manifolds_init
-        else:
-            inds = np.random.choice(len(Gs_init), args.k_latent)
-            Gs_init = [Gs_init[i] for i in inds]
-            init_fps = [args.manifolds_init[i] for i in inds]
-        vs, us = [], []
-        for G in Gs_init:
-            v, on = pathway_to_vec(X, G, nodelist)
-            signal = v[on]
-            u, _res = nmf_init_u(X, v)
-            v_new, _res = nmf_init_v(X, u)
-            v_new[on] = signal
-            vs.append(v_new)
-            us.append(u)
-        V_init = np.concatenate(vs, axis=1)
-        U_init = np.concatenate(us, axis=1)
-        sys.stdout.write("Using the following manifolds for initialization:\n{}\n".format("\n".join(init_fps)))
-        with open(os.path.join(args.outdir, 'init_pathways.txt'), 'w') as fh:
-            fh.write("\n".join(init_fps))
+        U_init, V_init = initial_factors(args, X, manifolds, nodelist)
 
-    from .solver import nmf_pathway                     # the GPU solve (:1067)
-    U, V, obj_data = nmf_pathway(X, Gs, nodelist=nodelist, gamma=args.gamma, tradeoff=tradeoff,
-                                 k_latent=args.k_latent, U_init=U_init, V_init=V_init, verbose=args.verbose,
-                                 x_dtype=args.x_dtype)
-    cols = ["LV{}".format(x) for x in range(args.k_latent)]
-    U = pd.DataFrame(U, index=samples, columns=cols)
-    V = pd.DataFrame(V, index=nodelist, columns=cols)
-    U.to_csv(U_fp, sep=",", index=has_row_names, quoting=csv.QUOTE_NONNUMERIC)
-    V.to_csv(V_fp, sep=",", index=True, quoting=csv.QUOTE_NONNUMERIC)
-
-    if args.cross_validation is not None:               # :1073-1079
-        from .solver import measure_cv_performance     # GPU: one sweep + batched NNLS (prmf/__init__.py:768-798)
-        errs = measure_cv_performance(V.to_numpy(), X_test, x_dtype=args.x_dtype)
+    from .solver import measure_cv_performance, nmf_pathway
+    U, V, obj_data = nmf_pathway(X, manifolds.graphs, nodelist=nodelist, gamma=args.gamma,       # the GPU solve (:1067)
+                                 tradeoff=None if args.tradeoff == -1 else args.tradeoff, k_latent=args.k_latent,
+                                 U_init=U_init, V_init=V_init, verbose=args.verbose, x_dtype=args.x_dtype)
+    if X_test is not None:                                 # :1073-1079: one sweep + batched NNLS (prmf/__init__.py:768-798)
+        errs = measure_cv_performance(V, X_test, x_dtype=args.x_dtype)
         np.savetxt(os.path.join(args.outdir, 'test_error.csv'), errs, delimiter=",")
         obj_data['average_normalized_test_error'] = np.mean(errs)
-
-    with open(obj_fp, 'w') as fh:                        # :1081-1093
-        l2p = obj_data.pop('latent_to_pathway_data', {})
-        for k, v in obj_data.items():
-            fh.write("{} = {:0.5f}\n".format(k, v))
-        for k in sorted(l2p.keys()):
-            fh.write("{} -> {}\n".format(k, G_fp_pairs[l2p[k][0][0]][1]))
+    write_outputs(args, data, manifolds, samples, nodelist, U, V, obj_data)
 
 
 if __name__ == "__main__":

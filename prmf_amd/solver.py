@@ -11,6 +11,7 @@ through the ctypes C-ABI of include/prmf_hip.h.  PyTorch is used only to own
 device buffers and to name the current HIP stream.  There is no CPU fallback.
 """
 import ctypes as C
+import datetime
 import math
 import sys
 
@@ -417,6 +418,17 @@ def restrict(scores_kP, latent_to_pathway_data, percentile=19.9):
     return rv
 
 
+def print_latent_to_pathway_data(latent_to_pathway_data, out=None):
+    """The `--verbose` candidate table (prmf_runner.py:67-88): per latent factor its remaining candidate pathways,
+    best score first, `<pathway id>\t<score>` indented by two spaces."""
+    out = out or sys.stdout
+    lines = ["-----------------------------", "Latent to pathway match data:", "-----------------------------"]
+    for latent_id, data in latent_to_pathway_data.items():
+        lines.append("Latent vector: {}".format(latent_id))
+        lines.extend("  {}\t{}".format(pid, score) for pid, score in sorted(data, key=lambda x: x[1], reverse=True))
+    out.write("\n".join(lines) + "\n")
+
+
 def force_distinct_lapls(V, library, latent_to_pathway_data, k_to_lapl, gamma, delta):
     """prmf_runner.py:209-258: max-weight matching between latent factors and their
     remaining candidate pathways, weight 1/(gamma v^T L v + delta*ignore).  As in the
@@ -512,10 +524,12 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
                     l2p = force_distinct_lapls(Vh, library, l2p, dict(k_to_lapl), gamma, delta)
                     candidates_remain = False
                 else:
-                    sys.stderr.write('Before restrict\n')
+                    sys.stderr.write('Before restrict: ' + str(datetime.datetime.now()) + '\n')     # :762
                     l2p = restrict(engine.score_candidates(V), l2p)
-                    sys.stderr.write('After restrict\n')
+                    sys.stderr.write('After restrict: ' + str(datetime.datetime.now()) + '\n')      # :764
                     candidates_remain = any(len(v) > 1 for v in l2p.values())
+                if verbose:
+                    print_latent_to_pathway_data(l2p)                                              # :759, :770
             prev_obj, obj = obj, obj_data["obj"]
             converged = abs(obj - prev_obj) / obj < tol              # :772-774
         if best["obj_data"]["obj"] < obj_data["obj"]:                # :778-782

@@ -126,3 +126,12 @@ def test_cli_exit_codes(tmp_path):
     r = _run_cli(["--data", c["data"], "--outdir", out, "--manifolds", c["manifolds"][0], "--delimiter", "\t",
                   "--nodelist", bad_nodes], out)
     assert r.returncode == 24 and "Invalid manifolds" in r.stderr
+
+
+def test_verbose_candidate_table_format(capsys):
+    """--verbose prints, after every restrict / matching round, the remaining candidates of each latent factor
+    best score first (prmf_runner.py:67-88)."""
+    solver.print_latent_to_pathway_data({0: [(3, 0.25), (1, 1.5)], 1: [(2, 2)]})
+    out = capsys.readouterr().out.splitlines()
+    assert out == ["-----------------------------", "Latent to pathway match data:", "-----------------------------",
+                   "Latent vector: 0", "  1\t1.5", "  3\t0.25", "Latent vector: 1", "  2\t2"]
