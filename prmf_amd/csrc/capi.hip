@@ -273,6 +273,10 @@ SweepPrologue post_prologue(prmf_ctx* c, int it) {
   p.nwaves = c->vblocks;
   p.colnorm2 = c->colnorm2_ring + (size_t)slot * c->k;
   p.cross = c->cross_ring + slot;
+  if (c->nranks > 1) {                 // replicated multi-rank: the kept U^T U is the all-reduced one
+    p.gu_src = c->gram_buf;
+    p.gu_keep = c->Gu_keep + (size_t)slot * c->k * c->k;
+  }
   return p;
 }
 
@@ -390,7 +394,7 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, &c->hyper, 4))) return bail(rc);
   if ((rc = dev_alloc(c, &c->records, (size_t)MAX_RECORDS * PRMF_OBJ_STRIDE))) return bail(rc);
   if ((rc = dev_alloc(c, &c->colnorm, (size_t)k))) return bail(rc);
-  if (nranks == 1) {
+  if (nranks == 1 || c->replicated) {
     if ((rc = dev_alloc(c, &c->Gu_keep, (size_t)(MAX_RECORDS + 1) * k * k, false))) return bail(rc);
     if ((rc = dev_alloc(c, &c->Gv_keep, (size_t)(MAX_RECORDS + 1) * k * k, false))) return bail(rc);
     if ((rc = dev_alloc(c, &c->colnorm2_ring, (size_t)(MAX_RECORDS + 1) * k))) return bail(rc);
@@ -568,7 +572,7 @@ int prmf_set_pathway_library(prmf_ctx* c, int P, const int64_t* sup_ptr, const i
   if ((rc = dev_alloc(c, &c->gnum, (size_t)c->kc * max_sup))) return rc;
   if ((rc = dev_alloc(c, &c->gden, (size_t)c->kc * max_sup))) return rc;
   if ((rc = dev_alloc(c, &c->obj_scratch, (size_t)c->kc * max_sup))) return rc;
-  if (c->nranks == 1 && (rc = dev_alloc(c, &c->vsup_ring, (size_t)MAX_RECORDS * c->k * max_sup))) return rc;
+  if ((c->nranks == 1 || c->replicated) && (rc = dev_alloc(c, &c->vsup_ring, (size_t)MAX_RECORDS * c->k * max_sup))) return rc;
   c->have_lib = true;
   return PRMF_OK;
 }
@@ -651,8 +655,11 @@ int prmf_begin(prmf_ctx* c, float* dU, float* dV, double gamma, double delta, do
   if (!c->prepared && (rc = prepare(c, s))) return rc;
   // objective deferred to prmf_end + reductions folded into the sweeps: single rank, fused MFMA epilogues, default
   // 4-wave sweep workgroups, tradeoff feedback off (with it on, gamma/delta of step t+1 need the record of step t)
-  c->lazy = c->nranks == 1 && c->m > 0 && c->fused_u && c->fused_v && !(tradeoff >= 0.0) && c->plan_xv.nw == 4 &&
-            c->plan_xtu.nw == 4 && c->vsup_ring && !c->dist_driver && !(c->flags & PRMF_FLAG_EAGER_OBJECTIVE);
+  // Multi-rank, replicated mode: the same deferral (every rank holds all of V and the all-reduced U^T U and X^T U), but the
+  // U-side reduction stays a launch of its own right after the U epilogue so that the k x k all-reduce can run next to
+  // the X^T U sweep.  Column-sharded mode keeps the eager sequence (its objective pieces travel with the all-gather).
+  c->lazy = (c->nranks == 1 ? !c->dist_driver : c->replicated) && c->m > 0 && c->fused_u && c->fused_v && !(tradeoff >= 0.0) &&
+            c->plan_xv.nw == 4 && c->plan_xtu.nw == 4 && c->vsup_ring && !(c->flags & PRMF_FLAG_EAGER_OBJECTIVE);
   c->batch_open = true;
   return PRMF_OK;
 }
@@ -689,7 +696,12 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
         HIP_TRY(c, launch_gram_partials(fu, (float*)c->gram_partial, s));
         c->nparts_u = gram_blocks(fu.rows);
       }
-      return PRMF_OK;                  // U^T U is reduced, and the pathway terms are computed, by the X^T U sweep's prologue
+      if (c->nranks > 1) {             // the caller all-reduces U^T U next: reduce the local partials (+ pathway terms) now
+        HIP_TRY(c, launch_mid((const float*)c->gram_partial, c->nparts_u, c->k, c->gram_buf, c->lib, c->active_dev, c->col0,
+                              c->ncols, c->V, c->hyper, c->gnum, c->gden, s));
+        c->graph_done = true;
+      }
+      return PRMF_OK;                  // one rank: U^T U and the pathway terms come from the X^T U sweep's prologue
     }
     if (c->post_pending) {            // V^T V (and gamma/delta) of the previous iteration come from the aux stream
       HIP_TRY(c, hipStreamWaitEvent(s, c->ev_post, 0));
@@ -733,14 +745,15 @@ int prmf_phase_q(prmf_ctx* c, void* stream) {
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 2], s));
     // Q = X^T U_new                                       (:424)
     SweepPrologue pro;
-    if (c->lazy) pro = mid_prologue(c, c->cursor);
+    const bool mid_in_sweep = c->lazy && c->nranks == 1;
+    if (mid_in_sweep) pro = mid_prologue(c, c->cursor);
     HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xtu, c->XT, c->ldxt, c->n, c->Up, c->NT, c->slabs, c->slab_stride_q, s, c->split_f32,
-                           c->lazy ? &pro : nullptr));
+                           mid_in_sweep ? &pro : nullptr));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 3], s));
     // the replicated multi-rank mode all-reduces Q, so it needs the summed dense form even on the fused path
     if (!c->fused_v || c->replicated)
       HIP_TRY(c, launch_slab_sum_blocks(c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP, c->n, c->k, c->kc,
-                                        c->lr, c->q_send, s));
+                                        c->lr, c->q_send, c->plan_xtu.max_seg, s));
   } else {
     HIP_TRY(c, hipMemsetAsync(c->q_send, 0, (size_t)c->n * c->kc * c->lr * sizeof(float), s));
   }
@@ -760,8 +773,9 @@ int prmf_phase_v(prmf_ctx* c, void* stream) {
     // pathway terms and U^T U came from the sweep's prologue; the objective pieces are deferred to prmf_end
     HIP_TRY(c, launch_v_epilogue(c->V, c->n, c->k, c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP,
                                  c->gram_buf, c->pos, c->gnum, c->gden, c->lib.max_support, c->pack_dtype, c->Vp, c->Kpad_x,
-                                 c->vpartial, (float*)c->gram_partial, &c->gram_v_done, nullptr,
+                                 c->vpartial, (float*)c->gram_partial, &c->gram_v_done, c->replicated ? c->q_recv : nullptr,
                                  c->vsup_ring + (size_t)c->cursor * c->k * c->lib.max_support, c->wpt_v, s));
+    c->graph_done = false;
     c->nparts_v = epilogue_blocks(c->Kpad_x, c->wpt_v);
     if (!c->gram_v_done) {
       FactorView fv{c->V, (int)c->n, c->k, c->k, 0};
@@ -1117,9 +1131,9 @@ extern "C" int prmf_debug_slab_sum(prmf_ctx* c, int which, float* out_dev, void*
   if ((rc = set_device(c))) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (which == 0)
-    HIP_TRY(c, launch_slab_sum_blocks(c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP, c->m, c->k, c->k, 1, out_dev, s));
+    HIP_TRY(c, launch_slab_sum_blocks(c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP, c->m, c->k, c->k, 1, out_dev, c->plan_xv.max_seg, s));
   else
-    HIP_TRY(c, launch_slab_sum_blocks(c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP, c->n, c->k, c->k, 1, out_dev, s));
+    HIP_TRY(c, launch_slab_sum_blocks(c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP, c->n, c->k, c->k, 1, out_dev, c->plan_xtu.max_seg, s));
   return PRMF_OK;
 }
 

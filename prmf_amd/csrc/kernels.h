@@ -65,6 +65,8 @@ struct SweepPrologue {
   int nwaves = 0;
   double* colnorm2 = nullptr;           // [k]
   double* cross = nullptr;              // [1]
+  const double* gu_src = nullptr;       // multi-rank: the ALL-REDUCED U^T U of the closed iteration (still in the exchange
+  double* gu_keep = nullptr;            //   buffer) is copied to its kept slot here; null with one rank
   // PROLOGUE_MID (before X^T U): pathway terms of the V update on the old V
   PathwayLibDev lib{};
   const int32_t* active = nullptr;
@@ -149,7 +151,8 @@ hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStrea
 hipError_t launch_gram_partials(const FactorView& f, float* partial, hipStream_t s);
 // Q slabs -> q_send[nranks][n][kc]
 hipError_t launch_slab_sum_blocks(const float* slabs, const uint32_t* segmask, int panel_rows, int64_t slab_stride, int KP,
-                                  int64_t n, int k, int kc, int nranks, float* q_send, hipStream_t s);
+                                  int64_t n, int k, int kc, int nranks, float* q_send,
+                                  int max_seg /* most slabs a panel receives (plan.max_seg): sizes the cooperative sum */, hipStream_t s);
 hipError_t launch_set_hyper(double* hyper, double gamma, double delta, double tradeoff, hipStream_t s);
 hipError_t launch_set_active(int32_t* active_dev, const int32_t* host_vals, int k, hipStream_t s);
 // pos[n][kc] = index in the active pathway's support of gene j for own column c, or -1

@@ -129,6 +129,8 @@ __device__ __forceinline__ void run_sweep_prologue(const SweepPrologue& p, char*
     // workgroups from the far end of the grid first: at small k they are the ones without a Gram job
     for (int c = (int)(gridDim.x - 1 - blockIdx.x); c <= p.k; c += gridDim.x)
       colcross_job(p.vpartial, p.nwaves, p.k, c, p.colnorm2, p.cross, red);
+    if (p.gu_keep)
+      for (int e = (int)(blockIdx.x * 256 + threadIdx.x); e < kk2; e += (int)(gridDim.x * 256)) p.gu_keep[e] = p.gu_src[e];
   } else if (p.kind == PROLOGUE_MID) {
     float* vs = reinterpret_cast<float*>(lds + 2048);
     const bool fits = lds_bytes >= 2048 + (int)sizeof(float) * p.lib.max_support;

@@ -848,15 +848,24 @@ hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G
 template <int NT>
 __global__ void __launch_bounds__(256)
 slab_sum_blocks_kernel(const float* __restrict__ slabs, const uint32_t* __restrict__ segmask, int panel_rows,
-                       int64_t slab_stride, int64_t n, int k, int kc, float* __restrict__ q_send) {
-  // one wave per 32-row tile: fragment-order 16-B loads, summed over the tile's segments, written by owner block
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                       int64_t slab_stride, int64_t n, int k, int kc, float* __restrict__ q_send, int wpt) {
+  // `wpt` waves per 32-row tile (cooperative slab sum, see my_segments): fragment-order 16-B loads, summed over the
+  // tile's segments, written by owner block
+  constexpr int COMB = NT <= 2 ? 4 * NT * 16 * 64 : 1;
+  __shared__ float comb[COMB];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int c = lane & 31, h = lane >> 5;
+  const int tpw = 4 / wpt, sub = wave % wpt, tslot = wave / wpt;
   const int64_t ntiles = (n + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+  for (int64_t base = (int64_t)blockIdx.x * tpw; base < ntiles; base += (int64_t)gridDim.x * tpw) {
+    const int64_t tile = base + tslot;
     const int64_t row0 = tile * 32;
+    const bool live = tile < ntiles;
     float q[NT][16];
-    load_slab_tile<NT>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);
+    if (live) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, q);
+    else load_slab_tile<NT>(slabs, slab_stride, 0u, tile, lane, q);
+    if constexpr (NT <= 2) combine_tile_sums<NT>(q, wpt, sub, wave, lane, comb);
+    if (!live || sub != 0) continue;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int col = 32 * t + c;
@@ -873,15 +882,18 @@ slab_sum_blocks_kernel(const float* __restrict__ slabs, const uint32_t* __restri
 }
 
 hipError_t launch_slab_sum_blocks(const float* slabs, const uint32_t* segmask, int panel_rows, int64_t slab_stride, int KP,
-                                  int64_t n, int k, int kc, int nranks, float* q_send, hipStream_t s) {
+                                  int64_t n, int k, int kc, int nranks, float* q_send, int max_seg, hipStream_t s) {
   (void)nranks;
+  const int NT = KP / 32;
+  const int wpt = epilogue_wpt(n, max_seg, NT);
   const int64_t tiles = (n + 31) / 32;
-  const int grid = (int)((tiles + 3) / 4 < 2048 ? (tiles + 3) / 4 : 2048);
-  switch (KP / 32) {
-    case 1: slab_sum_blocks_kernel<1><<<grid, 256, 0, s>>>(slabs, segmask, panel_rows, slab_stride, n, k, kc, q_send); break;
-    case 2: slab_sum_blocks_kernel<2><<<grid, 256, 0, s>>>(slabs, segmask, panel_rows, slab_stride, n, k, kc, q_send); break;
-    case 3: slab_sum_blocks_kernel<3><<<grid, 256, 0, s>>>(slabs, segmask, panel_rows, slab_stride, n, k, kc, q_send); break;
-    case 4: slab_sum_blocks_kernel<4><<<grid, 256, 0, s>>>(slabs, segmask, panel_rows, slab_stride, n, k, kc, q_send); break;
+  const int tpw = 4 / wpt;
+  const int grid = (int)((tiles + tpw - 1) / tpw < 2048 ? (tiles + tpw - 1) / tpw : 2048);
+  switch (NT) {
+    case 1: slab_sum_blocks_kernel<1><<<grid, 256, 0, s>>>(slabs, segmask, panel_rows, slab_stride, n, k, kc, q_send, wpt); break;
+    case 2: slab_sum_blocks_kernel<2><<<grid, 256, 0, s>>>(slabs, segmask, panel_rows, slab_stride, n, k, kc, q_send, wpt); break;
+    case 3: slab_sum_blocks_kernel<3><<<grid, 256, 0, s>>>(slabs, segmask, panel_rows, slab_stride, n, k, kc, q_send, 1); break;
+    case 4: slab_sum_blocks_kernel<4><<<grid, 256, 0, s>>>(slabs, segmask, panel_rows, slab_stride, n, k, kc, q_send, 1); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
