@@ -30,6 +30,10 @@
 #include "prologue.h"
 
 
+#ifndef PRMF_SWEEP_MINW
+#define PRMF_SWEEP_MINW 2     // 1 (the compiler then takes 268 registers at k = 128: one workgroup per CU) is 12% slower there
+#endif
+
 namespace prmf {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -294,7 +298,7 @@ __device__ __forceinline__ void store_b_chunk(u32x4* sb, const u32x4 (&src)[NB],
 //              workgroup -> more resident workgroups (bytes in flight) per CU
 // The chunk loop is unrolled x2 with compile-time LDS buffer offsets; a segment may have any number of chunks.
 template <int MODE, int MT, int NT, int NW, bool BDB>
-__global__ void __launch_bounds__(64 * NW, (MODE == 2 && NT == 2 && NW == 4) ? 2 : 1)
+__global__ void __launch_bounds__(64 * NW, PRMF_SWEEP_MINW)   // two workgroups per CU: at most 256 registers (arch + accumulator) per wave
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
              const uint4* __restrict__ Bp, int npanels, int g_begin, int ngroups /* work units (UNIT chunks each) [g_begin, g_begin+ngroups) of every row */,
              int nx, int pmax, int seg_base, float* __restrict__ slabs, int64_t slab_stride,

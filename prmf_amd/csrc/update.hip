@@ -11,6 +11,10 @@
 #include "kernels.h"
 #include "prologue.h"
 
+#ifndef PRMF_EPI_NB2
+#define PRMF_EPI_NB2 2     // slab segments per load batch at k = 64 (4 measured identical: profiles/r02_ab_epilogue_slab_batch.txt)
+#endif
+
 namespace prmf {
 
 // float32 machine epsilon used as the clamp value (prmf_runner.py:23)
@@ -500,7 +504,7 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
     float p[NT][16];
     if constexpr (NT <= 2) {
       if (wpt > 1) {
-        if (live) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, p);
+        if (live) load_slab_tile<NT, NT == 1 ? 4 : PRMF_EPI_NB2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, p);
         else load_slab_tile<NT>(slabs, slab_stride, 0u, tile, lane, p);
         combine_tile_sums<NT>(p, wpt, sub, wave, lane, red_store);
       }
@@ -513,7 +517,7 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
     if (lead && live) {
       // issue every load of the tile first (slabs, A layout, C/D layout), then the MFMA chain
       float ua[16 * NT], uu[NT][16];
-      if (wpt == 1) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, p);
+      if (wpt == 1) load_slab_tile<NT, NT == 1 ? 4 : PRMF_EPI_NB2>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, p);
       load_tile_a_layout<NT>(U, m, k, row0, lane, ua);
       float* const Ut = U + row0 * k;
       const int last = (int)((m - row0 < 32 ? m - row0 : 32) - 1);
@@ -636,7 +640,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
     float q[NT][16];
     if constexpr (NT <= 2 && !DENSE) {
       if (wpt > 1) {
-        if (live) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, q);
+        if (live) load_slab_tile<NT, NT == 1 ? 4 : PRMF_EPI_NB2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, q);
         else load_slab_tile<NT>(slabs, slab_stride, 0u, tile, lane, q);
         combine_tile_sums<NT>(q, wpt, sub, wave, lane, red_store);
       }
@@ -663,7 +667,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
 #pragma unroll
           for (int i = 0; i < 16; ++i) q[t][i] = Qt[cd_off(t, i)];
       } else {
-        if (wpt == 1) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);
+        if (wpt == 1) load_slab_tile<NT, NT == 1 ? 4 : PRMF_EPI_NB2>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);
       }
       float ua[16 * NT];
       load_tile_a_layout<NT>(V, n, k, row0, lane, ua);
@@ -862,7 +866,7 @@ slab_sum_blocks_kernel(const float* __restrict__ slabs, const uint32_t* __restri
     const int64_t row0 = tile * 32;
     const bool live = tile < ntiles;
     float q[NT][16];
-    if (live) load_slab_tile<NT, NT == 1 ? 4 : 2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, q);
+    if (live) load_slab_tile<NT, NT == 1 ? 4 : PRMF_EPI_NB2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, q);
     else load_slab_tile<NT>(slabs, slab_stride, 0u, tile, lane, q);
     if constexpr (NT <= 2) combine_tile_sums<NT>(q, wpt, sub, wave, lane, comb);
     if (!live || sub != 0) continue;
