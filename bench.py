@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed --steps block (median reported)")
+    ap.add_argument("--eager-objective", action="store_true",
+                    help="A/B switch: evaluate the objective every iteration (7 launches per iteration, the round-1 sequence) "
+                         "instead of the default 4-launch iteration with the records evaluated per batch")
     ap.add_argument("--dist-mode", default="colshard", choices=["colshard", "replicated"],
                     help="N > 1: how the V update is shared.  colshard (default; BASELINE.json's wording): the k latent "
                          "columns and their pathway Laplacians are sharded -- reduce-scatter of X^T U by owner column "
@@ -167,7 +170,7 @@ def main():
     lo, hi = syn.shard_rows(m, world, rank)
     Xd = syn.x_rows_torch(torch, dev, args.seed, n, k, lo, hi, tdt)
     eng = PrmfEngine(hi - lo, n, k, x_dtype=x_dtype, device=local_rank, nranks=world, rank=rank,
-                     dist_mode=args.dist_mode if world > 1 else None)
+                     dist_mode=args.dist_mode if world > 1 else None, eager_objective=args.eager_objective)
     cdev = dev if backend == "nccl" else "cpu"         # where the tiny control tensors of the collectives live
     nsq = torch.tensor([eng.local_norm_sq(Xd)], dtype=torch.float64, device=cdev)
     if world > 1:
@@ -254,6 +257,8 @@ def main():
                                    "active pathway k mod P, gamma=||X||/k, delta=10/||X||"
                                    % (args.workload, m, n, x_dtype, k, P),
                        "samples": m, "genes": n, "k_latent": k, "pathways": P,
+                       "launches_per_iteration": (None if world > 1 else (7 if k <= 64 else 11) if args.eager_objective
+                                                  else (4 if k <= 64 else 6)),
                        "parallelism": ("single GPU" if world == 1 else
                                        "X row-sharded x%d, V update %s, RCCL %s" % (
                                            world, eng.dist_mode, "in-library" if runner.native else "host-driven"))},
