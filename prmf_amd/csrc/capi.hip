@@ -291,7 +291,7 @@ SweepPrologue mid_prologue(prmf_ctx* c, int it) {
   p.lib = c->lib;
   p.active = c->active_dev;
   p.col0 = 0;
-  p.ncols = c->k;
+  p.ncols = 0;                         // the pathway terms were computed next to the U epilogue (GraphJob)
   p.V = c->V;
   p.hyper = c->hyper;
   p.gnum = c->gnum;
@@ -689,8 +689,20 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
     if (c->lazy) {
       c->gv_pending = false;
       bool gram_done = false;
+      GraphJob gj;                     // one rank: the pathway terms ride in the U epilogue launch (extra workgroups)
+      if (c->nranks == 1) {
+        gj.lib = c->lib;
+        gj.active = c->active_dev;
+        gj.col0 = 0;
+        gj.ncols = c->k;
+        gj.V = c->V;
+        gj.hyper = c->hyper;
+        gj.gnum = c->gnum;
+        gj.gden = c->gden;
+      }
       HIP_TRY(c, launch_u_epilogue(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP,
-                                   c->Gv, c->pack_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, c->wpt_u, s));
+                                   c->Gv, c->pack_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, c->wpt_u, s,
+                                   c->nranks == 1 ? &gj : nullptr));
       c->nparts_u = epilogue_blocks(c->Kpad_xt, c->wpt_u);
       if (!gram_done) {                // k > 64: the epilogue has no registers left for the Gram tiles
         HIP_TRY(c, launch_gram_partials(fu, (float*)c->gram_partial, s));

@@ -105,6 +105,18 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
                        const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s,
                        bool split = false /* f32 X as three bf16 pieces, packedB in the bf16 hi/lo layout */,
                        const SweepPrologue* prologue = nullptr /* only with 4-wave workgroups (plan.nw == 4) */);
+// Pathway terms of the V update as extra workgroups of the U epilogue launch (they depend on the OLD V and gamma / delta
+// only; the epilogue leaves a quarter of the chip's slots idle and runs longer than the terms' dependent-load chain, so
+// they cost nothing there -- as a prologue of the X^T U sweep they delayed k of its workgroups by 6-9 us).  ncols = 0: none.
+struct GraphJob {
+  PathwayLibDev lib{};
+  const int32_t* active = nullptr;
+  int col0 = 0, ncols = 0;
+  const float* V = nullptr;
+  const double* hyper = nullptr;
+  float* gnum = nullptr;
+  float* gden = nullptr;
+};
 // the same prologue work as a stand-alone launch (end of a batch: no sweep follows)
 hipError_t launch_prologue_alone(const SweepPrologue& p, hipStream_t s);
 hipError_t launch_copy_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols,
@@ -125,7 +137,7 @@ int epilogue_wpt(int64_t rows, int max_seg, int NT);   // waves sharing a tile's
 int epilogue_blocks(int64_t rows, int wpt = 1);
 hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
-                             float* gram_partial, bool* gram_done, int wpt, hipStream_t s);
+                             float* gram_partial, bool* gram_done, int wpt, hipStream_t s, const GraphJob* graph = nullptr);
 hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G, hipStream_t s);
 // fused single-rank V epilogue (k % 4 == 0): in place, + packing + per-wave partials [waves][k+1]
 int v_epilogue_waves(int64_t n, int wpt = 1);

@@ -478,12 +478,21 @@ template <int NT, bool BF16, bool GRAM>
 __global__ void __launch_bounds__(256, NT <= 2 ? 2 : 1)
 u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs, const uint32_t* __restrict__ segmask,
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gv, void* __restrict__ packed,
-                  int64_t ntiles_pack, float* __restrict__ gram_partial, int wpt /* waves per tile: 1, 2 or 4 */) {
+                  int64_t ntiles_pack, float* __restrict__ gram_partial, int wpt /* waves per tile: 1, 2 or 4 */,
+                  int nblocks_main, const GraphJob gj) {
   constexpr int KP = 32 * NT, NP = NT * (NT + 1) / 2;
   constexpr int COMB = NT <= 2 ? 4 * NT * 16 * 64 : 1;              // cooperative slab sums exist for k <= 64
   __shared__ float Gs[KP * KP];
   __shared__ float red_store[(GRAM ? 4 * 16 * 64 : 1) > COMB ? (GRAM ? 4 * 16 * 64 : 1) : COMB];   // Gram reduction | slab-sum exchange
   float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(red_store);
+  if ((int)blockIdx.x >= nblocks_main) {      // extra workgroups: the pathway terms of one latent column each (GraphJob)
+    const int c = (int)blockIdx.x - nblocks_main;
+    if ((size_t)gj.lib.max_support * sizeof(float) <= sizeof(Gs))
+      graph_terms_body<true>(gj.lib, gj.active, gj.col0, c, gj.V, k, gj.hyper, gj.gnum, gj.gden, Gs);
+    else
+      graph_terms_body<false>(gj.lib, gj.active, gj.col0, c, gj.V, k, gj.hyper, gj.gnum, gj.gden, Gs);
+    return;
+  }
   stage_gram<NT>(Gv, k, 0, k, Gs);
   __syncthreads();
   // the wave index is made provably uniform: tile bases then live in scalar registers
@@ -496,7 +505,7 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) gtot[p][ii] = 0.f;
   // uniform trip count over the workgroup (the cooperative sum and the Gram round have barriers)
-  for (int64_t base = (int64_t)blockIdx.x * tpw; base < ntiles_pack; base += (int64_t)gridDim.x * tpw) {
+  for (int64_t base = (int64_t)blockIdx.x * tpw; base < ntiles_pack; base += (int64_t)nblocks_main * tpw) {
     const int64_t tile = base + tslot;
     const int64_t row0 = tile * 32;
     const bool live = tile < ntiles_pack && row0 < m;
@@ -580,15 +589,17 @@ int epilogue_blocks(int64_t rows, int wpt) {
 
 hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
-                             float* gram_partial, bool* gram_done, int wpt, hipStream_t s) {
+                             float* gram_partial, bool* gram_done, int wpt, hipStream_t s, const GraphJob* graph) {
   const int NT = KP / 32;
   const int64_t ntiles = Kpad / 32;          // every tile of the packed buffer is (re)written, zero beyond m
   if (NT > 2) wpt = 1;
-  const int grid = epilogue_blocks(Kpad, wpt);
+  const int nmain = epilogue_blocks(Kpad, wpt);
+  const GraphJob gj = graph ? *graph : GraphJob{};
+  const int grid = nmain + (gj.ncols > 0 ? gj.ncols : 0);
   *gram_done = NT <= 2;
 #define PRMF_UEP(NTV, GR)                                                                                          \
-  if (x_dtype == 1) u_epilogue_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial, wpt); \
-  else u_epilogue_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial, wpt)
+  if (x_dtype == 1) u_epilogue_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial, wpt, nmain, gj); \
+  else u_epilogue_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial, wpt, nmain, gj)
   switch (NT) {
     case 1: PRMF_UEP(1, true); break;
     case 2: PRMF_UEP(2, true); break;
