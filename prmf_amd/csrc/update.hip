@@ -11,6 +11,9 @@
 #include "kernels.h"
 #include "prologue.h"
 
+#ifndef PRMF_EPI_CS_MIN_NT
+#define PRMF_EPI_CS_MIN_NT 3   // column-split epilogue (one wave per 32-column tile) from this many column tiles (k > 64)
+#endif
 #ifndef PRMF_EPI_NB2
 #define PRMF_EPI_NB2 2     // slab segments per load batch at k = 64 (4 measured identical: profiles/r02_ab_epilogue_slab_batch.txt)
 #endif
@@ -572,6 +575,7 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
 // waves that share one 32-row tile in the fused epilogues (see my_segments): as many as keep the launch within the
 // chip's 2048 resident waves and leave every wave at least one slab segment
 int epilogue_wpt(int64_t rows, int max_seg, int NT) {
+  if (NT >= PRMF_EPI_CS_MIN_NT) return NT;      // column-split form: the NT waves of a tile own one column tile each
   if (NT > 2) return 1;
   const int64_t tiles = (rows + 31) / 32;
   int w = 1;
@@ -587,14 +591,320 @@ int epilogue_blocks(int64_t rows, int wpt) {
   return (int)(blocks < 1 ? 1 : blocks);
 }
 
+// ---------------------------------------------------------------------------
+// Column-split fused epilogue (k > 64): one wave per (32-row tile, 32-column tile).
+//
+// With one wave per whole tile (the kernels above) a k = 128 tile is 256 f32 MFMAs in a row, 64-register arrays in
+// every phase, no room for the Gram tiles (a separate gram_mfma launch per side) and one workgroup per CU: 63 us (U) and
+// 98 us (V) per iteration at 25000 x 25000 plus 2 x 22 us of Gram launches.  Here the NT waves of a tile each own one
+// column tile t: they sum only their quarter of every slab segment, run 64 MFMAs of F (A layout, all k columns) against
+// their 32 columns of G, update / store / pack their 32 columns from 16-register arrays, and then exchange the updated
+// tile through LDS so that the NT (NT + 1) / 2 Gram blocks of the tile are shared out among them (f32 MFMA, operands
+// straight from the exchange buffer).  Same arithmetic per element; the summation order of the slabs is the slab-index
+// order as before.
+// ---------------------------------------------------------------------------
+struct EpiArgs {
+  float* F;                     // U (m x k) or V (n x k), updated in place
+  int64_t rows;
+  int k;
+  const float* slabs;           // sweep slabs, or (DENSE) Q [n][k]
+  const uint32_t* segmask;
+  int panel_rows;
+  int64_t slab_stride;
+  const double* G;              // V^T V (U side) or U^T U (V side)
+  void* packed;
+  int64_t ntiles_pack;
+  float* gram_partial;          // [blocks][k*k]
+  int nblocks_main;
+  // V side only
+  const int32_t* pos;
+  const float* gnum;
+  const float* gden;
+  int max_support;
+  double* partial;              // [blocks * 4][k + 1]
+  float* vsup;
+};
+
+template <int NT, bool IS_V, bool BF16, bool DENSE>
+__global__ void __launch_bounds__(256, 2)
+epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
+  constexpr int KP = 32 * NT, HALF = KP / 2, NP = NT * (NT + 1) / 2;
+  constexpr int TPW = NT == 3 ? 1 : 4 / NT;                 // tiles per workgroup round
+  constexpr int GMAX = (NP + NT - 1) / NT;                  // Gram blocks per wave: block p belongs to wave p % NT, slot p / NT
+  __shared__ float Gs[KP * KP];
+  __shared__ float exch[4][16][64];                         // the updated tile, one column tile per wave (C/D layout)
+  const int k = a.k;
+  if ((int)blockIdx.x >= a.nblocks_main) {                  // extra workgroups: pathway terms of one latent column each
+    const int c = (int)blockIdx.x - a.nblocks_main;
+    if ((size_t)gj.lib.max_support * sizeof(float) <= sizeof(Gs))
+      graph_terms_body<true>(gj.lib, gj.active, gj.col0, c, gj.V, k, gj.hyper, gj.gnum, gj.gden, Gs);
+    else
+      graph_terms_body<false>(gj.lib, gj.active, gj.col0, c, gj.V, k, gj.hyper, gj.gnum, gj.gden, Gs);
+    return;
+  }
+  stage_gram<NT>(a.G, k, 0, k, Gs);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int c = lane & 31, h = lane >> 5, r = lane & 31;
+  const int tslot = NT == 3 ? 0 : wave / NT, t = NT == 3 ? wave : wave % NT;
+  const bool wave_on = t < NT;                              // NT = 3: the fourth wave only keeps the barriers company
+  const int col = 32 * t + c, colc = col < k ? col : k - 1;
+  f32x16 gacc[GMAX];
+#pragma unroll
+  for (int p = 0; p < GMAX; ++p)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gacc[p][i] = 0.f;
+  double colsq = 0.0, cross = 0.0;
+  for (int64_t base = (int64_t)blockIdx.x * TPW; base < a.ntiles_pack; base += (int64_t)a.nblocks_main * TPW) {
+    const int64_t tile = base + tslot;
+    const int64_t row0 = tile * 32;
+    const bool in_range = wave_on && tile < a.ntiles_pack;
+    const bool live = in_range && row0 < a.rows;
+    float* const Ft = a.F + (live ? row0 : 0) * k;
+    const int last = live ? (int)((a.rows - row0 < 32 ? a.rows - row0 : 32) - 1) : 0;
+    auto cd_off = [&](int i) -> unsigned {
+      const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
+      return (unsigned)((rr < last ? rr : last) * k + colc);
+    };
+    float vn[16], q[16], fv[16], gn[16], gd[16];
+    int ps[16];
+    f32x16 den;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      vn[i] = 0.f;
+      q[i] = 0.f;
+      den[i] = 0.f;
+    }
+    if (live) {
+      // (1) this wave's column tile of the slab segments, in slab-index order, 4 segments per round trip
+      if constexpr (DENSE) {
+        const float* const Qt = a.slabs + row0 * k;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) q[i] = Qt[cd_off(i)];
+      } else {
+        const int64_t fbase = (tile * NT + t) * 256 + lane;         // float4 index of (tile, t, q4 = 0, lane)
+        uint32_t mask = a.segmask[row0 / a.panel_rows];
+        while (mask) {
+          int sg[4];
+          float on[4];
+          const int first = __ffs(mask) - 1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            sg[j] = mask ? __ffs(mask) - 1 : first;
+            on[j] = mask ? 1.f : 0.f;
+            mask &= mask - 1;
+          }
+          float4 v[4][4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4* sl = reinterpret_cast<const float4*>(a.slabs + (int64_t)sg[j] * a.slab_stride) + fbase;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) v[j][q4] = sl[q4 * 64];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              q[4 * q4] += on[j] * v[j][q4].x;
+              q[4 * q4 + 1] += on[j] * v[j][q4].y;
+              q[4 * q4 + 2] += on[j] * v[j][q4].z;
+              q[4 * q4 + 3] += on[j] * v[j][q4].w;
+            }
+        }
+      }
+      // (2) den = F_tile (all k columns, A layout) x G[:, this column tile] on the f32 MFMA; the old values of this
+      //     column tile (C/D layout) and, V side, the position map and the gathered pathway terms
+      float ua[HALF];
+      load_tile_a_layout<NT>(a.F, a.rows, k, row0, lane, ua);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) fv[i] = Ft[cd_off(i)];
+      if constexpr (IS_V) {
+        const int32_t* const pt = a.pos + row0 * k;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ps[i] = pt[cd_off(i)];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < HALF; ++s2)
+        den = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[s2], Gs[(s2 + HALF * h) * KP + 32 * t + r], den, 0, 0, 0);
+      if constexpr (IS_V) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {        // branch-free gathers: off-support entries read element 0 and are masked
+          const unsigned goff = ps[i] >= 0 ? (unsigned)colc * (unsigned)a.max_support + (unsigned)ps[i] : 0u;
+          gn[i] = a.gnum[goff];
+          gd[i] = a.gden[goff];
+        }
+      }
+    }
+    // The tile's waves update F in place, and every one of them has just read ALL columns of the old tile (A layout):
+    // nobody stores before everybody's loads have been consumed by the MFMA chain above.
+    __syncthreads();
+    if (live) {
+      // (3) the element-wise update of this column tile
+      if constexpr (IS_V) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const bool on = ps[i] >= 0, valid = row < a.rows && col < k;
+          const float num = q[i] + (on ? gn[i] : 0.f);
+          float d = den[i] + (on ? gd[i] : 0.f);
+          if (d < PRMF_EPS) d = PRMF_EPS;                              // :442
+          float r2 = fv[i] * (num / d);                                // :443
+          if (r2 < PRMF_EPS) r2 = PRMF_EPS;                            // :444
+          if (!valid) r2 = 0.f;
+          if (valid) Ft[cd_off(i)] = r2;
+          if (a.vsup && on && valid) a.vsup[(unsigned)col * (unsigned)a.max_support + (unsigned)ps[i]] = r2;
+          colsq += (double)r2 * (double)r2;
+          cross += (double)(valid ? q[i] : 0.f) * (double)r2;
+          vn[i] = r2;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const bool valid = row < a.rows && col < k;
+          const float d = den[i] + fv[i];                              // U (V^T V) + U      (prmf_runner.py:421)
+          float r2 = fv[i] * ((d != 0.f) ? q[i] / d : 1.f);            // 0/0 := 1           (:422)
+          if (!valid) r2 = 0.f;
+          if (valid) Ft[cd_off(i)] = r2;
+          vn[i] = r2;
+        }
+      }
+    }
+    // (4) this column tile's fragments of the packed factor (tiles past the end are packed as zeros)
+    if (in_range) {
+      if constexpr (BF16) {
+        uint4* out = reinterpret_cast<uint4*>(a.packed);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          float e[8];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(vn[8 * kb + i]), __float_as_uint(vn[8 * kb + 4 + i]), false, false);
+            e[i] = __uint_as_float(sw[0]);
+            e[4 + i] = __uint_as_float(sw[1]);
+          }
+          unsigned hi[4], lo[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            hi[j] = pack_bf16_pair(e[2 * j], e[2 * j + 1]);
+            lo[j] = pack_bf16_pair(e[2 * j] - bf16_trunc_back(e[2 * j]), e[2 * j + 1] - bf16_trunc_back(e[2 * j + 1]));
+          }
+          const int64_t blk = ((row0 / 16 + kb) * NT + t) * 2;
+          out[blk * 64 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+          out[(blk + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+      } else {
+        float4* out = reinterpret_cast<float4*>(a.packed);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          out[((row0 / 8 + g) * NT + t) * 64 + lane] = make_float4(vn[4 * g], vn[4 * g + 1], vn[4 * g + 2], vn[4 * g + 3]);
+      }
+    }
+    // (5) Gram blocks of the tile: exchange the column tiles through LDS; block p = (t1, t2 >= t1) belongs to wave p % NT
+#pragma unroll
+    for (int i = 0; i < 16; ++i) exch[wave][i][lane] = vn[i];
+    __syncthreads();
+    if (wave_on) {
+      const int w0 = NT == 3 ? 0 : tslot * NT;
+      int p = 0;
+#pragma unroll
+      for (int t1 = 0; t1 < NT; ++t1)
+#pragma unroll
+        for (int t2 = t1; t2 < NT; ++t2, ++p)
+          if (p % NT == t) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+              gacc[p / NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(exch[w0 + t1][i][lane], exch[w0 + t2][i][lane], gacc[p / NT], 0, 0, 0);
+          }
+    }
+    __syncthreads();
+  }
+  if constexpr (IS_V) {
+    // per-wave partials [k + 1]: this wave's 32 columns, zeros elsewhere, <Q, V_new> last (fixed order)
+    double* out = a.partial + ((int64_t)blockIdx.x * 4 + wave) * (k + 1);
+    const double tot = colsq + __shfl_xor(colsq, 32);
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+      if (h == 0 && 32 * tt + c < k) out[32 * tt + c] = (wave_on && tt == t) ? tot : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cross += __shfl_xor(cross, off);
+    if (lane == 0) out[k] = cross;
+  }
+  // the workgroup's Gram partial: the tile slots of a workgroup (k <= 64: 2 or 4) are summed through LDS in slot order
+  float* gout = a.gram_partial + (int64_t)blockIdx.x * k * k;
+  constexpr int SLOTS = NT == 3 ? 1 : 4 / NT;
+  int p = 0;
+#pragma unroll
+  for (int t1 = 0; t1 < NT; ++t1)
+#pragma unroll
+    for (int t2 = t1; t2 < NT; ++t2, ++p) {
+      const bool own = wave_on && (p % NT == t);
+      f32x16 g = gacc[p / NT];
+#pragma unroll
+      for (int sl = 1; sl < SLOTS; ++sl) {
+        __syncthreads();
+        if (own && tslot == sl)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) exch[0][i][lane] = g[i];
+        __syncthreads();
+        if (own && tslot == 0)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) g[i] += exch[0][i][lane];
+      }
+      if (own && tslot == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int ra = 32 * t1 + (i & 3) + 8 * (i >> 2) + 4 * h, cb = 32 * t2 + c;
+          if (ra < k && cb < k) {
+            gout[ra * k + cb] = g[i];
+            if (t1 != t2) gout[cb * k + ra] = g[i];
+          }
+        }
+      }
+    }
+}
+
+template <bool IS_V>
+static hipError_t launch_epilogue_cs(const EpiArgs& a, const GraphJob& gj, int NT, bool bf16, bool dense, int grid, hipStream_t s) {
+#define PRMF_CS(NTV)                                                                                     \
+  if (bf16) {                                                                                            \
+    if (dense) epilogue_cs_kernel<NTV, IS_V, true, IS_V><<<grid, 256, 0, s>>>(a, gj);                       \
+    else epilogue_cs_kernel<NTV, IS_V, true, false><<<grid, 256, 0, s>>>(a, gj);                            \
+  } else {                                                                                               \
+    if (dense) epilogue_cs_kernel<NTV, IS_V, false, IS_V><<<grid, 256, 0, s>>>(a, gj);                      \
+    else epilogue_cs_kernel<NTV, IS_V, false, false><<<grid, 256, 0, s>>>(a, gj);                           \
+  }
+  switch (NT) {
+#if PRMF_EPI_CS_MIN_NT <= 1
+    case 1: PRMF_CS(1) break;
+#endif
+#if PRMF_EPI_CS_MIN_NT <= 2
+    case 2: PRMF_CS(2) break;
+#endif
+    case 3: PRMF_CS(3) break;
+    case 4: PRMF_CS(4) break;
+    default: return hipErrorInvalidValue;
+  }
+#undef PRMF_CS
+  return hipGetLastError();
+}
+
 hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
                              float* gram_partial, bool* gram_done, int wpt, hipStream_t s, const GraphJob* graph) {
   const int NT = KP / 32;
   const int64_t ntiles = Kpad / 32;          // every tile of the packed buffer is (re)written, zero beyond m
+  const GraphJob gj = graph ? *graph : GraphJob{};
+  if (NT >= PRMF_EPI_CS_MIN_NT) {
+    EpiArgs a{};
+    a.F = U; a.rows = m; a.k = k; a.slabs = slabs; a.segmask = segmask; a.panel_rows = panel_rows; a.slab_stride = slab_stride;
+    a.G = Gv; a.packed = packed; a.ntiles_pack = ntiles; a.gram_partial = gram_partial;
+    a.nblocks_main = epilogue_blocks(Kpad, NT);
+    *gram_done = true;
+    return launch_epilogue_cs<false>(a, gj, NT, x_dtype == 1, false, a.nblocks_main + (gj.ncols > 0 ? gj.ncols : 0), s);
+  }
   if (NT > 2) wpt = 1;
   const int nmain = epilogue_blocks(Kpad, wpt);
-  const GraphJob gj = graph ? *graph : GraphJob{};
   const int grid = nmain + (gj.ncols > 0 ? gj.ncols : 0);
   *gram_done = NT <= 2;
 #define PRMF_UEP(NTV, GR)                                                                                          \
@@ -759,6 +1069,15 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
                              hipStream_t s) {
   const int NT = KP / 32;
   const int64_t ntiles = Kpad / 32;
+  if (NT >= PRMF_EPI_CS_MIN_NT) {
+    EpiArgs a{};
+    a.F = V; a.rows = n; a.k = k; a.slabs = qdense ? qdense : slabs; a.segmask = segmask; a.panel_rows = panel_rows;
+    a.slab_stride = slab_stride; a.G = Gu; a.packed = packed; a.ntiles_pack = ntiles; a.gram_partial = gram_partial;
+    a.nblocks_main = epilogue_blocks(Kpad, NT);
+    a.pos = pos; a.gnum = gnum; a.gden = gden; a.max_support = max_support; a.partial = partial; a.vsup = vsup;
+    *gram_done = true;
+    return launch_epilogue_cs<true>(a, GraphJob{}, NT, x_dtype == 1, qdense != nullptr, a.nblocks_main, s);
+  }
   // `wpt` must be the value the caller sized `partial` with (v_epilogue_waves): every partial row is written by
   // exactly one wave; the dense-Q form has no slabs to share and runs one wave per tile on the same grid
   if (NT > 2) wpt = 1;
