@@ -379,7 +379,7 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, (char**)&c->Up, (size_t)packed_bytes(c, c->Kpad_xt)))) return bail(rc);
   if ((rc = dev_alloc(c, &c->slabs, (size_t)slab_floats, false))) return bail(rc);
   int gb = gram_blocks(m_local > n ? m_local : n);
-  if (gb < 512) gb = 512;                      // the fused epilogues write up to 512 per-workgroup partials
+  if (gb < 1024) gb = 1024;                    // the fused epilogues write up to GRAM_MAX_PARTS per-workgroup partials
   if ((rc = dev_alloc(c, (float**)&c->gram_partial, (size_t)gb * k * k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->Gv, (size_t)k * k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->active_dev, (size_t)k))) return bail(rc);
@@ -1151,6 +1151,8 @@ extern "C" int prmf_debug_slab_sum(prmf_ctx* c, int which, float* out_dev, void*
 
 /* debug (not in the public header): device buffer of 2*grid uint64 start/end stamps of the next sweep launches */
 extern "C" int prmf_debug_set_stamps(void* dev_buf) { prmf::g_sweep_stamps = (unsigned long long*)dev_buf; return 0; }
+/* debug: 8 uint64 phase stamps per workgroup of the next column-split epilogue launches (tools/epi_phases.py) */
+extern "C" int prmf_debug_set_epi_stamps(void* dev_buf) { prmf::g_epi_stamps = (unsigned long long*)dev_buf; return 0; }
 
 int prmf_quantile_transform(int device, double* dX, int64_t m, int64_t n, int64_t ld, const int64_t* fit_rows,
                             int64_t n_fit, int n_quantiles, void* stream) {

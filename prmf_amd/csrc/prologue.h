@@ -36,12 +36,12 @@ __device__ __forceinline__ double block_sum_256(double v, double* red /* [256] s
 // ---------------------------------------------------------------------------
 // G[e] = sum over the per-workgroup float partials, in float64.
 // Job j (256 threads) finishes entries [8 j, 8 j + 8): thread (sub = tid >> 3, el = tid & 7) loads
-// partials sub, sub + 32, ... of entry 8 j + el -- all of them in flight at once (nparts <= 512:
-// at most 16 independent loads, one memory round trip) -- and sums them in index order; the 32
+// partials sub, sub + 32, ... of entry 8 j + el -- all of them in flight at once (nparts <= 1024:
+// at most 32 independent loads, one memory round trip) -- and sums them in index order; the 32
 // sub-sums are then added in index order.  The order depends on (nparts, entry) only.
 // ---------------------------------------------------------------------------
 constexpr int GRAM_JOB_ENTRIES = 8;
-constexpr int GRAM_MAX_PARTS = 512;
+constexpr int GRAM_MAX_PARTS = 1024;
 __host__ __device__ inline int gram_reduce_jobs(int kk2) { return (kk2 + GRAM_JOB_ENTRIES - 1) / GRAM_JOB_ENTRIES; }
 
 __device__ __forceinline__ void gram_reduce_job(const float* __restrict__ partial, int nparts, int kk2,

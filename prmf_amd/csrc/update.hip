@@ -304,12 +304,28 @@ __device__ __forceinline__ void tile_times_gram(const float (&ua)[16 * NT], int 
       den[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[s2], Gs[(s2 + HALF * h) * KP + 32 * t + r], den[t], 0, 0, 0);
 }
 
+// G (k x k float64, row-major) -> Gs [KP][KP] floats in LDS, zero outside k.  The loads are issued in batches of 16
+// per thread BEFORE the LDS stores of the batch: written as `Gs[i] = (float)G[...]` in one loop the compiler kept every
+// load behind the previous store, and the staging was a chain of KP*KP/256 dependent L2 round trips -- 24 us of a
+// 53 us epilogue workgroup at k = 128 (tools/epi_phases.py), ~5 us at k = 64.
 template <int NT>
 __device__ __forceinline__ void stage_gram(const double* __restrict__ G, int k, int col0, int ncols, float* Gs) {
-  constexpr int KP = 32 * NT;
-  for (int i = threadIdx.x; i < KP * KP; i += blockDim.x) {
-    const int q = i / KP, c = i - q * KP;
-    Gs[i] = (q < k && c < ncols) ? (float)G[q * k + col0 + c] : 0.f;
+  constexpr int KP = 32 * NT, PER = KP * KP / 256;           // 4, 16, 36, 64 values per thread
+  constexpr int B = PER % 16 == 0 ? 16 : (PER % 12 == 0 ? 12 : PER);
+  static_assert(PER % B == 0 && B <= 16, "whole batches");
+#pragma unroll 1
+  for (int b0 = 0; b0 < PER; b0 += B) {
+    double v[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      const int i = (int)threadIdx.x + 256 * (b0 + j);
+      const int q = i / KP, c = i - q * KP;
+      const bool in = q < k && c < ncols;
+      v[j] = G[in ? q * k + col0 + c : 0];
+      if (!in) v[j] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < B; ++j) Gs[(int)threadIdx.x + 256 * (b0 + j)] = (float)v[j];
   }
 }
 
@@ -587,7 +603,12 @@ int epilogue_blocks(int64_t rows, int wpt) {
   const int64_t tiles = (rows + 31) / 32;
   const int tpw = 4 / (wpt < 1 ? 1 : wpt);
   int64_t blocks = (tiles + tpw - 1) / tpw;
-  if (blocks > 512) blocks = 512;
+  // at most 512 workgroups (the resident slots at two per CU; one Gram partial each), and every workgroup the same
+  // number of rounds: 782 tiles become 391 workgroups x 2 rounds, not 512 of which 270 run twice
+  if (blocks > 512) {
+    const int64_t rounds = (blocks + 511) / 512;
+    blocks = (blocks + rounds - 1) / rounds;
+  }
   return (int)(blocks < 1 ? 1 : blocks);
 }
 
@@ -623,6 +644,7 @@ struct EpiArgs {
   int max_support;
   double* partial;              // [blocks * 4][k + 1]
   float* vsup;
+  unsigned long long* stamps;   // debug (tools/epi_phases.py): 8 wall-clock stamps per workgroup, first round of wave 0
 };
 
 template <int NT, bool IS_V, bool BF16, bool DENSE>
@@ -634,6 +656,8 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
   __shared__ float Gs[KP * KP];
   __shared__ float exch[4][16][64];                         // the updated tile, one column tile per wave (C/D layout)
   const int k = a.k;
+#define EPI_STAMP(j) do { if (a.stamps && threadIdx.x == 0 && first_round) a.stamps[8 * blockIdx.x + (j)] = wall_clock64(); } while (0)
+  bool first_round = true;
   if ((int)blockIdx.x >= a.nblocks_main) {                  // extra workgroups: pathway terms of one latent column each
     const int c = (int)blockIdx.x - a.nblocks_main;
     if ((size_t)gj.lib.max_support * sizeof(float) <= sizeof(Gs))
@@ -642,8 +666,10 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
       graph_terms_body<false>(gj.lib, gj.active, gj.col0, c, gj.V, k, gj.hyper, gj.gnum, gj.gden, Gs);
     return;
   }
+  EPI_STAMP(0);
   stage_gram<NT>(a.G, k, 0, k, Gs);
   __syncthreads();
+  EPI_STAMP(1);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int c = lane & 31, h = lane >> 5, r = lane & 31;
   const int tslot = NT == 3 ? 0 : wave / NT, t = NT == 3 ? wave : wave % NT;
@@ -712,6 +738,7 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
             }
         }
       }
+      if (a.stamps) { float t_ = 0.f; for (int i = 0; i < 16; ++i) t_ += q[i]; if (t_ == 1.2345e-33f) vn[0] = t_; EPI_STAMP(2); }
       // (2) den = F_tile (all k columns, A layout) x G[:, this column tile] on the f32 MFMA; the old values of this
       //     column tile (C/D layout) and, V side, the position map and the gathered pathway terms
       float ua[HALF];
@@ -735,9 +762,11 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
         }
       }
     }
+    if (a.stamps) { float t_ = 0.f; for (int i = 0; i < 16; ++i) t_ += den[i]; if (t_ == 1.2345e-33f) vn[1] = t_; EPI_STAMP(3); }
     // The tile's waves update F in place, and every one of them has just read ALL columns of the old tile (A layout):
     // nobody stores before everybody's loads have been consumed by the MFMA chain above.
     __syncthreads();
+    EPI_STAMP(4);
     if (live) {
       // (3) the element-wise update of this column tile
       if constexpr (IS_V) {
@@ -770,6 +799,7 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
         }
       }
     }
+    if (a.stamps) { float t_ = 0.f; for (int i = 0; i < 16; ++i) t_ += vn[i]; if (t_ == 1.2345e-33f) vn[2] = t_; EPI_STAMP(5); }
     // (4) this column tile's fragments of the packed factor (tiles past the end are packed as zeros)
     if (in_range) {
       if constexpr (BF16) {
@@ -804,6 +834,7 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) exch[wave][i][lane] = vn[i];
     __syncthreads();
+    EPI_STAMP(6);
     if (wave_on) {
       const int w0 = NT == 3 ? 0 : tslot * NT;
       int p = 0;
@@ -818,7 +849,10 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
           }
     }
     __syncthreads();
+    EPI_STAMP(7);
+    first_round = false;
   }
+#undef EPI_STAMP
   if constexpr (IS_V) {
     // per-wave partials [k + 1]: this wave's 32 columns, zeros elsewhere, <Q, V_new> last (fixed order)
     double* out = a.partial + ((int64_t)blockIdx.x * 4 + wave) * (k + 1);
@@ -864,8 +898,12 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
     }
 }
 
+unsigned long long* g_epi_stamps = nullptr;   // debug: per-workgroup phase stamps of the next column-split epilogue launches
+
 template <bool IS_V>
-static hipError_t launch_epilogue_cs(const EpiArgs& a, const GraphJob& gj, int NT, bool bf16, bool dense, int grid, hipStream_t s) {
+static hipError_t launch_epilogue_cs(const EpiArgs& a_in, const GraphJob& gj, int NT, bool bf16, bool dense, int grid, hipStream_t s) {
+  EpiArgs a = a_in;
+  a.stamps = g_epi_stamps;
 #define PRMF_CS(NTV)                                                                                     \
   if (bf16) {                                                                                            \
     if (dense) epilogue_cs_kernel<NTV, IS_V, true, IS_V><<<grid, 256, 0, s>>>(a, gj);                       \
