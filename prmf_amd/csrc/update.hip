@@ -951,8 +951,10 @@ hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, con
   switch (NT) {
     case 1: PRMF_UEP(1, true); break;
     case 2: PRMF_UEP(2, true); break;
+#if PRMF_EPI_CS_MIN_NT > 3      // k > 64 takes the column-split kernel above
     case 3: PRMF_UEP(3, false); break;
     case 4: PRMF_UEP(4, false); break;
+#endif
     default: return hipErrorInvalidValue;
   }
 #undef PRMF_UEP
@@ -1131,8 +1133,10 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
   switch (NT) {
     case 1: PRMF_VEP(1, true); break;
     case 2: PRMF_VEP(2, true); break;
+#if PRMF_EPI_CS_MIN_NT > 3      // k > 64 takes the column-split kernel above
     case 3: PRMF_VEP(3, false); break;
     case 4: PRMF_VEP(4, false); break;
+#endif
     default: return hipErrorInvalidValue;
   }
 #undef PRMF_VEP
