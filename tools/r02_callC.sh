@@ -1,5 +1,5 @@
 # round-2 GPU batch: tests, then (only if the GPU is still healthy) benches and kernel traces
-OUT=gpurun_out/r02o; mkdir -p $OUT; export TMPDIR=/tmp
+OUT=gpurun_out/r02y; mkdir -p $OUT; export TMPDIR=/tmp
 timeout -k 10 900 python -u -m pytest tests -m gpu -q -rA -p no:cacheprovider > $OUT/pytest.log 2>&1; rc=$?; echo pytest_rc=$rc; if [ $rc -ge 124 ]; then tail -3 $OUT/pytest.log | cut -c1-300; echo "pytest crashed or timed out: no further GPU step"; exit 1; fi
 tail -4 $OUT/pytest.log
 python -c "import torch; print(torch.zeros(4, device='cuda').sum().item())" || exit 1
