@@ -53,8 +53,8 @@ struct prmf_ctx {
   void* Vp = nullptr;
   void* Up = nullptr;
   GemmPlan plan_xv{}, plan_xtu{};
-  uint32_t* nseg_xv = nullptr;        // device copies of the plans' per-panel slab masks
-  uint32_t* nseg_xtu = nullptr;
+  segmask_t* nseg_xv = nullptr;        // device copies of the plans' per-panel slab masks
+  segmask_t* nseg_xtu = nullptr;
   float* slabs = nullptr;             // shared by both sweeps
   int64_t slab_stride_p = 0, slab_stride_q = 0;
 
@@ -369,8 +369,8 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if (c->slab_stride_q * c->plan_xtu.max_seg > slab_floats) slab_floats = c->slab_stride_q * c->plan_xtu.max_seg;
   if ((rc = dev_alloc(c, &c->nseg_xv, c->plan_xv.segmask.size(), false))) return bail(rc);
   if ((rc = dev_alloc(c, &c->nseg_xtu, c->plan_xtu.segmask.size(), false))) return bail(rc);
-  if (hipMemcpy(c->nseg_xv, c->plan_xv.segmask.data(), c->plan_xv.segmask.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(c->nseg_xtu, c->plan_xtu.segmask.data(), c->plan_xtu.segmask.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+  if (hipMemcpy(c->nseg_xv, c->plan_xv.segmask.data(), c->plan_xv.segmask.size() * sizeof(segmask_t), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->nseg_xtu, c->plan_xtu.segmask.data(), c->plan_xtu.segmask.size() * sizeof(segmask_t), hipMemcpyHostToDevice) != hipSuccess) {
     fail(c, PRMF_ERR_HIP, "hipMemcpy(plan) failed");
     return bail(PRMF_ERR_HIP);
   }

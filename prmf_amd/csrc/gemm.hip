@@ -505,7 +505,7 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
   }
   if (G < 1) G = 1;
   // which slabs does every panel receive?  simulate the kernel's decomposition for one launch
-  auto simulate = [&](int ngroups_sub, int nx, int64_t Gl, int seg_base, int* pmax_out, std::vector<uint32_t>* mask) -> bool {
+  auto simulate = [&](int ngroups_sub, int nx, int64_t Gl, int seg_base, int* pmax_out, std::vector<segmask_t>* mask) -> bool {
     const int64_t Gx = Gl / nx;
     std::vector<int> parts((size_t)p.panels * nx, 0);
     int pmax = 1;
@@ -523,21 +523,21 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
       }
     }
     *pmax_out = pmax;
-    if (seg_base + nx * pmax > 32) return false;
+    if (seg_base + nx * pmax > MAX_SLABS) return false;
     if (mask)
       for (int q = 0; q < p.panels; ++q)
         for (int x = 0; x < nx; ++x)
-          for (int j = 0; j < parts[(size_t)q * nx + x]; ++j) (*mask)[q] |= 1u << (seg_base + x * pmax + j);
+          for (int j = 0; j < parts[(size_t)q * nx + x]; ++j) (*mask)[q] |= segmask_t(1) << (seg_base + x * pmax + j);
     return true;
   };
   for (;;) {
     p.grid = (int)G;
-    p.segmask.assign(p.panels, 0u);
+    p.segmask.assign(p.panels, segmask_t(0));
     if (simulate(p.ngroups, p.nx, G, 0, &p.pmax, &p.segmask)) {
       p.max_seg = p.nx * p.pmax;
       break;
     }
-    // too many segments per panel for the 32-bit mask: drop the slices, then workgroups
+    // too many segments per panel for the 64-bit mask: drop the slices, then workgroups
     if (p.nx > 1) p.nx = 1;
     else G = G > 16 ? G / 2 : 1;
   }

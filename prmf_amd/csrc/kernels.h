@@ -81,6 +81,10 @@ struct SweepPrologue {
 // gemm.hip
 // ---------------------------------------------------------------------------
 hipError_t launch_pack_factor(const FactorView& f, int x_dtype, int NT, int64_t Kpad, void* packed, hipStream_t s);
+// which slabs hold a segment of a row panel: one bit per slab, at most 64 slabs per panel (wide, short matrices -- the
+// reference's typical samples << genes shape -- have 2-3 panels and would otherwise run the X V sweep on 32 workgroups per panel)
+typedef uint64_t segmask_t;
+constexpr int MAX_SLABS = 64;
 struct GemmPlan {
   int nw = 8;               // waves per workgroup
   int mt = 1;               // 32-row tiles per wave
@@ -93,7 +97,7 @@ struct GemmPlan {
   int nx = 1;               // slices of the reduction range (8 = one per XCD)
   int pmax = 1;             // most workgroups that touch one (panel, slice)
   int max_seg = 1;          // slabs allocated: nx * pmax
-  std::vector<uint32_t> segmask;   // [panels] bit s set <=> slab s holds a segment of this panel
+  std::vector<segmask_t> segmask;  // [panels] bit s set <=> slab s holds a segment of this panel
 };
 // Test hooks, read from the environment ONCE per prmf_create (capi.hip) -- the planner itself takes no knobs.
 struct SweepTuning {
@@ -130,19 +134,19 @@ hipError_t launch_transpose_pad(int x_dtype, const void* src, int64_t ld_src, in
 // ---------------------------------------------------------------------------
 
 // U <- U * (P / (U Gv + U)), P = sum of `splits` slabs     (prmf_runner.py:420-422)
-hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
+hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const segmask_t* segmask, int panel_rows,
                            int64_t slab_stride, int KP, const double* Gv, hipStream_t s);
 // fused U epilogue (k % 4 == 0): slab sum + U (V^T V) on the f32 MFMA + update + fragment packing
 // (*gram_done: the kernel also wrote epilogue_blocks(Kpad) per-workgroup partials of F_new^T F_new)
 int epilogue_wpt(int64_t rows, int max_seg, int NT);   // waves sharing a tile's slab sum (1, 2, 4)
 int epilogue_blocks(int64_t rows, int wpt = 1);
-hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
+hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const segmask_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
                              float* gram_partial, bool* gram_done, int wpt, hipStream_t s, const GraphJob* graph = nullptr);
 hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G, hipStream_t s);
 // fused single-rank V epilogue (k % 4 == 0): in place, + packing + per-wave partials [waves][k+1]
 int v_epilogue_waves(int64_t n, int wpt = 1);
-hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
+hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const segmask_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gu, const int32_t* pos, const float* gnum,
                              const float* gden, int max_support, int x_dtype, void* packed, int64_t Kpad,
                              double* partial, float* gram_partial, bool* gram_done,
@@ -163,7 +167,7 @@ hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStrea
 // only the gram_blocks(f.rows) per-workgroup partials [k*k] floats (the reduction happens in a sweep's prologue)
 hipError_t launch_gram_partials(const FactorView& f, float* partial, hipStream_t s);
 // Q slabs -> q_send[nranks][n][kc]
-hipError_t launch_slab_sum_blocks(const float* slabs, const uint32_t* segmask, int panel_rows, int64_t slab_stride, int KP,
+hipError_t launch_slab_sum_blocks(const float* slabs, const segmask_t* segmask, int panel_rows, int64_t slab_stride, int KP,
                                   int64_t n, int k, int kc, int nranks, float* q_send,
                                   int max_seg /* most slabs a panel receives (plan.max_seg): sizes the cooperative sum */, hipStream_t s);
 hipError_t launch_set_hyper(double* hyper, double gamma, double delta, double tradeoff, hipStream_t s);

@@ -36,7 +36,7 @@ __device__ __forceinline__ int64_t slab_index(int64_t row, int col, int NT) {
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 u_update_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs,
-                const uint32_t* __restrict__ segmask, int panel_rows, int64_t slab_stride, int KP,
+                const segmask_t* __restrict__ segmask, int panel_rows, int64_t slab_stride, int KP,
                 const double* __restrict__ Gv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int k4 = (k + 3) & ~3;
@@ -77,8 +77,8 @@ u_update_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict
         if (col < k) {
           float p = 0.f;
           const int64_t si = slab_index(row, col, KP >> 5);
-          for (uint32_t mk = segmask[row / panel_rows]; mk; mk &= mk - 1)
-            p += slabs[(int64_t)(__ffs(mk) - 1) * slab_stride + si];
+          for (segmask_t mk = segmask[row / panel_rows]; mk; mk &= mk - 1)
+            p += slabs[(int64_t)(__ffsll((long long)mk) - 1) * slab_stride + si];
           const float uu = urow[col];
           const float d = den[j] + uu;
           const float ratio = (d != 0.f) ? p / d : 1.f;
@@ -89,7 +89,7 @@ u_update_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict
   }
 }
 
-hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
+hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const segmask_t* segmask, int panel_rows,
                            int64_t slab_stride, int KP, const double* Gv, hipStream_t s) {
   const int k4 = (k + 3) & ~3;
   const int RT = 256 / (k4 >> 2);
@@ -334,7 +334,7 @@ __device__ __forceinline__ void stage_gram(const double* __restrict__ G, int k, 
 // loop costs a full memory round trip per segment: up to 8 per tile); missing slots of the last
 // batch re-read the first slab and are masked out of the sum.
 template <int NT, int NB = 2>
-__device__ __forceinline__ void load_slab_tile(const float* __restrict__ slabs, int64_t slab_stride, uint32_t mask, int64_t tile,
+__device__ __forceinline__ void load_slab_tile(const float* __restrict__ slabs, int64_t slab_stride, segmask_t mask, int64_t tile,
                                                int lane, float (&p)[NT][16]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -344,10 +344,10 @@ __device__ __forceinline__ void load_slab_tile(const float* __restrict__ slabs, 
   while (mask) {
     int sg[NB];
     float on[NB];
-    const int first = __ffs(mask) - 1;
+    const int first = __ffsll((long long)mask) - 1;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      sg[j] = mask ? __ffs(mask) - 1 : first;
+      sg[j] = mask ? __ffsll((long long)mask) - 1 : first;
       on[j] = mask ? 1.f : 0.f;
       mask &= mask - 1;
     }
@@ -378,12 +378,12 @@ __device__ __forceinline__ void load_slab_tile(const float* __restrict__ slabs, 
 // 26 segments each) one wave per tile walks a chain of dependent load batches on a handful of CUs.  `wpt` = 2 or 4
 // waves then share a tile: wave `sub` sums the segments whose ordinal (in slab-index order) is congruent to sub,
 // the sub-sums meet in LDS and the tile's leader wave (sub 0) adds them in sub order -- a fixed order again.
-__device__ __forceinline__ uint32_t my_segments(uint32_t mask, int wpt, int sub) {
+__device__ __forceinline__ segmask_t my_segments(segmask_t mask, int wpt, int sub) {
   if (wpt == 1) return mask;
-  uint32_t mine = 0;
+  segmask_t mine = 0;
   int ord = 0;
-  for (uint32_t mk = mask; mk; mk &= mk - 1, ++ord)
-    if (ord % wpt == sub) mine |= mk & (0u - mk);
+  for (segmask_t mk = mask; mk; mk &= mk - 1, ++ord)
+    if (ord % wpt == sub) mine |= mk & (segmask_t(0) - mk);
   return mine;
 }
 
@@ -495,7 +495,7 @@ __device__ __forceinline__ void gram_total_store(const float (&gtot)[NT * (NT + 
 // GRAM: also accumulate F_new^T F_new (per-workgroup partial [k*k] floats at gram_partial[blockIdx])
 template <int NT, bool BF16, bool GRAM>
 __global__ void __launch_bounds__(256, NT <= 2 ? 2 : 1)
-u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs, const uint32_t* __restrict__ segmask,
+u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs, const segmask_t* __restrict__ segmask,
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gv, void* __restrict__ packed,
                   int64_t ntiles_pack, float* __restrict__ gram_partial, int wpt /* waves per tile: 1, 2 or 4 */,
                   int nblocks_main, const GraphJob gj) {
@@ -533,7 +533,7 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
     if constexpr (NT <= 2) {
       if (wpt > 1) {
         if (live) load_slab_tile<NT, NT == 1 ? 4 : PRMF_EPI_NB2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, p);
-        else load_slab_tile<NT>(slabs, slab_stride, 0u, tile, lane, p);
+        else load_slab_tile<NT>(slabs, slab_stride, segmask_t(0), tile, lane, p);
         combine_tile_sums<NT>(p, wpt, sub, wave, lane, red_store);
       }
     }
@@ -629,7 +629,7 @@ struct EpiArgs {
   int64_t rows;
   int k;
   const float* slabs;           // sweep slabs, or (DENSE) Q [n][k]
-  const uint32_t* segmask;
+  const segmask_t* segmask;
   int panel_rows;
   int64_t slab_stride;
   const double* G;              // V^T V (U side) or U^T U (V side)
@@ -709,14 +709,14 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
         for (int i = 0; i < 16; ++i) q[i] = Qt[cd_off(i)];
       } else {
         const int64_t fbase = (tile * NT + t) * 256 + lane;         // float4 index of (tile, t, q4 = 0, lane)
-        uint32_t mask = a.segmask[row0 / a.panel_rows];
+        segmask_t mask = a.segmask[row0 / a.panel_rows];
         while (mask) {
           int sg[4];
           float on[4];
-          const int first = __ffs(mask) - 1;
+          const int first = __ffsll((long long)mask) - 1;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            sg[j] = mask ? __ffs(mask) - 1 : first;
+            sg[j] = mask ? __ffsll((long long)mask) - 1 : first;
             on[j] = mask ? 1.f : 0.f;
             mask &= mask - 1;
           }
@@ -927,7 +927,7 @@ static hipError_t launch_epilogue_cs(const EpiArgs& a_in, const GraphJob& gj, in
   return hipGetLastError();
 }
 
-hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
+hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const segmask_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
                              float* gram_partial, bool* gram_done, int wpt, hipStream_t s, const GraphJob* graph) {
   const int NT = KP / 32;
@@ -966,7 +966,7 @@ hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, con
 // squares and <Q, V_new> (float64) + (GRAM) V_new^T V_new partials.
 template <int NT, bool BF16, bool GRAM, bool DENSE>
 __global__ void __launch_bounds__(256, NT <= 2 ? 2 : 1)
-v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ slabs /* DENSE: Q [n][k] */, const uint32_t* __restrict__ segmask,
+v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ slabs /* DENSE: Q [n][k] */, const segmask_t* __restrict__ segmask,
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gu, const int32_t* __restrict__ pos,
                   const float* __restrict__ gnum, const float* __restrict__ gden, int max_support,
                   void* __restrict__ packed, int64_t ntiles_pack, double* __restrict__ partial /*[waves][k+1]*/,
@@ -1002,7 +1002,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
     if constexpr (NT <= 2 && !DENSE) {
       if (wpt > 1) {
         if (live) load_slab_tile<NT, NT == 1 ? 4 : PRMF_EPI_NB2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, q);
-        else load_slab_tile<NT>(slabs, slab_stride, 0u, tile, lane, q);
+        else load_slab_tile<NT>(slabs, slab_stride, segmask_t(0), tile, lane, q);
         combine_tile_sums<NT>(q, wpt, sub, wave, lane, red_store);
       }
     }
@@ -1102,7 +1102,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
 
 int v_epilogue_waves(int64_t n, int wpt) { return epilogue_blocks(round_up(n, K_PAD), wpt) * 4; }
 
-hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const uint32_t* segmask, int panel_rows,
+hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, const segmask_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gu, const int32_t* pos, const float* gnum,
                              const float* gden, int max_support, int x_dtype, void* packed, int64_t Kpad,
                              double* partial, float* gram_partial, bool* gram_done, const float* qdense, float* vsup, int wpt,
@@ -1223,7 +1223,7 @@ hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G
 // ---------------------------------------------------------------------------
 template <int NT>
 __global__ void __launch_bounds__(256)
-slab_sum_blocks_kernel(const float* __restrict__ slabs, const uint32_t* __restrict__ segmask, int panel_rows,
+slab_sum_blocks_kernel(const float* __restrict__ slabs, const segmask_t* __restrict__ segmask, int panel_rows,
                        int64_t slab_stride, int64_t n, int k, int kc, float* __restrict__ q_send, int wpt) {
   // `wpt` waves per 32-row tile (cooperative slab sum, see my_segments): fragment-order 16-B loads, summed over the
   // tile's segments, written by owner block
@@ -1239,7 +1239,7 @@ slab_sum_blocks_kernel(const float* __restrict__ slabs, const uint32_t* __restri
     const bool live = tile < ntiles;
     float q[NT][16];
     if (live) load_slab_tile<NT, NT == 1 ? 4 : PRMF_EPI_NB2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, q);
-    else load_slab_tile<NT>(slabs, slab_stride, 0u, tile, lane, q);
+    else load_slab_tile<NT>(slabs, slab_stride, segmask_t(0), tile, lane, q);
     if constexpr (NT <= 2) combine_tile_sums<NT>(q, wpt, sub, wave, lane, comb);
     if (!live || sub != 0) continue;
 #pragma unroll
@@ -1257,7 +1257,7 @@ slab_sum_blocks_kernel(const float* __restrict__ slabs, const uint32_t* __restri
   }
 }
 
-hipError_t launch_slab_sum_blocks(const float* slabs, const uint32_t* segmask, int panel_rows, int64_t slab_stride, int KP,
+hipError_t launch_slab_sum_blocks(const float* slabs, const segmask_t* segmask, int panel_rows, int64_t slab_stride, int KP,
                                   int64_t n, int k, int kc, int nranks, float* q_send, int max_seg, hipStream_t s) {
   (void)nranks;
   const int NT = KP / 32;
