@@ -78,3 +78,42 @@ def test_deferred_objective_equals_per_iteration_form():
             eng.close()
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (m, n, k)
         assert outs[0][2] == outs[1][2], (m, n, k)
+
+
+def test_long_call_is_batched_like_short_calls():
+    """prmf_step keeps at most 256 iterations of deferred-objective state on the device: a 300-iteration call runs as two
+    batches inside the library and must equal three 100-iteration calls bit for bit (factors and all 300 records)."""
+    import torch
+    from prmf_amd import PathwayLibrary
+    from prmf_amd.solver import PrmfEngine
+    case = synth.small_case(seed=8, m=300, n=700, k=8, P=4, order=50)
+    outs = []
+    for calls in ((300,), (100, 100, 100)):
+        eng = PrmfEngine(300, 700, 8)
+        eng.set_x(case["X"])
+        eng.set_library(PathwayLibrary.from_edge_lists(700, case["pathways"]))
+        eng.set_active(np.arange(8) % 4)
+        U = eng.device_tensor(case["U0"], torch.float32)
+        V = eng.device_tensor(case["V0"], torch.float32)
+        objs = []
+        for nst in calls:
+            o, _ = eng.step(U, V, nst, case["gamma"], case["delta"])
+            objs += o
+        outs.append((U.cpu().numpy(), V.cpu().numpy(), objs))
+        eng.close()
+    assert len(outs[0][2]) == 300 and outs[0][2] == outs[1][2]
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    with pytest.raises(Exception):      # the active pathways belong to a whole batch: changing them mid-batch is an error
+        eng2 = PrmfEngine(300, 700, 8)
+        eng2.set_x(case["X"])
+        eng2.set_library(PathwayLibrary.from_edge_lists(700, case["pathways"]))
+        eng2.set_active(np.arange(8) % 4)
+        U = eng2.device_tensor(case["U0"], torch.float32)
+        V = eng2.device_tensor(case["V0"], torch.float32)
+        eng2.begin(U, V, case["gamma"], case["delta"])
+        eng2.phase_u(); eng2.phase_q(); eng2.phase_v(); eng2.phase_post()
+        try:
+            eng2.set_active((np.arange(8) + 1) % 4)
+        finally:
+            eng2.end(1)
+            eng2.close()
