@@ -18,8 +18,11 @@ for i in range(2):
     eng.phase_u(); eng.phase_q(); eng.phase_v(); eng.phase_post()
 torch.cuda.synchronize()
 st = torch.zeros(8 * 2048, dtype=torch.int64, device=dev)
-names = ["G staged", "slab sum", "MFMA chain", "barrier", "update+stores", "pack+exchange", "Gram"]
-for side, pre, ph in (("U", None, eng.phase_u), ("V", eng.phase_q, eng.phase_v)):
+cs = k > 64
+names = (["G staged", "slab sum", "MFMA chain", "barrier", "update+stores", "pack+exchange", "Gram"] if cs else
+         ["G staged", "slab + U loads", "MFMA chain", "update+stores", "pack", "Gram round", "-"])
+sides = (("U", None, eng.phase_u), ("V", eng.phase_q, eng.phase_v)) if cs else (("U", None, eng.phase_u),)   # k <= 64: U kernel only
+for side, pre, ph in sides:
     if pre:
         pre()
     torch.cuda.synchronize()
