@@ -465,7 +465,9 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 // byte of X, 3% slower at k = 64 and 5% at k = 128; 32-row wave tiles with 3 workgroups per CU -- 11% slower at k = 128;
 // 4 waves x 128 rows, one workgroup per CU -- 10% slower at k = 64; the factor chunk staged by LDS-DMA
 // (global_load_lds_dwordx4) instead of through registers -- 8% slower at k = 64, 14% at k = 16:
-// profiles/r02_ab_factor_lds_dma.txt; one or three workgroups per CU -- 35% / 12% slower at 5000 x 10000):
+// profiles/r02_ab_factor_lds_dma.txt; one or three workgroups per CU -- 35% / 12% slower at 5000 x 10000; two 4-wave
+// K-groups per workgroup that add their accumulators through LDS (half the slabs) -- 5% / 15% slower on the two C3
+// sweeps; an 8-wave workgroup on a 512-row panel -- equal at C3, 14% slower at C2: profiles/r02_ab_kgroups_and_8wave.txt):
 //   4 waves x 64 rows (MT = 2), two workgroups per CU;
 //   k <= 64: factor chunk double-buffered in LDS (32 KiB of A tiles + 2 x 8 NT KiB), one barrier per chunk;
 //   k  > 64: factor chunk single-buffered (k = 128: 32 + 32 KiB, 116 VGPRs + 128 accumulator registers), two barriers.
