@@ -30,6 +30,12 @@
 #include "prologue.h"
 
 
+#ifndef PRMF_SWEEP_PRIO
+#define PRMF_SWEEP_PRIO 1   // see the chunk loop
+#endif
+#ifndef PRMF_PHASE_PROF
+#define PRMF_PHASE_PROF 0
+#endif
 #ifndef PRMF_SWEEP_MINW
 #define PRMF_SWEEP_MINW 2     // 1 (the compiler then takes 268 registers at k = 128: one workgroup per CU) is 12% slower there
 #endif
@@ -161,8 +167,8 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&ac
   const int r = lane & 31, h = lane >> 5;
   const int swz = (r >> 1) & 7;
   if constexpr (MODE == 2) {
-    // not unrolled over the two k-blocks: the three-piece split is register-hungry and the kernel must stay within
-    // 128 VGPRs next to its 2 x 64 accumulator registers (two waves per SIMD)
+    // not unrolled over the two k-blocks: the three-piece split is register-hungry (222 registers at k = 64 next to the
+    // 2 x 64 accumulator registers; two waves per SIMD allow 256); unrolled it is no faster at k = 16 or k = 64
 #pragma unroll 1
     for (int kb = 0; kb < 2; ++kb) {
       u32x4 bh[NT], bl[NT];
@@ -191,6 +197,38 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&ac
           mm(acc[mt][t], ah, bh[t]);
         }
       }
+    }
+    return;
+  }
+  if constexpr (BF16 && NT > 2) {
+    // k > 64: the fragment reads of step j + 1 (a B hi/lo pair; the A fragments when a new 16-element slice starts) are
+    // issued before the MFMAs of step j (the scheduling barriers keep the compiler from sinking them back): 2% at
+    // k = 128; at k = 64 it changes nothing (profiles/r02_ab_priority_and_pipelined_reads.txt)
+    u32x4 av[2][MT], bb[2][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) av[0][mt] = sa[mt * 256 + r * 8 + ((0 + h) ^ swz)];
+    bb[0][0] = sb[0 * 64 + lane];
+    bb[0][1] = sb[1 * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 4 * NT; ++j) {
+      const int s4 = j / NT, t = j % NT, jn = j + 1;
+      if (jn < 4 * NT) {
+        if (jn % NT == 0) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) av[(jn / NT) & 1][mt] = sa[mt * 256 + r * 8 + ((2 * (jn / NT) + h) ^ swz)];
+        }
+        bb[jn & 1][0] = sb[(jn * 2 + 0) * 64 + lane];
+        bb[jn & 1][1] = sb[(jn * 2 + 1) * 64 + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(bf16x8, av[s4 & 1][mt]), __builtin_bit_cast(bf16x8, bb[j & 1][0]), acc[mt][t], 0, 0, 0);
+        acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(bf16x8, av[s4 & 1][mt]), __builtin_bit_cast(bf16x8, bb[j & 1][1]), acc[mt][t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     return;
   }
@@ -320,6 +358,12 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if PRMF_PHASE_PROF
+  unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_sum[6] = {0, 0, 0, 0, 0, 0};
+#define PH_MARK(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_sum[i] += t_ - ph_t; ph_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PH_MARK(i) do {} while (0)
+#endif
 
   // Balanced, XCD-aware persistent decomposition.  The launch has one workgroup per
   // resident slot.  The reduction range (ngroups units of UNIT chunks) is cut into `nx` slices
@@ -397,13 +441,17 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   // The chunk loop is unrolled x2 so that the LDS buffer offsets are compile-time constants; it handles any number of
   // chunks per segment (odd only with UNIT = 1), and the last chunk of a segment loads nothing (it used to re-load
   // itself: one wasted chunk per segment).  `have` / `next` are workgroup-uniform.
+  // f32 X on the bf16 MFMA (MODE 2): loads first only at k <= 32 (-6% on the 5000 x 10000, k = 16 sweeps); at k = 64 the
+  // chunk in flight costs 22 more registers (244, no spills) and the sweeps are 0.5% slower (profiles/r02_ab_f32_loads_first.txt)
+  constexpr bool LF_MODE_OK = MODE != 2 || NT == 1;
   for (int c = 0; c < nch; c += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const bool have = c + u < nch, next = c + u + 1 < nch;
       if (have) {
         const int cn = c + u + 1;
-        if constexpr (LOADS_FIRST && MODE != 2) {
+        PH_MARK(0);
+        if constexpr (LOADS_FIRST && LF_MODE_OK) {
           // the next chunk's loads are in flight while this chunk is computed from LDS
           if (next) {
             load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
@@ -411,8 +459,20 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+        PH_MARK(1);
+        // The compute segment runs at raised wave priority: the wave that shares this SIMD (it belongs to the CU's other
+        // workgroup) is then the one that yields issue slots while it queues loads or LDS writes.  Same-session A/B:
+        // 1-2.5% on both sweeps at 50000 x 20000, 4.5% at k = 128, neutral at 5000 x 10000; the inverse (loaders high)
+        // and a priority kept through the LDS writes are 1-4% slower (profiles/r02_ab_priority_and_pipelined_reads.txt).
+#if PRMF_SWEEP_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
         sweep_compute<MODE, MT, NT>(acc, acc_lo, myA, sB[BDB ? u : 0], lane);
-        if constexpr (!(LOADS_FIRST && MODE != 2)) {
+#if PRMF_SWEEP_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        PH_MARK(2);
+        if constexpr (!(LOADS_FIRST && LF_MODE_OK)) {
           if (next) {
             load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
             load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
@@ -421,6 +481,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
           __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (!BDB) __syncthreads();          // everyone has finished reading B(c)
+        PH_MARK(3);
         if (next) {
           store_b_chunk<BPT, NTHR, BCH>(sB[BDB ? (u ^ 1) : 0], bs, tid);
 #pragma unroll
@@ -428,7 +489,9 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 #pragma unroll
             for (int i = 0; i < 4; ++i) myA[mt * 256 + i * 64 + lane] = a[mt][i];
         }
+        PH_MARK(4);
         __syncthreads();      // also orders this chunk's LDS reads before the next segment's prologue writes
+        PH_MARK(5);
       }
     }
   }
@@ -458,6 +521,10 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
       }
   }
   }   // segments
+#if PRMF_PHASE_PROF
+  if (stamps && lane == 0)
+    for (int i = 0; i < 6; ++i) stamps[2048 + (blockIdx.x * 4 + wave) * 8 + i] = ph_sum[i];
+#endif
   if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x + 1] = wall_clock64();
 }
 
