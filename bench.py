@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3f32", "c5", "c5shard"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3f32", "c5", "c5shard", "c5shardf32"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)

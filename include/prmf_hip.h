@@ -43,7 +43,7 @@ enum prmf_status {
 };
 
 enum prmf_x_dtype {
-  PRMF_X_F32 = 0,            /* X float32: exact (k <= 64: split into three bf16 pieces on the bf16 MFMA; else fp32 MFMA) */
+  PRMF_X_F32 = 0,            /* X float32: exact (every value split into three bf16 pieces on the bf16 MFMA) */
   PRMF_X_BF16 = 1            /* X bfloat16, bf16 MFMA with hi+lo split factors, fp32 acc */
 };
 
@@ -257,7 +257,7 @@ typedef struct prmf_sweep_info {
   int64_t bytes_xt_sweep;   /* bytes of X^T streamed by the X^T*U sweep             */
   int32_t splits_xv, splits_xtu;
   int32_t grid_xv, grid_xtu;
-  int32_t f32_split;        /* 1: f32 X is multiplied as three bf16 pieces on the bf16 MFMA (k <= 64); 0: f32 MFMA or bf16 X */
+  int32_t f32_split;        /* 1: f32 X, multiplied as three bf16 pieces on the bf16 MFMA; 0: bf16 X */
   int32_t reserved;
 } prmf_sweep_info;
 int prmf_get_sweep_info(const prmf_ctx* ctx, prmf_sweep_info* out);

@@ -356,11 +356,12 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if (const char* e = getenv("PRMF_SWEEP_XCD")) tune.force_slices = atoi(e);
   c->plan_xv = plan_gemm(x_dtype, m_local > 0 ? m_local : 1, c->Kpad_x, c->NT, n_cus, tune);
   c->plan_xtu = plan_gemm(x_dtype, n, c->Kpad_xt, c->NT, n_cus, tune);
-  // f32 X at k <= 64: the sweep splits every f32 value of X exactly into three bf16 pieces in registers and runs the
+  // f32 X: the sweep splits every f32 value of X exactly into three bf16 pieces in registers and runs the
   // bf16 MFMA against the hi/lo-packed factor (5 products, cross terms in their own accumulators) instead of the f32
   // MFMA at 1/16 of the rate: 0.75 vs 1.05 ms per sweep at 50000 x 20000, and a smaller error (P = X V: rms 2.9e-7
-  // against 7.4e-7, no bias).  k > 64 keeps the f32 MFMA (two accumulator sets do not fit the registers).
-  c->split_f32 = x_dtype == PRMF_X_F32 && c->NT <= 2;
+  // against 7.4e-7, no bias).  k > 64: the same with 32-row wave tiles (two accumulator sets of a 64-row tile do not fit
+  // the registers): 0.80 vs 1.17 ms per sweep at 25000 x 25000, k = 128.
+  c->split_f32 = x_dtype == PRMF_X_F32;
   c->pack_dtype = c->split_f32 ? PRMF_X_BF16 : x_dtype;
   // slabs are written as whole 32-row tiles of whole panels (fragment order, no row masking)
   c->slab_stride_p = (int64_t)c->plan_xv.panels * c->plan_xv.panel_rows * c->KP;

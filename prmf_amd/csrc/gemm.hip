@@ -84,42 +84,20 @@ __global__ void __launch_bounds__(256) pack_bf16_kernel(FactorView f, int NT, in
   out[(blk + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
-__global__ void __launch_bounds__(256) pack_f32_kernel(FactorView f, int NT, int64_t ng, float4* __restrict__ out) {
-  int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int lane = (int)(gid & 63);
-  int64_t rest = gid >> 6;
-  int t = (int)(rest % NT);
-  int64_t g = rest / NT;
-  if (g >= ng) return;
-  int c = lane & 31, h = lane >> 5;
-  int col = 32 * t + c;
-  int64_t row0 = g * 8 + 4 * h;
-  float4 v;
-  v.x = factor_at(f, row0 + 0, col);
-  v.y = factor_at(f, row0 + 1, col);
-  v.z = factor_at(f, row0 + 2, col);
-  v.w = factor_at(f, row0 + 3, col);
-  out[(g * NT + t) * 64 + lane] = v;
-}
-
 hipError_t launch_pack_factor(const FactorView& f, int x_dtype, int NT, int64_t Kpad, void* packed, hipStream_t s) {
-  if (x_dtype == 1) {
-    int64_t nkb = Kpad / 16;
-    int64_t threads = nkb * NT * 64;
-    pack_bf16_kernel<<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(f, NT, nkb, (uint4*)packed);
-  } else {
-    int64_t ng = Kpad / 8;
-    int64_t threads = ng * NT * 64;
-    pack_f32_kernel<<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(f, NT, ng, (float4*)packed);
-  }
+  if (x_dtype != 1) return hipErrorInvalidValue;   // every sweep multiplies with the hi/lo bf16 fragment layout
+  int64_t nkb = Kpad / 16;
+  int64_t threads = nkb * NT * 64;
+  pack_bf16_kernel<<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(f, NT, nkb, (uint4*)packed);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
 // the sweep
 // ---------------------------------------------------------------------------
-// BF16 = true : A bf16, B hi/lo bf16, 2 MFMA (32x32x16) per fragment pair
-// BF16 = false: A f32,  B f32,        MFMA 32x32x2 f32 (exact f32 products)
+// MODE 1: A bf16, B hi/lo bf16, 2 MFMA (32x32x16) per fragment pair
+// MODE 2: A f32 split exactly into three bf16 pieces in registers, B hi/lo bf16, 5 MFMAs per fragment pair
+// (the f32 MFMA form of round 1 -- 1/16 of the bf16 rate -- is gone: at k = 128 it was 40% slower than MODE 2)
 //
 // A path.  The MFMA A fragment of lane (r = lane&31, h = lane>>5) is 16 B of row
 // r, i.e. a wave-wide fragment load touches 32 different 128-B lines with 32 B
@@ -155,21 +133,22 @@ __device__ __forceinline__ void split_fragment(const u32x4& f0, const u32x4& f1,
   }
 }
 
-// MODE 0: A f32, B f32 fragments, f32 MFMA | MODE 1: A bf16, B hi/lo bf16 | MODE 2: A f32 split into three bf16
-// pieces in registers, B hi/lo bf16 (5 bf16 MFMAs per fragment instead of 8 f32 MFMAs at 1/16 of the rate)
+// MODE 1: A bf16, B hi/lo bf16 | MODE 2: A f32 split into three bf16 pieces in registers, B hi/lo bf16 (5 bf16 MFMAs
+// per fragment instead of 8 f32 MFMAs at 1/16 of the rate)
 // acc_lo (MODE 2 only): the cross terms (<= 2^-8 of the main products) are summed in their own accumulators -- added
 // into the main ones they fall below half an ulp of a long running sum and are always rounded DOWN (a -4.8e-6 bias of
 // X V at 50000 x 20000: exactly the mean of the lowest piece of X)
 template <int MODE, int MT, int NT>
 __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&acc_lo)[MODE == 2 ? MT : 1][MODE == 2 ? NT : 1],
                                               const u32x4* __restrict__ sa, const u32x4* __restrict__ sb, int lane) {
-  constexpr bool BF16 = MODE == 1;
   const int r = lane & 31, h = lane >> 5;
   const int swz = (r >> 1) & 7;
   if constexpr (MODE == 2) {
-    // not unrolled over the two k-blocks: the three-piece split is register-hungry (222 registers at k = 64 next to the
-    // 2 x 64 accumulator registers; two waves per SIMD allow 256); unrolled it is no faster at k = 16 or k = 64
-#pragma unroll 1
+    // 64-row wave tiles (k <= 64): not unrolled over the two k-blocks -- the three-piece split is register-hungry (222
+    // registers at k = 64 next to the 2 x 64 accumulator registers; two waves per SIMD allow 256) and unrolled it is no
+    // faster at k = 16 or k = 64.  32-row wave tiles (k > 64): unrolled, so that the split of the second k-block runs
+    // under the MFMAs of the first (-2.5%, 229 registers at k = 128).
+#pragma unroll MT == 1 ? 2 : 1
     for (int kb = 0; kb < 2; ++kb) {
       u32x4 bh[NT], bl[NT];
 #pragma unroll
@@ -200,7 +179,8 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&ac
     }
     return;
   }
-  if constexpr (BF16 && NT > 2) {
+  static_assert(MODE == 1 || MODE == 2, "MODE 1: bf16 X, MODE 2: f32 X");
+  if constexpr (NT > 2) {
     // k > 64: the fragment reads of step j + 1 (a B hi/lo pair; the A fragments when a new 16-element slice starts) are
     // issued before the MFMAs of step j (the scheduling barriers keep the compiler from sinking them back): 2% at
     // k = 128; at k = 64 it changes nothing (profiles/r02_ab_priority_and_pipelined_reads.txt)
@@ -239,26 +219,14 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&ac
     for (int mt = 0; mt < MT; ++mt) av[mt] = sa[mt * 256 + r * 8 + ((2 * s4 + h) ^ swz)];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if constexpr (BF16) {
-        const u32x4 bh = sb[((s4 * NT + t) * 2 + 0) * 64 + lane];
-        const u32x4 bl = sb[((s4 * NT + t) * 2 + 1) * 64 + lane];
+      const u32x4 bh = sb[((s4 * NT + t) * 2 + 0) * 64 + lane];
+      const u32x4 bl = sb[((s4 * NT + t) * 2 + 1) * 64 + lane];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, av[mt]), __builtin_bit_cast(bf16x8, bh), acc[mt][t], 0, 0, 0);
-          acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, av[mt]), __builtin_bit_cast(bf16x8, bl), acc[mt][t], 0, 0, 0);
-        }
-      } else {
-        // f32: piece 2 s4 + h of the row = floats [8 s4 + 4 h, +4) = 8-row group s4 of B
-        const u32x4 bv = sb[(s4 * NT + t) * 64 + lane];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av[mt][q]), __uint_as_float(bv[q]),
-                                                              acc[mt][t], 0, 0, 0);
-        }
+      for (int mt = 0; mt < MT; ++mt) {
+        acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(bf16x8, av[mt]), __builtin_bit_cast(bf16x8, bh), acc[mt][t], 0, 0, 0);
+        acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(bf16x8, av[mt]), __builtin_bit_cast(bf16x8, bl), acc[mt][t], 0, 0, 0);
       }
     }
   }
@@ -441,9 +409,10 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   // The chunk loop is unrolled x2 so that the LDS buffer offsets are compile-time constants; it handles any number of
   // chunks per segment (odd only with UNIT = 1), and the last chunk of a segment loads nothing (it used to re-load
   // itself: one wasted chunk per segment).  `have` / `next` are workgroup-uniform.
-  // f32 X on the bf16 MFMA (MODE 2): loads first only at k <= 32 (-6% on the 5000 x 10000, k = 16 sweeps); at k = 64 the
-  // chunk in flight costs 22 more registers (244, no spills) and the sweeps are 0.5% slower (profiles/r02_ab_f32_loads_first.txt)
-  constexpr bool LF_MODE_OK = MODE != 2 || NT == 1;
+  // f32 X on the bf16 MFMA (MODE 2): loads first at k <= 32 (-6% on the 5000 x 10000, k = 16 sweeps) and at k > 64 (32-row
+  // wave tiles: -3%); at k = 64 the chunk in flight costs 22 more registers (244, no spills) and the sweeps are 0.5%
+  // slower (profiles/r02_ab_f32_loads_first.txt, r02_ab_f32_wide.txt)
+  constexpr bool LF_MODE_OK = MODE != 2 || NT == 1 || MT == 1;
   for (int c = 0; c < nch; c += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -544,8 +513,9 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
   GemmPlan p;
   p.nw = SWEEP_NW;
   p.bdb = NT <= 2;
-  p.mt = SWEEP_MT;
-  p.panel_rows = SWEEP_NW * 32 * SWEEP_MT;
+  // f32 X at k > 64 (three-piece split: two accumulator sets): 32-row wave tiles, 128-row panels
+  p.mt = (x_dtype == 0 && NT > 2) ? 1 : SWEEP_MT;
+  p.panel_rows = SWEEP_NW * 32 * p.mt;
   p.panels = (int)(round_up(M, p.panel_rows) / p.panel_rows);
   p.nchunks = (int)(Kpad / chunk_elems(x_dtype));          // even (K_PAD)
   p.ngroups = p.nchunks / UNIT;                            // work units per row panel
@@ -645,17 +615,16 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
   const int64_t lda16 = lda * elem_bytes(x_dtype) / 16;
   const SweepPrologue pro = prologue ? *prologue : SweepPrologue{};
   if (pro.kind != PROLOGUE_NONE && (p.nw != 4 || pro.nparts > GRAM_MAX_PARTS)) return hipErrorInvalidValue;
-  // arithmetic: 1 = bf16 X x hi/lo bf16 factor; 2 = f32 X split into three bf16 pieces (k <= 64); 0 = f32 MFMA (f32 X, k > 64)
-  const int mode = x_dtype == 1 ? 1 : (split ? 2 : 0);
-  if (p.nw != SWEEP_NW || p.mt != SWEEP_MT || p.bdb != (NT <= 2)) return hipErrorInvalidValue;
+  // arithmetic: 1 = bf16 X x hi/lo bf16 factor; 2 = f32 X split into three bf16 pieces (every k)
+  const int mode = x_dtype == 1 ? 1 : 2;
+  if (x_dtype != 1 && !split) return hipErrorInvalidValue;
+  if (p.nw != SWEEP_NW || p.mt != ((mode == 2 && NT > 2) ? 1 : SWEEP_MT) || p.bdb != (NT <= 2)) return hipErrorInvalidValue;
   if (NT <= 2) {
     if (mode == 1) return launch_sweep_nt<1, SWEEP_NW, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
-    if (mode == 2) return launch_sweep_nt<2, SWEEP_NW, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
-    return hipErrorInvalidValue;       // f32 X at k <= 64 always takes the split form
+    return launch_sweep_nt<2, SWEEP_NW, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
   }
   if (mode == 1) return launch_sweep_nt<1, SWEEP_NW, false, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
-  if (mode == 0) return launch_sweep_nt<0, SWEEP_NW, false, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
-  return hipErrorInvalidValue;
+  return launch_sweep_nt<2, SWEEP_NW, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
 }
 
 // the prologue work without a sweep behind it (end of a batch)

@@ -10,6 +10,7 @@ CONFIGS = {
     "c3f32": (50000, 20000, 64, 300, "f32"),      # the CLI default storage of X
     "c5": (200000, 25000, 128, 1000, "bf16"),
     "c5shard": (25000, 25000, 128, 1000, "bf16"),     # one rank's share of c5 on 8 GPUs
+    "c5shardf32": (25000, 25000, 128, 1000, "f32"),   # the same with the CLI's default storage of X
 }
 
 

@@ -123,7 +123,7 @@ def _tile_check(torch, name, got, want, tol_tile):
     return {"rel_" + name: r, "tile_" + name: worst, "bad_tiles_" + name: bad}
 
 
-@pytest.mark.parametrize("workload,x_dtype", [("c3", "bf16"), ("c3", "f32"), ("c5shard", "bf16")])
+@pytest.mark.parametrize("workload,x_dtype", [("c3", "bf16"), ("c3", "f32"), ("c5shard", "bf16"), ("c5shard", "f32")])
 def test_one_iteration_vs_fp64_at_full_size(workload, x_dtype):
     import torch
     eng, Xd, U, V, pathways, active, gamma, delta = _engine(torch, workload, x_dtype, 11)
