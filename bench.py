@@ -26,7 +26,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-F32_MFMA_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak (same guide)
 
 
 def parse():
@@ -230,13 +229,12 @@ def main():
     bytes_launch = 0.5 * ((ml * n * eb + n * k * 4 + ml * k * 4) + (ml * n * eb + ml * k * 4 + n * k * 4))
     avg_ms = 0.5 * (ms_xv + ms_xtu)
     achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
-    # f32 X at k > 64 runs on the f32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense = 1/16 of the bf16 rate): that
-    # pipe, not HBM, bounds the sweep there; bf16 X, and f32 X at k <= 64 (split into bf16 pieces), are HBM-bound
+    # Every sweep runs on the bf16 MFMA (bf16 X: 2 instructions per 16-element product with the hi/lo factor; f32 X: 5, the
+    # three-piece split).  At the nominal 2.5 PFLOP/s even the heaviest case (f32 X, k = 128: 5 x 2 m n k = 8e11 flop
+    # per launch = 0.32 ms) is no slower than its HBM time at 8 TB/s (0.31 ms), so HBM is the roof for every workload;
+    # DESIGN.md section 5 has the clock the chip actually sustains under these kernels.
     flops_launch = 2.0 * ml * n * k
     tflops = flops_launch / (avg_ms * 1e-3) / 1e12
-    # which roof is lower for this shape: flop per byte against the machine balance of the pipe that runs it
-    mfma_bound = (x_dtype != "bf16" and not eng.sweep_info().f32_split and
-                  flops_launch / bytes_launch > F32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9))
     # whole-iteration roofline: B = 2 m n s_X + 12 (m + n) k + 8 sum nnz + 12 sum |S|
     nnz_active = sum(2 * len(pathways[p][0]) for p in active)
     sup_active = sum(len(pathways[p][2]) for p in active)
@@ -263,10 +261,8 @@ def main():
                                        "X row-sharded x%d, V update %s, RCCL %s" % (
                                            world, eng.dist_mode, "in-library" if runner.native else "host-driven"))},
             "recon_err": objs[-1]["recon"], "objective": objs[-1]["obj"],
-            "roofline": ({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": achieved / HBM_PEAK_GBS, "tflops": tflops} if not mfma_bound else
-                         {"bound": "mfma", "achieved": tflops, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": tflops / F32_MFMA_PEAK_TFLOPS, "hbm_gbs": achieved}),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "tflops": tflops},
         }
         out["roofline"].update({"traffic": traffic,
                                 "kernel": "sweep_kernel (X*V and X^T*U, 2 launches/iteration)",
