@@ -509,12 +509,17 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 //   k  > 64: factor chunk single-buffered (k = 128: 32 + 32 KiB, 116 VGPRs + 128 accumulator registers), two barriers.
 constexpr int SWEEP_NW = 4, SWEEP_MT = 2, SWEEP_WGS_PER_CU = 2;
 
+// 32-row tiles per wave.  bf16 X: 2 at every k.  f32 X (three-piece split, two accumulator sets): 2 at k = 33..64; 1 at
+// k > 64, where two do not fit 256 registers, and at k <= 32, where the 128-row panels measure 4% faster on the
+// 5000 x 10000, k = 16 sweeps (half as many segments per panel); at k = 64 one tile per wave is 1-2% slower
+// (profiles/r02_ab_f32_wide.txt).
+static int f32_wave_tiles(int x_dtype, int NT) { return (x_dtype == 0 && NT != 2) ? 1 : SWEEP_MT; }
+
 GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, const SweepTuning& tune) {
   GemmPlan p;
   p.nw = SWEEP_NW;
   p.bdb = NT <= 2;
-  // f32 X at k > 64 (three-piece split: two accumulator sets): 32-row wave tiles, 128-row panels
-  p.mt = (x_dtype == 0 && NT > 2) ? 1 : SWEEP_MT;
+  p.mt = f32_wave_tiles(x_dtype, NT);
   p.panel_rows = SWEEP_NW * 32 * p.mt;
   p.panels = (int)(round_up(M, p.panel_rows) / p.panel_rows);
   p.nchunks = (int)(Kpad / chunk_elems(x_dtype));          // even (K_PAD)
@@ -618,9 +623,10 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
   // arithmetic: 1 = bf16 X x hi/lo bf16 factor; 2 = f32 X split into three bf16 pieces (every k)
   const int mode = x_dtype == 1 ? 1 : 2;
   if (x_dtype != 1 && !split) return hipErrorInvalidValue;
-  if (p.nw != SWEEP_NW || p.mt != ((mode == 2 && NT > 2) ? 1 : SWEEP_MT) || p.bdb != (NT <= 2)) return hipErrorInvalidValue;
+  if (p.nw != SWEEP_NW || p.mt != f32_wave_tiles(x_dtype, NT) || p.bdb != (NT <= 2)) return hipErrorInvalidValue;
   if (NT <= 2) {
     if (mode == 1) return launch_sweep_nt<1, SWEEP_NW, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
+    if (p.mt == 1) return launch_sweep_nt<2, SWEEP_NW, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
     return launch_sweep_nt<2, SWEEP_NW, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
   }
   if (mode == 1) return launch_sweep_nt<1, SWEEP_NW, false, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
