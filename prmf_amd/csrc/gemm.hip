@@ -539,11 +539,18 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
     // 50000x20000, k=64 (interleaved runs): X^T*U (12.8 MB factor) 0.425 -> 0.36-0.39 ms at 4 slices;
     // X*V (5.1 MB factor) is fastest unsliced (0.35-0.375 vs 0.40-0.42: the extra segments cost more).
     const double factor_mb = (double)Kpad * 32.0 * NT * 4.0 / (1024.0 * 1024.0);
-    if (factor_mb > 6.0) {
+    if (factor_mb > 7.0) {
       const double slice_mb = 3.5;      // 8 slices (2 MB each) were bimodal: 0.355 / 0.413 ms
       p.nx = 2;
       while (p.nx < 8 && factor_mb / p.nx > slice_mb) p.nx *= 2;
       while (p.nx > 1 && units_per_wg < 0.5 * ((double)p.ngroups / p.nx)) p.nx /= 2;
+    } else if (factor_mb > 4.0 && units_per_wg <= 0.5 * ((double)p.ngroups / 2.0)) {
+      // A factor that barely exceeds the L2 (5.1 MB: V at 20000 genes, k = 64; 4.3 / 6.4 MB: U of a 16667 / 25000-row
+      // share) is worth two slices when a workgroup's share is at most half a slice row, i.e. for the row shares of a
+      // multi-GPU run: X V 69.7 -> 61.8 us at 6250 rows, 112 -> 103 at 12500, 136 -> 127 at 16667, 192 -> 188 at 25000;
+      // X^T U 207 -> 181 us at 25000 samples.  With longer shares (50000 rows: 0.77 of a slice row) the shares
+      // straddle slice boundaries and two slices are 0-6% slower (profiles/r02_slices_small_shares.txt).
+      p.nx = 2;
     }
     if (tune.force_slices == 1 || tune.force_slices == 2 || tune.force_slices == 4 || tune.force_slices == 8) p.nx = tune.force_slices;
   }
