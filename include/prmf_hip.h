@@ -272,7 +272,10 @@ int prmf_get_sweep_info(const prmf_ctx* ctx, prmf_sweep_info* out);
  * prologues of the two sweeps) and the objective records of all iterations since prmf_begin are evaluated in prmf_end
  * from per-iteration state kept on the device -- same arithmetic, bit-identical records.  This flag keeps the
  * per-iteration evaluation (three more launches per iteration): the form the tradeoff feedback (prmf_runner.py:542-548)
- * and the multi-rank phases always use. */
+ * always uses.  Multi-rank: the replicated mode defers in the same way; the column-sharded mode keeps its update
+ * sequence but reduces V^T V in the next sweep's prologue and writes the records in prmf_end from the kept Grams and
+ * the gathered per-rank sums (two launches fewer per iteration, bit-identical records); the flag restores the
+ * per-iteration form there too. */
 #define PRMF_FLAG_EAGER_OBJECTIVE 0x4u
 /* Switch the per-launch event timing on or off after creation (bench.py times its
  * throughput run without events and a second short run with them). */

@@ -97,6 +97,8 @@ struct prmf_ctx {
   double* Gv_keep = nullptr;          // [MAX_RECORDS][k*k]
   double* colnorm2_ring = nullptr;    // [MAX_RECORDS][k]
   double* cross_ring = nullptr;       // [MAX_RECORDS]
+  double* extras_ring = nullptr;      // column-sharded mode: [MAX_RECORDS][nranks][3] gathered <Q,V>, manifold, ignore
+  bool lazy_cs = false;               // column-sharded mode with the records deferred to prmf_end (see prmf_begin)
   double* colres_ring = nullptr;      // [MAX_RECORDS][k][2]
   float* vsup_ring = nullptr;         // [MAX_RECORDS][k][max_support]   (allocated with the pathway library)
 
@@ -269,11 +271,13 @@ SweepPrologue post_prologue(prmf_ctx* c, int it) {
   p.k = c->k;
   p.G = c->Gv;
   p.G_keep = c->Gv_keep + (size_t)slot * c->k * c->k;
-  p.vpartial = c->vpartial;
-  p.nwaves = c->vblocks;
-  p.colnorm2 = c->colnorm2_ring + (size_t)slot * c->k;
-  p.cross = c->cross_ring + slot;
-  if (c->nranks > 1) {                 // replicated multi-rank: the kept U^T U is the all-reduced one
+  if (!c->lazy_cs) {                   // (column-sharded: these sums come with the all-gather, see extras_ring)
+    p.vpartial = c->vpartial;
+    p.nwaves = c->vblocks;
+    p.colnorm2 = c->colnorm2_ring + (size_t)slot * c->k;
+    p.cross = c->cross_ring + slot;
+  }
+  if (c->nranks > 1) {                 // multi-rank: the kept U^T U is the all-reduced one
     p.gu_src = c->gram_buf;
     p.gu_keep = c->Gu_keep + (size_t)slot * c->k * c->k;
   }
@@ -395,9 +399,13 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, &c->hyper, 4))) return bail(rc);
   if ((rc = dev_alloc(c, &c->records, (size_t)MAX_RECORDS * PRMF_OBJ_STRIDE))) return bail(rc);
   if ((rc = dev_alloc(c, &c->colnorm, (size_t)k))) return bail(rc);
-  if (nranks == 1 || c->replicated) {
+  if (nranks > 1 && !c->replicated && 3 * nranks <= 256 &&
+      (rc = dev_alloc(c, &c->extras_ring, (size_t)MAX_RECORDS * nranks * 3))) return bail(rc);
+  {
     if ((rc = dev_alloc(c, &c->Gu_keep, (size_t)(MAX_RECORDS + 1) * k * k, false))) return bail(rc);
     if ((rc = dev_alloc(c, &c->Gv_keep, (size_t)(MAX_RECORDS + 1) * k * k, false))) return bail(rc);
+  }
+  if (nranks == 1 || c->replicated) {
     if ((rc = dev_alloc(c, &c->colnorm2_ring, (size_t)(MAX_RECORDS + 1) * k))) return bail(rc);
     if ((rc = dev_alloc(c, &c->cross_ring, (size_t)MAX_RECORDS + 1))) return bail(rc);
     if ((rc = dev_alloc(c, &c->colres_ring, (size_t)MAX_RECORDS * k * 2))) return bail(rc);
@@ -461,6 +469,7 @@ int prmf_destroy(prmf_ctx* c) {
   dev_free(c->Gv_keep);
   dev_free(c->colnorm2_ring);
   dev_free(c->cross_ring);
+  dev_free(c->extras_ring);
   dev_free(c->colres_ring);
   dev_free(c->vsup_ring);
   dev_free(c->scores_dev);
@@ -661,6 +670,12 @@ int prmf_begin(prmf_ctx* c, float* dU, float* dV, double gamma, double delta, do
   // the X^T U sweep.  Column-sharded mode keeps the eager sequence (its objective pieces travel with the all-gather).
   c->lazy = (c->nranks == 1 ? !c->dist_driver : c->replicated) && c->m > 0 && c->fused_u && c->fused_v && !(tradeoff >= 0.0) &&
             c->plan_xv.nw == 4 && c->plan_xtu.nw == 4 && c->vsup_ring && !(c->flags & PRMF_FLAG_EAGER_OBJECTIVE);
+  // Column-sharded mode: the update sequence stays as it is (its objective pieces travel with the all-gather), but the
+  // record of an iteration is not needed before prmf_end unless the tradeoff feedback is on: V^T V is then reduced by
+  // the next X V sweep's prologue and the records of the batch come from one launch at the end (2 launches fewer per
+  // iteration).  Decided per rank; the collectives do not depend on it.
+  c->lazy_cs = c->nranks > 1 && !c->replicated && c->m > 0 && c->fused_u && c->NT <= 2 && !(tradeoff >= 0.0) &&
+               c->plan_xv.nw == 4 && c->extras_ring && !(c->flags & PRMF_FLAG_EAGER_OBJECTIVE);
   c->batch_open = true;
   return PRMF_OK;
 }
@@ -674,12 +689,15 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (c->m > 0) {
     const bool timing = (c->flags & PRMF_FLAG_TIMING) != 0;
-    if (c->lazy && c->gv_pending && c->cursor == 0) {   // cannot happen through prmf_begin/prmf_end; keep V^T V right anyway
+    if ((c->lazy || c->lazy_cs) && c->gv_pending && c->cursor == 0) {   // cannot happen through prmf_begin/prmf_end; keep V^T V right anyway
       HIP_TRY(c, launch_prologue_alone(post_prologue(c, -1), s));
       c->gv_pending = false;
     }
     SweepPrologue pro;
-    if (c->lazy && c->gv_pending) pro = post_prologue(c, c->cursor - 1);
+    if ((c->lazy || c->lazy_cs) && c->gv_pending) {
+      pro = post_prologue(c, c->cursor - 1);
+      if (c->lazy_cs) c->gv_pending = false;
+    }
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 0], s));
     // P = X V                                             (prmf_runner.py:420)
     HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xv, c->X, c->ldx, c->m, c->Vp, c->NT, c->slabs, c->slab_stride_p, s, c->split_f32,
@@ -837,7 +855,14 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
     if (c->fused_u) {
       bool gram_done = false;
       HIP_TRY(c, launch_v_post(c->V, c->n, c->k, c->v_recv, c->v_send_floats, c->kc, c->KP, c->pack_dtype, c->Vp, c->Kpad_x,
-                               (float*)c->gram_partial, &gram_done, s));
+                               (float*)c->gram_partial, &gram_done, s,
+                               c->lazy_cs ? c->extras_ring + (size_t)c->cursor * c->lr * 3 : nullptr, c->lr, c->extras_off));
+      if (gram_done && c->lazy_cs) {   // V^T V: the next X V sweep's prologue (or prmf_end); record: prmf_end
+        c->nparts_v = epilogue_blocks(c->Kpad_x);
+        c->gv_pending = true;
+        c->cursor++;
+        return PRMF_OK;
+      }
       if (gram_done) {
         HIP_TRY(c, launch_gram_reduce((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x), c->k, c->Gv, s));
         HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->lr, c->v_send_floats, c->extras_off,
@@ -887,6 +912,14 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
                                     c->obj_scratch, s));
     HIP_TRY(c, launch_records_all(c->Gu_keep, c->Gv_keep, c->k, c->cursor, c->cross_ring, c->colres_ring, c->norm_x_sq, c->hyper,
                                   c->records, s));
+  }
+  if (c->lazy_cs) {
+    if (c->gv_pending) {
+      HIP_TRY(c, launch_prologue_alone(post_prologue(c, c->cursor - 1), s));
+      c->gv_pending = false;
+    }
+    HIP_TRY(c, launch_finalize_batch(c->Gu_keep, c->Gv_keep, c->k, c->cursor, c->extras_ring, c->lr, c->norm_x_sq, c->hyper,
+                                     c->records, s));
   }
   c->batch_open = false;
   if (n_steps > 0)

@@ -202,7 +202,10 @@ hipError_t launch_mid(const float* gram_partial, int nparts, int k, double* Gu, 
                       float* gden, hipStream_t s);
 // multi-rank phase_post in one pass: gathered blocks -> V, packed fragments, V^T V partials
 hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_t blk_stride, int kc, int KP, int x_dtype,
-                         void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, hipStream_t s);
+                         void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, hipStream_t s,
+                         double* extras_keep = nullptr, int nranks = 0, int64_t extras_off = 0);
+hipError_t launch_finalize_batch(const double* Gu_keep, const double* Gv_keep, int k, int n_it, const double* extras_ring,
+                                 int nranks, double norm_x_sq, double* hyper, double* records, hipStream_t s);
 hipError_t launch_post(const float* gram_partial, int nparts, int k, double* Gv, const PathwayLibDev& lib,
                        const int32_t* active_dev, const float* V, const double* partial, int nblocks, double* colres,
                        double* scratch, hipStream_t s);

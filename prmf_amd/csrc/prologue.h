@@ -127,8 +127,9 @@ __device__ __forceinline__ void run_sweep_prologue(const SweepPrologue& p, char*
   for (int j = blockIdx.x; j < nj; j += gridDim.x) gram_reduce_job(p.gram_partial, p.nparts, kk2, p.G, p.G_keep, j, red);
   if (p.kind == PROLOGUE_POST) {
     // workgroups from the far end of the grid first: at small k they are the ones without a Gram job
-    for (int c = (int)(gridDim.x - 1 - blockIdx.x); c <= p.k; c += gridDim.x)
-      colcross_job(p.vpartial, p.nwaves, p.k, c, p.colnorm2, p.cross, red);
+    if (p.vpartial)                  // column-sharded multi-rank mode: these sums arrive with the all-gather instead
+      for (int c = (int)(gridDim.x - 1 - blockIdx.x); c <= p.k; c += gridDim.x)
+        colcross_job(p.vpartial, p.nwaves, p.k, c, p.colnorm2, p.cross, red);
     if (p.gu_keep)
       for (int e = (int)(blockIdx.x * 256 + threadIdx.x); e < kk2; e += (int)(gridDim.x * 256)) p.gu_keep[e] = p.gu_src[e];
   } else if (p.kind == PROLOGUE_MID) {

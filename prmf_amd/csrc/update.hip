@@ -1167,8 +1167,11 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
 template <int NT, bool BF16, bool GRAM>
 __global__ void __launch_bounds__(256)
 v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ v_recv, int64_t blk_stride, int kc,
-              void* __restrict__ packed, int64_t ntiles_pack, float* __restrict__ gram_partial) {
+              void* __restrict__ packed, int64_t ntiles_pack, float* __restrict__ gram_partial,
+              double* __restrict__ extras_keep /* null or [nranks][3] */, int nranks, int64_t extras_off) {
   constexpr int NP = NT * (NT + 1) / 2;
+  if (extras_keep && blockIdx.x == 0 && (int)threadIdx.x < 3 * nranks)   // deferred records: <Q,V>, manifold, ignore of every rank
+    extras_keep[threadIdx.x] = reinterpret_cast<const double*>(v_recv + (int64_t)(threadIdx.x / 3) * blk_stride + extras_off)[threadIdx.x % 3];
   __shared__ float red[GRAM ? 4 : 1][16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
@@ -1208,14 +1211,16 @@ v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__
 }
 
 hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_t blk_stride, int kc, int KP, int x_dtype,
-                         void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, hipStream_t s) {
+                         void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, hipStream_t s,
+                         double* extras_keep, int nranks, int64_t extras_off) {
+  if (extras_keep && 3 * nranks > 256) return hipErrorInvalidValue;
   const int NT = KP / 32;
   const int64_t ntiles = Kpad / 32;
   const int grid = epilogue_blocks(Kpad);
   *gram_done = NT <= 2;
 #define PRMF_VPOST(NTV, GR)                                                                                      \
-  if (x_dtype == 1) v_post_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial); \
-  else v_post_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial)
+  if (x_dtype == 1) v_post_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, extras_keep, nranks, extras_off); \
+  else v_post_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, extras_keep, nranks, extras_off)
   switch (NT) {
     case 1: PRMF_VPOST(1, true); break;
     case 2: PRMF_VPOST(2, true); break;
@@ -1636,9 +1641,15 @@ __global__ void __launch_bounds__(256)
 finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, int k, const float* __restrict__ v_recv,
                 int nranks, int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* __restrict__ hyper,
                 double* __restrict__ record, const double* __restrict__ loc_partial, int loc_nblocks,
-                const double* __restrict__ loc_colres) {
+                const double* __restrict__ loc_colres, const double* __restrict__ extras_ring /* batch form, else null */) {
   __shared__ double red[5][256];
   const int tid = threadIdx.x;
+  if (extras_ring) {                   // batch form (column-sharded mode, records deferred): workgroup = iteration
+    Gu += (size_t)blockIdx.x * k * k;
+    Gv += (size_t)blockIdx.x * k * k;
+    record += (size_t)blockIdx.x * 8;        // PRMF_OBJ_STRIDE
+    extras_ring += (size_t)blockIdx.x * 3 * nranks;
+  }
   // five sums, one tree reduction (fixed order: deterministic)
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // <Gu,Gv>, trace Gu, cross, manifold, ignore
   for (int i = tid; i < k * k; i += 256) acc[0] += Gu[i] * Gv[i];
@@ -1666,7 +1677,8 @@ finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, in
     double cross = lcross, man = lman, ign = lign;
     if (!loc_partial)
       for (int r = 0; r < nranks; ++r) {
-        const double* ex = reinterpret_cast<const double*>(v_recv + (int64_t)r * blk_stride + extras_off);
+        const double* ex = extras_ring ? extras_ring + 3 * r
+                                       : reinterpret_cast<const double*>(v_recv + (int64_t)r * blk_stride + extras_off);
         cross += ex[0];
         man += ex[1];
         ign += ex[2];
@@ -1695,7 +1707,16 @@ hipError_t launch_finalize(const double* Gu, const double* Gv, int k, const floa
                            int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* hyper, double* record,
                            const double* loc_partial, int loc_nblocks, const double* loc_colres, hipStream_t s) {
   finalize_kernel<<<1, 256, 0, s>>>(Gu, Gv, k, v_recv, nranks, blk_stride, extras_off, norm_x_sq, hyper, record,
-                                    loc_partial, loc_nblocks, loc_colres);
+                                    loc_partial, loc_nblocks, loc_colres, nullptr);
+  return hipGetLastError();
+}
+
+// the records of `n_it` iterations at once from the kept Grams and rank extras (column-sharded mode, tradeoff off)
+hipError_t launch_finalize_batch(const double* Gu_keep, const double* Gv_keep, int k, int n_it, const double* extras_ring,
+                                 int nranks, double norm_x_sq, double* hyper, double* records, hipStream_t s) {
+  if (n_it <= 0) return hipSuccess;
+  finalize_kernel<<<n_it, 256, 0, s>>>(Gu_keep, Gv_keep, k, nullptr, nranks, 0, 0, norm_x_sq, hyper, records, nullptr, 0,
+                                       nullptr, extras_ring);
   return hipGetLastError();
 }
 

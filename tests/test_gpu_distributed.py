@@ -47,7 +47,7 @@ def _collect(procs, q, deadline_s=300):
     return res
 
 
-def _worker(rank, world, port, k, x_dtype, mode, q):
+def _worker(rank, world, port, k, x_dtype, mode, q, eager=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -61,7 +61,8 @@ def _worker(rank, world, port, k, x_dtype, mode, q):
         case = synth.small_case(seed=13, m=700, n=1500, k=k, P=6, order=80, bf16_x=(x_dtype == "bf16"))
         X = case["X"]
         lo, hi = shard_rows(X.shape[0], world, rank)
-        eng = PrmfEngine(hi - lo, X.shape[1], k, x_dtype=x_dtype, device=0, nranks=world, rank=rank, dist_mode=mode)
+        eng = PrmfEngine(hi - lo, X.shape[1], k, x_dtype=x_dtype, device=0, nranks=world, rank=rank, dist_mode=mode,
+                         eager_objective=eager)
         assert eng.dist_mode == mode
         eng.set_x(X[lo:hi], norm_x_sq=float(np.sum(X * X)))
         eng.set_library(PathwayLibrary.from_edge_lists(X.shape[1], case["pathways"]))
@@ -101,6 +102,25 @@ def test_two_ranks_match_single_rank(k, x_dtype, mode):
     for a, b in zip(res[0][2], tr):
         for key in ("recon", "manifold", "ignore", "fro", "obj"):
             assert abs(a[key] - b[key]) <= 1e-4 * max(abs(b[key]), 1e-12), key
+
+
+@pytest.mark.parametrize("k,x_dtype", [(64, "bf16"), (16, "f32")])
+def test_column_sharded_deferred_records_equal_eager(k, x_dtype):
+    """Column-sharded mode: the records evaluated at prmf_end from the kept Grams and gathered rank extras (V^T V reduced
+    by the next sweep's prologue) against the per-iteration form (PRMF_FLAG_EAGER_OBJECTIVE): bit for bit, factors too."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = []
+    for eager in (False, True):
+        q = ctx.SimpleQueue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, k, x_dtype, "colshard", q, eager)) for r in range(2)]
+        for p in procs:
+            p.start()
+        out.append(_collect(procs, q))
+    for r in range(2):
+        assert np.array_equal(out[0][r][0], out[1][r][0]) and np.array_equal(out[0][r][1], out[1][r][1])
+        assert out[0][r][2] == out[1][r][2]
 
 
 def test_in_library_rccl_step_single_rank():
