@@ -261,6 +261,20 @@ int ensure_own_comm(prmf_ctx* c) {
   return PRMF_OK;
 }
 
+// the pathway terms of this rank's columns as extra workgroups of the U epilogue launch
+static GraphJob graph_job(const prmf_ctx* c) {
+  GraphJob gj;
+  gj.lib = c->lib;
+  gj.active = c->active_dev;
+  gj.col0 = c->col0;
+  gj.ncols = c->ncols;
+  gj.V = c->V;
+  gj.hyper = c->hyper;
+  gj.gnum = c->gnum;
+  gj.gden = c->gden;
+  return gj;
+}
+
 // prologue that closes iteration `it` of the batch on the V side (it < 0: results go to the spare ring slot)
 SweepPrologue post_prologue(prmf_ctx* c, int it) {
   const int slot = it >= 0 ? it : MAX_RECORDS;
@@ -708,30 +722,18 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
     if (c->lazy) {
       c->gv_pending = false;
       bool gram_done = false;
-      GraphJob gj;                     // one rank: the pathway terms ride in the U epilogue launch (extra workgroups)
-      if (c->nranks == 1) {
-        gj.lib = c->lib;
-        gj.active = c->active_dev;
-        gj.col0 = 0;
-        gj.ncols = c->k;
-        gj.V = c->V;
-        gj.hyper = c->hyper;
-        gj.gnum = c->gnum;
-        gj.gden = c->gden;
-      }
+      const GraphJob gj = graph_job(c);   // the pathway terms ride in the U epilogue launch (extra workgroups)
       HIP_TRY(c, launch_u_epilogue(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP,
-                                   c->Gv, c->pack_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, c->wpt_u, s,
-                                   c->nranks == 1 ? &gj : nullptr));
+                                   c->Gv, c->pack_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, c->wpt_u, s, &gj));
       c->nparts_u = epilogue_blocks(c->Kpad_xt, c->wpt_u);
       if (!gram_done) {                // k > 64: the epilogue has no registers left for the Gram tiles
         HIP_TRY(c, launch_gram_partials(fu, (float*)c->gram_partial, s));
         c->nparts_u = gram_blocks(fu.rows);
       }
-      if (c->nranks > 1) {             // the caller all-reduces U^T U next: reduce the local partials (+ pathway terms) now
+      c->graph_done = true;
+      if (c->nranks > 1)               // the caller all-reduces U^T U next: reduce the local partials now
         HIP_TRY(c, launch_mid((const float*)c->gram_partial, c->nparts_u, c->k, c->gram_buf, c->lib, c->active_dev, c->col0,
-                              c->ncols, c->V, c->hyper, c->gnum, c->gden, s));
-        c->graph_done = true;
-      }
+                              0, c->V, c->hyper, c->gnum, c->gden, s));
       return PRMF_OK;                  // one rank: U^T U and the pathway terms come from the X^T U sweep's prologue
     }
     if (c->post_pending) {            // V^T V (and gamma/delta) of the previous iteration come from the aux stream
@@ -740,15 +742,15 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
     }
     if (c->fused_u) {
       bool gram_done = false;
+      // the pathway terms of the own columns (they depend on the old V and gamma/delta only) ride in the U epilogue
+      // launch as extra workgroups; `mid` then only reduces (this rank's) U^T U
+      const GraphJob gj = graph_job(c);
       HIP_TRY(c, launch_u_epilogue(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP,
-                                   c->Gv, c->pack_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, c->wpt_u, s));
+                                   c->Gv, c->pack_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, c->wpt_u, s, &gj));
+      c->graph_done = true;
       if (gram_done) {
-        // one launch: reduce (this rank's) U^T U and compute the pathway terms of the own columns
-        // (they depend on the old V and gamma/delta only); next to the X^T U sweep when driven internally
-        hipStream_t ms = s;
         HIP_TRY(c, launch_mid((const float*)c->gram_partial, epilogue_blocks(c->Kpad_xt, c->wpt_u), c->k, c->gram_buf, c->lib,
-                              c->active_dev, c->col0, c->ncols, c->V, c->hyper, c->gnum, c->gden, ms));
-        c->graph_done = true;
+                              c->active_dev, c->col0, 0, c->V, c->hyper, c->gnum, c->gden, s));
         return PRMF_OK;
       }
     } else {
