@@ -111,25 +111,25 @@ hipError_t launch_pack_factor(const FactorView& f, int x_dtype, int NT, int64_t 
 // of the 256-B bank row (rows of equal parity in a group differ in (r>>1)&7).
 // No barrier is needed for A: a wave only reads what it wrote, and the LDS
 // executes one wave's instructions in order.
-// f32 -> three bf16 pieces by truncation: x = h + m + l exactly (8 + 8 + 8 mantissa bits)
-__device__ __forceinline__ void split3(unsigned xb, unsigned& hb, unsigned& mb, unsigned& lb) {
-  hb = xb & 0xFFFF0000u;
-  const float r1 = __uint_as_float(xb) - __uint_as_float(hb);
-  mb = __float_as_uint(r1) & 0xFFFF0000u;
-  const float r2 = r1 - __uint_as_float(mb);
-  lb = __float_as_uint(r2) & 0xFFFF0000u;
-}
+// f32 -> three bf16 pieces by truncation: x = h + m + l exactly (8 + 8 + 8 mantissa bits).  h, m, l are the upper halves
+// of x, r1 = x - h and r2 = r1 - m, so the bf16 pairs are packed straight from those with one v_perm_b32 each; only the
+// two subtrahends need a mask.
 // 8 floats (two 16-B pieces) -> bf16x8 fragments of the high, middle and low pieces
 __device__ __forceinline__ void split_fragment(const u32x4& f0, const u32x4& f1, u32x4& fh, u32x4& fm, u32x4& fl) {
-  unsigned x[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+  const unsigned x[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+  constexpr unsigned UPPER_HALVES = 0x07060302u;    // v_perm_b32 (S0 = odd element, S1 = even): [S0.hi16 : S1.hi16]
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    unsigned h0, m0, l0, h1, m1, l1;
-    split3(x[2 * j], h0, m0, l0);
-    split3(x[2 * j + 1], h1, m1, l1);
-    fh[j] = (h0 >> 16) | h1;
-    fm[j] = (m0 >> 16) | m1;
-    fl[j] = (l0 >> 16) | l1;
+    unsigned r1[2], r2[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const unsigned xb = x[2 * j + e];
+      r1[e] = __float_as_uint(__uint_as_float(xb) - __uint_as_float(xb & 0xFFFF0000u));
+      r2[e] = __float_as_uint(__uint_as_float(r1[e]) - __uint_as_float(r1[e] & 0xFFFF0000u));
+    }
+    fh[j] = __builtin_amdgcn_perm(x[2 * j + 1], x[2 * j], UPPER_HALVES);
+    fm[j] = __builtin_amdgcn_perm(r1[1], r1[0], UPPER_HALVES);
+    fl[j] = __builtin_amdgcn_perm(r2[1], r2[0], UPPER_HALVES);
   }
 }
 
