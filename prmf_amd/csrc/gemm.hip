@@ -248,10 +248,6 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&ac
 #define PRMF_A_NT 1
 #endif
 constexpr bool NT_LOADS = PRMF_A_NT != 0;   // A is read exactly once: non-temporal loads keep it from displacing the factor in L2
-#ifndef PRMF_SLAB_NT
-#define PRMF_SLAB_NT 1
-#endif
-constexpr bool SLAB_NT = PRMF_SLAB_NT != 0; // slabs leave as full-line streaming writes (see the sweep's epilogue)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef PRMF_LOADS_FIRST
 #define PRMF_LOADS_FIRST 1
@@ -307,7 +303,7 @@ template <int MODE, int MT, int NT, int NW, bool BDB>
 __global__ void __launch_bounds__(64 * NW, PRMF_SWEEP_MINW)   // two workgroups per CU: at most 256 registers (arch + accumulator) per wave
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
              const uint4* __restrict__ Bp, int npanels, int g_begin, int ngroups /* work units (UNIT chunks each) [g_begin, g_begin+ngroups) of every row */,
-             int nx, int pmax, int seg_base, float* __restrict__ slabs, int64_t slab_stride,
+             int nx, int pmax, int seg_base, float* __restrict__ slabs, int64_t slab_stride, int slab_nt,
              unsigned long long* __restrict__ stamps /* debug, may be null */, const SweepPrologue pro) {
   if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x] = wall_clock64();
   constexpr int NTHR = 64 * NW;
@@ -485,7 +481,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
           v += w;
         }
         f32x4* dst = out + ((tile * NT + t) * 4 + q4) * 64 + lane;
-        if constexpr (SLAB_NT) __builtin_nontemporal_store(v, dst);
+        if (slab_nt) __builtin_nontemporal_store(v, dst);     // (uniform)
         else *dst = v;
       }
   }
@@ -592,6 +588,11 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
     if (p.nx > 1) p.nx = 1;
     else G = G > 16 ? G / 2 : 1;
   }
+  // Slabs leave as non-temporal full-line stores (see the sweep's epilogue) -- except when a launch writes only a few
+  // MB of them (5000 x 10000, k = 16: 9 MB): plain stores are then 2% faster on the iteration; from 34 MB up (k = 64 at
+  // any row count: (workgroups + panels) x 64 KiB) non-temporal is equal or up to 2% faster
+  // (profiles/r02_ab_slab_stores.txt).
+  p.slab_nt = (int64_t)(p.grid + p.panels) * p.panel_rows * 32 * NT * 4 > (int64_t)16 << 20;
   return p;
 }
 
@@ -603,7 +604,7 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
 #define PRMF_LAUNCH(NTV)                                                                                       \
   sweep_kernel<MODE, MTV, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), 0, s>>>(                                  \
       (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, 0, p.ngroups, p.nx, p.pmax, 0, slabs, slab_stride, \
-      g_sweep_stamps, pro)
+      p.slab_nt ? 1 : 0, g_sweep_stamps, pro)
   if constexpr (BDB) {
     switch (NT) {
       case 1: PRMF_LAUNCH(1); break;

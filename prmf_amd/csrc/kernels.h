@@ -97,6 +97,7 @@ struct GemmPlan {
   int nx = 1;               // slices of the reduction range (8 = one per XCD)
   int pmax = 1;             // most workgroups that touch one (panel, slice)
   int max_seg = 1;          // slabs allocated: nx * pmax
+  bool slab_nt = true;      // partial slabs leave as non-temporal stores (false: plain stores, small slab volumes)
   std::vector<segmask_t> segmask;  // [panels] bit s set <=> slab s holds a segment of this panel
 };
 // Test hooks, read from the environment ONCE per prmf_create (capi.hip) -- the planner itself takes no knobs.
