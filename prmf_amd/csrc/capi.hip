@@ -81,7 +81,7 @@ struct prmf_ctx {
   int vblocks = 0;
   int wpt_u = 1, wpt_v = 1;           // waves per tile in the fused epilogues (cooperative slab sum)
   bool fused_u = false, fused_v = false, gram_v_done = false;
-  // fused_u / fused_v: MFMA epilogues (k % 4 == 0; the V one when there is one column block: single rank or replicated mode)
+  // fused_u / fused_v: MFMA epilogues (the V one when there is one column block: single rank or replicated mode)
   bool graph_done = false;            // the pathway terms of this iteration were already computed in phase_u (merged launch)
 
   // Deferred objective + sweep prologues (single rank, fused epilogues, tradeoff off; `lazy` is decided per batch in
@@ -403,7 +403,7 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, &c->Gv, (size_t)k * k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->active_dev, (size_t)k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->pos, (size_t)n * c->kc, false))) return bail(rc);
-  c->fused_u = (k % 4 == 0);
+  c->fused_u = true;                    // any k since the A-layout loads have an element form (was: k % 4 == 0)
   c->fused_v = c->fused_u && c->lr == 1;
   c->wpt_u = epilogue_wpt(c->Kpad_xt, c->plan_xv.max_seg, c->NT);
   c->wpt_v = epilogue_wpt(c->Kpad_x, c->plan_xtu.max_seg, c->NT);

@@ -137,7 +137,7 @@ hipError_t launch_transpose_pad(int x_dtype, const void* src, int64_t ld_src, in
 // U <- U * (P / (U Gv + U)), P = sum of `splits` slabs     (prmf_runner.py:420-422)
 hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const segmask_t* segmask, int panel_rows,
                            int64_t slab_stride, int KP, const double* Gv, hipStream_t s);
-// fused U epilogue (k % 4 == 0): slab sum + U (V^T V) on the f32 MFMA + update + fragment packing
+// fused U epilogue (any k; k % 4 == 0 takes float4 loads of the factor rows): slab sum + U (V^T V) on the f32 MFMA + update + fragment packing
 // (*gram_done: the kernel also wrote epilogue_blocks(Kpad) per-workgroup partials of F_new^T F_new)
 int epilogue_wpt(int64_t rows, int max_seg, int NT);   // waves sharing a tile's slab sum (1, 2, 4)
 int epilogue_blocks(int64_t rows, int wpt = 1);

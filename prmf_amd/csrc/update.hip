@@ -212,7 +212,7 @@ hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStrea
 }
 
 // ---------------------------------------------------------------------------
-// Fused epilogues (k % 4 == 0): one pass per factor after its sweep.
+// Fused epilogues (any k): one pass per factor after its sweep.
 //
 //   den = F * G  on the f32 MFMA.  A operand = F in "A layout": lane (r,h) holds
 //   F[row0 + r][(KP/2) h + j], j = 0..KP/2-1 (contiguous float4 loads); MFMA step s
@@ -236,9 +236,9 @@ __device__ __forceinline__ float bf16_trunc_back(float a) {
 }
 
 // un[t][16]: a 32-row tile in C/D layout -> packed fragments of rows [row0, row0+32)
-template <int NT, bool BF16>
+template <int NT>
 __device__ __forceinline__ void pack_tile_from_cd(const float (&un)[NT][16], int64_t row0, int lane, void* packed) {
-  if constexpr (BF16) {
+  {
     uint4* out = reinterpret_cast<uint4*>(packed);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -263,29 +263,35 @@ __device__ __forceinline__ void pack_tile_from_cd(const float (&un)[NT][16], int
         out[blk * 64 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         out[(blk + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
       }
-  } else {
-    float4* out = reinterpret_cast<float4*>(packed);
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        out[((row0 / 8 + g) * NT + t) * 64 + lane] = make_float4(un[t][4 * g], un[t][4 * g + 1], un[t][4 * g + 2], un[t][4 * g + 3]);
   }
 }
 
-// A-layout load of one 32-row tile of F (lane (r,h): F[row0+r][(KP/2)h .. +KP/2), zero outside)
-template <int NT>
+// A-layout load of one 32-row tile of F (lane (r,h): F[row0+r][(KP/2)h .. +KP/2), zero outside).
+// VEC4: k % 4 == 0, the rows of F are 16-B aligned -> one float4 per 4 columns; else (any k -- the CLI's default is 6)
+// element loads with clamped addresses.  A template parameter, not a branch: both forms in one kernel cost the
+// k <= 64 epilogues their last free registers (256 + 200 B of scratch against 247).
+template <int NT, bool VEC4>
 __device__ __forceinline__ void load_tile_a_layout(const float* __restrict__ F, int64_t rows, int k, int64_t row0, int lane,
                                                    float (&ua)[16 * NT]) {
   constexpr int HALF = 16 * NT;
   const int r = lane & 31, h = lane >> 5;
   const int64_t row = row0 + r;
+  if constexpr (VEC4) {
 #pragma unroll
-  for (int q = 0; q < HALF / 4; ++q) {
-    const int col = HALF * h + 4 * q;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < rows && col < k) v = *reinterpret_cast<const float4*>(F + row * k + col);
-    ua[4 * q] = v.x; ua[4 * q + 1] = v.y; ua[4 * q + 2] = v.z; ua[4 * q + 3] = v.w;
+    for (int q = 0; q < HALF / 4; ++q) {
+      const int col = HALF * h + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < rows && col < k) v = *reinterpret_cast<const float4*>(F + row * k + col);
+      ua[4 * q] = v.x; ua[4 * q + 1] = v.y; ua[4 * q + 2] = v.z; ua[4 * q + 3] = v.w;
+    }
+  } else {
+    const float* Fr = F + (row < rows ? row : rows - 1) * k;
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) {
+      const int col = HALF * h + j;
+      const float v = Fr[col < k ? col : k - 1];
+      ua[j] = (row < rows && col < k) ? v : 0.f;
+    }
   }
 }
 
@@ -495,7 +501,7 @@ __device__ __forceinline__ void gram_total_store(const float (&gtot)[NT * (NT + 
 }
 
 // GRAM: also accumulate F_new^T F_new (per-workgroup partial [k*k] floats at gram_partial[blockIdx])
-template <int NT, bool BF16, bool GRAM>
+template <int NT, bool VEC4, bool GRAM>
 __global__ void __launch_bounds__(256, NT <= 2 ? 2 : 1)
 u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs, const segmask_t* __restrict__ segmask,
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gv, void* __restrict__ packed,
@@ -553,7 +559,7 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
       // issue every load of the tile first (slabs, A layout, C/D layout), then the MFMA chain
       float ua[16 * NT], uu[NT][16];
       if (wpt == 1) load_slab_tile<NT, NT == 1 ? 4 : PRMF_EPI_NB2>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, p);
-      load_tile_a_layout<NT>(U, m, k, row0, lane, ua);
+      load_tile_a_layout<NT, VEC4>(U, m, k, row0, lane, ua);
       float* const Ut = U + row0 * k;
       const int last = (int)((m - row0 < 32 ? m - row0 : 32) - 1);
       auto cd_off = [&](int t, int i) -> unsigned {
@@ -587,7 +593,7 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
     }
     EPI_DEP(un);
     EPI_STAMP(4);
-    if (lead) pack_tile_from_cd<NT, BF16>(un, row0, lane, packed);   // tiles past m are packed as zeros
+    if (lead) pack_tile_from_cd<NT>(un, row0, lane, packed);   // tiles past m are packed as zeros
     EPI_STAMP(5);
     if constexpr (GRAM) {
       f32x16 gt[NP];
@@ -666,7 +672,7 @@ struct EpiArgs {
   unsigned long long* stamps;   // debug (tools/epi_phases.py): 8 wall-clock stamps per workgroup, first round of wave 0
 };
 
-template <int NT, bool IS_V, bool BF16, bool DENSE>
+template <int NT, bool IS_V, bool VEC4, bool DENSE>
 __global__ void __launch_bounds__(256, 2)
 epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
   constexpr int KP = 32 * NT, HALF = KP / 2, NP = NT * (NT + 1) / 2;
@@ -761,7 +767,7 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
       // (2) den = F_tile (all k columns, A layout) x G[:, this column tile] on the f32 MFMA; the old values of this
       //     column tile (C/D layout) and, V side, the position map and the gathered pathway terms
       float ua[HALF];
-      load_tile_a_layout<NT>(a.F, a.rows, k, row0, lane, ua);
+      load_tile_a_layout<NT, VEC4>(a.F, a.rows, k, row0, lane, ua);
 #pragma unroll
       for (int i = 0; i < 16; ++i) fv[i] = Ft[cd_off(i)];
       if constexpr (IS_V) {
@@ -821,7 +827,7 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
     if (a.stamps) { float t_ = 0.f; for (int i = 0; i < 16; ++i) t_ += vn[i]; if (t_ == 1.2345e-33f) vn[2] = t_; EPI_STAMP(5); }
     // (4) this column tile's fragments of the packed factor (tiles past the end are packed as zeros)
     if (in_range) {
-      if constexpr (BF16) {
+      {
         uint4* out = reinterpret_cast<uint4*>(a.packed);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -842,11 +848,6 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
           out[blk * 64 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
           out[(blk + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         }
-      } else {
-        float4* out = reinterpret_cast<float4*>(a.packed);
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          out[((row0 / 8 + g) * NT + t) * 64 + lane] = make_float4(vn[4 * g], vn[4 * g + 1], vn[4 * g + 2], vn[4 * g + 3]);
       }
     }
     // (5) Gram blocks of the tile: exchange the column tiles through LDS; block p = (t1, t2 >= t1) belongs to wave p % NT
@@ -920,10 +921,12 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
 
 template <bool IS_V>
 static hipError_t launch_epilogue_cs(const EpiArgs& a_in, const GraphJob& gj, int NT, bool bf16, bool dense, int grid, hipStream_t s) {
+  if (!bf16) return hipErrorInvalidValue;      // the factors are always packed as hi/lo bf16 fragments
+  const bool vec4 = (a_in.k & 3) == 0;         // rows of F 16-B aligned
   EpiArgs a = a_in;
   a.stamps = g_epi_stamps;
 #define PRMF_CS(NTV)                                                                                     \
-  if (bf16) {                                                                                            \
+  if (vec4) {                                                                                            \
     if (dense) epilogue_cs_kernel<NTV, IS_V, true, IS_V><<<grid, 256, 0, s>>>(a, gj);                       \
     else epilogue_cs_kernel<NTV, IS_V, true, false><<<grid, 256, 0, s>>>(a, gj);                            \
   } else {                                                                                               \
@@ -951,6 +954,7 @@ hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, con
   const int NT = KP / 32;
   const int64_t ntiles = Kpad / 32;          // every tile of the packed buffer is (re)written, zero beyond m
   const GraphJob gj = graph ? *graph : GraphJob{};
+  if (x_dtype != 1) return hipErrorInvalidValue;   // fragment layout of the packed factor: hi/lo bf16 only
   if (NT >= PRMF_EPI_CS_MIN_NT) {
     EpiArgs a{};
     a.F = U; a.rows = m; a.k = k; a.slabs = slabs; a.segmask = segmask; a.panel_rows = panel_rows; a.slab_stride = slab_stride;
@@ -964,7 +968,7 @@ hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, con
   const int grid = nmain + (gj.ncols > 0 ? gj.ncols : 0);
   *gram_done = NT <= 2;
 #define PRMF_UEP(NTV, GR)                                                                                          \
-  if (x_dtype == 1) u_epilogue_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial, wpt, nmain, gj, g_epi_stamps); \
+  if ((k & 3) == 0) u_epilogue_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial, wpt, nmain, gj, g_epi_stamps); \
   else u_epilogue_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial, wpt, nmain, gj, g_epi_stamps)
   switch (NT) {
     case 1: PRMF_UEP(1, true); break;
@@ -982,7 +986,7 @@ hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, con
 // Single-rank V epilogue: V <- V * (Q + g_num) / max(V (U^T U) + g_den, eps), clamp
 // (prmf_runner.py:424-444), in place, + packing + per-wave partial column sums of
 // squares and <Q, V_new> (float64) + (GRAM) V_new^T V_new partials.
-template <int NT, bool BF16, bool GRAM, bool DENSE>
+template <int NT, bool VEC4, bool GRAM, bool DENSE>
 __global__ void __launch_bounds__(256, NT <= 2 ? 2 : 1)
 v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ slabs /* DENSE: Q [n][k] */, const segmask_t* __restrict__ segmask,
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gu, const int32_t* __restrict__ pos,
@@ -1049,7 +1053,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
         if (wpt == 1) load_slab_tile<NT, NT == 1 ? 4 : PRMF_EPI_NB2>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, q);
       }
       float ua[16 * NT];
-      load_tile_a_layout<NT>(V, n, k, row0, lane, ua);
+      load_tile_a_layout<NT, VEC4>(V, n, k, row0, lane, ua);
       f32x16 den[NT];
       tile_times_gram<NT>(ua, lane, Gs, den);
       // The element-wise update, one 32-column half at a time (register budget: q, den and the new tile stay live;
@@ -1094,7 +1098,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
         }
       }
     }
-    if (lead) pack_tile_from_cd<NT, BF16>(vn, row0, lane, packed);   // tiles past n are packed as zeros
+    if (lead) pack_tile_from_cd<NT>(vn, row0, lane, packed);   // tiles past n are packed as zeros
     if constexpr (GRAM) {
       f32x16 gt[NP];
 #pragma unroll
@@ -1127,6 +1131,7 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
                              hipStream_t s) {
   const int NT = KP / 32;
   const int64_t ntiles = Kpad / 32;
+  if (x_dtype != 1) return hipErrorInvalidValue;
   if (NT >= PRMF_EPI_CS_MIN_NT) {
     EpiArgs a{};
     a.F = V; a.rows = n; a.k = k; a.slabs = qdense ? qdense : slabs; a.segmask = segmask; a.panel_rows = panel_rows;
@@ -1143,10 +1148,10 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
   const int kwpt = qdense ? 1 : wpt;
   *gram_done = NT <= 2;
   const float* qsrc = qdense ? qdense : slabs;
-#define PRMF_VEP2(NTV, GR, BF, DN)                                                                                  \
-  v_epilogue_kernel<NTV, BF, GR, DN><<<grid, 256, 0, s>>>(V, n, k, qsrc, segmask, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial, vsup, kwpt)
+#define PRMF_VEP2(NTV, GR, V4, DN)                                                                                  \
+  v_epilogue_kernel<NTV, V4, GR, DN><<<grid, 256, 0, s>>>(V, n, k, qsrc, segmask, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial, vsup, kwpt)
 #define PRMF_VEP(NTV, GR)                                                                                           \
-  if (x_dtype == 1) { if (qdense) PRMF_VEP2(NTV, GR, true, true); else PRMF_VEP2(NTV, GR, true, false); }           \
+  if ((k & 3) == 0) { if (qdense) PRMF_VEP2(NTV, GR, true, true); else PRMF_VEP2(NTV, GR, true, false); }           \
   else { if (qdense) PRMF_VEP2(NTV, GR, false, true); else PRMF_VEP2(NTV, GR, false, false); }
   switch (NT) {
     case 1: PRMF_VEP(1, true); break;
@@ -1164,7 +1169,7 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
 
 // Multi-rank phase_post in one pass: the gathered per-rank column blocks -> row-major V (caller's buffer),
 // packed fragments for the next sweep, V^T V partials (GRAM).  Same tile machinery as the epilogues.
-template <int NT, bool BF16, bool GRAM>
+template <int NT, bool GRAM>
 __global__ void __launch_bounds__(256)
 v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ v_recv, int64_t blk_stride, int kc,
               void* __restrict__ packed, int64_t ntiles_pack, float* __restrict__ gram_partial,
@@ -1205,7 +1210,7 @@ v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__
     if constexpr (GRAM) {
       if (row0 < n) gram_accumulate<NT>(vn, g);
     }
-    pack_tile_from_cd<NT, BF16>(vn, row0, lane, packed);
+    pack_tile_from_cd<NT>(vn, row0, lane, packed);
   }
   if constexpr (GRAM) gram_block_store<NT>(g, k, gram_partial + (int64_t)blockIdx.x * k * k, red);
 }
@@ -1213,14 +1218,13 @@ v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__
 hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_t blk_stride, int kc, int KP, int x_dtype,
                          void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, hipStream_t s,
                          double* extras_keep, int nranks, int64_t extras_off) {
-  if (extras_keep && 3 * nranks > 256) return hipErrorInvalidValue;
+  if ((extras_keep && 3 * nranks > 256) || x_dtype != 1) return hipErrorInvalidValue;
   const int NT = KP / 32;
   const int64_t ntiles = Kpad / 32;
   const int grid = epilogue_blocks(Kpad);
   *gram_done = NT <= 2;
 #define PRMF_VPOST(NTV, GR)                                                                                      \
-  if (x_dtype == 1) v_post_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, extras_keep, nranks, extras_off); \
-  else v_post_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, extras_keep, nranks, extras_off)
+  v_post_kernel<NTV, GR><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, extras_keep, nranks, extras_off)
   switch (NT) {
     case 1: PRMF_VPOST(1, true); break;
     case 2: PRMF_VPOST(2, true); break;
