@@ -67,6 +67,7 @@ const char* prmf_last_error(const prmf_ctx* ctx);
  * pathway Laplacians) are sharded for the V-update: rank r owns columns
  * [r*kc, min(k,(r+1)*kc)), kc = ceil(k/nranks) -- see prmf_comm_sizes.
  * Replaces: the shapes implied by X/U/V at prmf_runner.py:417-418.
+ * Limits: 1 <= k <= 128 (PRMF_ERR_UNSUPPORTED above); x_dtype PRMF_X_F32 or PRMF_X_BF16.
  */
 int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k,
                 int x_dtype, int nranks, int rank, unsigned flags);
