@@ -626,8 +626,19 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
                        const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s, bool split,
                        const SweepPrologue* prologue) {
   const int64_t lda16 = lda * elem_bytes(x_dtype) / 16;
-  const SweepPrologue pro = prologue ? *prologue : SweepPrologue{};
+  SweepPrologue pro = prologue ? *prologue : SweepPrologue{};
   if (pro.kind != PROLOGUE_NONE && (p.nw != 4 || pro.nparts > GRAM_MAX_PARTS)) return hipErrorInvalidValue;
+  if (pro.kind != PROLOGUE_NONE) {
+    // The prologue's jobs (k^2 / 8 Gram entries + k + 1 column sums) are dealt over the sweep's workgroups.  A small
+    // matrix launches few of them (one for 100 x 2000): at k = 64 its 512 jobs then ran one after the other -- 0.79 ms
+    // in front of a 10 us sweep (tools/shape_scan.py).  More than 4 jobs per workgroup: a launch of their own.
+    const int jobs = gram_reduce_jobs(pro.k * pro.k) + (pro.kind == PROLOGUE_POST ? pro.k + 1 : pro.ncols);
+    if (jobs > 4 * p.grid) {
+      const hipError_t e = launch_prologue_alone(pro, s);
+      if (e != hipSuccess) return e;
+      pro = SweepPrologue{};
+    }
+  }
   // arithmetic: 1 = bf16 X x hi/lo bf16 factor; 2 = f32 X split into three bf16 pieces (every k)
   const int mode = x_dtype == 1 ? 1 : 2;
   if (x_dtype != 1 && !split) return hipErrorInvalidValue;
