@@ -1,12 +1,13 @@
-"""Iteration / sweep times across shapes (m samples x n genes) for two (k, storage) pairs: looks for planner cliffs.
-    python tools/shape_scan.py"""
+"""Iteration / sweep times across shapes (m samples x n genes) for (k, storage) pairs: looks for planner cliffs.
+    [PAIRS=64:bf16,6:f32] python tools/shape_scan.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from prmf_amd import PathwayLibrary, synthetic as syn
 from prmf_amd.solver import PrmfEngine
 dev, P = "cuda:0", 50
-for k, xd in ((64, "bf16"), (6, "f32")):
+PAIRS = [(int(a.split(":")[0]), a.split(":")[1]) for a in os.environ.get("PAIRS", "64:bf16,6:f32").split(",")]
+for k, xd in PAIRS:
     for n in (2000, 20000, 60000):
         lib = PathwayLibrary.from_edge_lists(n, syn.tree_pathways(n, P, 300, 0))
         for m in (100, 500, 2000, 8000, 30000, 100000):
