@@ -118,11 +118,16 @@ struct GraphJob {
   PathwayLibDev lib{};
   const int32_t* active = nullptr;
   int col0 = 0, ncols = 0;
+  int nsplit = 1;           // workgroups per column (large supports): the launch adds ncols * nsplit workgroups
   const float* V = nullptr;
   const double* hyper = nullptr;
   float* gnum = nullptr;
   float* gden = nullptr;
 };
+static inline int graph_job_split(int max_support) {      // one workgroup per 1024 support rows, at most 16
+  const int s = (max_support + 1023) / 1024;
+  return s < 1 ? 1 : (s > 16 ? 16 : s);
+}
 // the same prologue work as a stand-alone launch (end of a batch: no sweep follows)
 hipError_t launch_prologue_alone(const SweepPrologue& p, hipStream_t s);
 hipError_t launch_copy_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols,

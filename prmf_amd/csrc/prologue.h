@@ -77,10 +77,14 @@ __device__ __forceinline__ void gram_reduce_job(const float* __restrict__ partia
 // The column's support values are gathered once into LDS (`vs`), the CSR rows (support-local
 // column indices) then read LDS only.
 // ---------------------------------------------------------------------------
+// `part` of `nsplit`: a large pathway (thousands of support genes) is shared by several workgroups -- each gathers the
+// whole support into its LDS and walks every nsplit-th block of 256 rows (one workgroup per column walked 39 dependent
+// rows per thread at |S| = 10000: +0.25 ms per iteration).
 template <bool USE_LDS>
 __device__ __forceinline__ void graph_terms_body(const PathwayLibDev& lib, const int32_t* __restrict__ active, int col0, int c,
                                                  const float* __restrict__ V, int k, const double* __restrict__ hyper,
-                                                 float* __restrict__ gnum, float* __restrict__ gden, float* vs) {
+                                                 float* __restrict__ gnum, float* __restrict__ gden, float* vs,
+                                                 int part = 0, int nsplit = 1) {
   const int kk = col0 + c;
   const int p = active[kk];
   const int64_t s0 = lib.sup_ptr[p];
@@ -90,7 +94,7 @@ __device__ __forceinline__ void graph_terms_body(const PathwayLibDev& lib, const
     for (int s = threadIdx.x; s < ns; s += 256) vs[s] = V[(int64_t)lib.sup_idx[s0 + s] * k + kk];
     __syncthreads();
   }
-  for (int s = threadIdx.x; s < ns; s += 256) {
+  for (int s = part * 256 + threadIdx.x; s < ns; s += 256 * nsplit) {
     const double v = USE_LDS ? (double)vs[s] : (double)V[(int64_t)lib.sup_idx[s0 + s] * k + kk];
     double wv = 0.0;
     for (int64_t e = lib.row_ptr[s0 + s]; e < lib.row_ptr[s0 + s + 1]; ++e) {

@@ -516,11 +516,11 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
 #define EPI_STAMP(j) do { if (stamps && threadIdx.x == 0 && first_round) stamps[8 * blockIdx.x + (j)] = wall_clock64(); } while (0)
 #define EPI_DEP(arr) do { if (stamps) { float t_ = 0.f; for (int t2_ = 0; t2_ < NT; ++t2_) for (int i_ = 0; i_ < 16; ++i_) t_ += arr[t2_][i_]; if (t_ == 1.2345e-33f) un[0][0] = t_; } } while (0)
   if ((int)blockIdx.x >= nblocks_main) {      // extra workgroups: the pathway terms of one latent column each (GraphJob)
-    const int c = (int)blockIdx.x - nblocks_main;
+    const int e = (int)blockIdx.x - nblocks_main, c = e / gj.nsplit, part = e % gj.nsplit;
     if ((size_t)gj.lib.max_support * sizeof(float) <= sizeof(Gs))
-      graph_terms_body<true>(gj.lib, gj.active, gj.col0, c, gj.V, k, gj.hyper, gj.gnum, gj.gden, Gs);
+      graph_terms_body<true>(gj.lib, gj.active, gj.col0, c, gj.V, k, gj.hyper, gj.gnum, gj.gden, Gs, part, gj.nsplit);
     else
-      graph_terms_body<false>(gj.lib, gj.active, gj.col0, c, gj.V, k, gj.hyper, gj.gnum, gj.gden, Gs);
+      graph_terms_body<false>(gj.lib, gj.active, gj.col0, c, gj.V, k, gj.hyper, gj.gnum, gj.gden, Gs, part, gj.nsplit);
     return;
   }
   EPI_STAMP(0);
@@ -684,11 +684,11 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
 #define EPI_STAMP(j) do { if (a.stamps && threadIdx.x == 0 && first_round) a.stamps[8 * blockIdx.x + (j)] = wall_clock64(); } while (0)
   bool first_round = true;
   if ((int)blockIdx.x >= a.nblocks_main) {                  // extra workgroups: pathway terms of one latent column each
-    const int c = (int)blockIdx.x - a.nblocks_main;
+    const int e = (int)blockIdx.x - a.nblocks_main, c = e / gj.nsplit, part = e % gj.nsplit;
     if ((size_t)gj.lib.max_support * sizeof(float) <= sizeof(Gs))
-      graph_terms_body<true>(gj.lib, gj.active, gj.col0, c, gj.V, k, gj.hyper, gj.gnum, gj.gden, Gs);
+      graph_terms_body<true>(gj.lib, gj.active, gj.col0, c, gj.V, k, gj.hyper, gj.gnum, gj.gden, Gs, part, gj.nsplit);
     else
-      graph_terms_body<false>(gj.lib, gj.active, gj.col0, c, gj.V, k, gj.hyper, gj.gnum, gj.gden, Gs);
+      graph_terms_body<false>(gj.lib, gj.active, gj.col0, c, gj.V, k, gj.hyper, gj.gnum, gj.gden, Gs, part, gj.nsplit);
     return;
   }
   EPI_STAMP(0);
@@ -961,11 +961,11 @@ hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, con
     a.G = Gv; a.packed = packed; a.ntiles_pack = ntiles; a.gram_partial = gram_partial;
     a.nblocks_main = epilogue_blocks(Kpad, NT);
     *gram_done = true;
-    return launch_epilogue_cs<false>(a, gj, NT, x_dtype == 1, false, a.nblocks_main + (gj.ncols > 0 ? gj.ncols : 0), s);
+    return launch_epilogue_cs<false>(a, gj, NT, x_dtype == 1, false, a.nblocks_main + (gj.ncols > 0 ? gj.ncols * gj.nsplit : 0), s);
   }
   if (NT > 2) wpt = 1;
   const int nmain = epilogue_blocks(Kpad, wpt);
-  const int grid = nmain + (gj.ncols > 0 ? gj.ncols : 0);
+  const int grid = nmain + (gj.ncols > 0 ? gj.ncols * gj.nsplit : 0);
   *gram_done = NT <= 2;
 #define PRMF_UEP(NTV, GR)                                                                                          \
   if ((k & 3) == 0) u_epilogue_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial, wpt, nmain, gj, g_epi_stamps); \
