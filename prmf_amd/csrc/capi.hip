@@ -80,8 +80,8 @@ struct prmf_ctx {
   double* vpartial = nullptr;         // [v_update_blocks][kc+1]
   int vblocks = 0;
   int wpt_u = 1, wpt_v = 1;           // waves per tile in the fused epilogues (cooperative slab sum)
-  bool fused_u = false, fused_v = false, gram_v_done = false;
-  // fused_u / fused_v: MFMA epilogues (the V one when there is one column block: single rank or replicated mode)
+  bool fused_v = false, gram_v_done = false;
+  // fused_v: the V epilogue straight from the sweep's slabs (one column block: single rank or replicated mode)
   bool graph_done = false;            // the pathway terms of this iteration were already computed in phase_u (merged launch)
 
   // Deferred objective + sweep prologues (single rank, fused epilogues, tradeoff off; `lazy` is decided per batch in
@@ -404,8 +404,7 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, &c->Gv, (size_t)k * k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->active_dev, (size_t)k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->pos, (size_t)n * c->kc, false))) return bail(rc);
-  c->fused_u = true;                    // any k since the A-layout loads have an element form (was: k % 4 == 0)
-  c->fused_v = c->fused_u && c->lr == 1;
+  c->fused_v = c->lr == 1;
   c->wpt_u = epilogue_wpt(c->Kpad_xt, c->plan_xv.max_seg, c->NT);
   c->wpt_v = epilogue_wpt(c->Kpad_x, c->plan_xtu.max_seg, c->NT);
   c->vblocks = c->fused_v ? v_epilogue_waves(n, c->wpt_v) : v_update_blocks(n);
@@ -683,13 +682,13 @@ int prmf_begin(prmf_ctx* c, float* dU, float* dV, double gamma, double delta, do
   // Multi-rank, replicated mode: the same deferral (every rank holds all of V and the all-reduced U^T U and X^T U), but the
   // U-side reduction stays a launch of its own right after the U epilogue so that the k x k all-reduce can run next to
   // the X^T U sweep.  Column-sharded mode keeps the eager sequence (its objective pieces travel with the all-gather).
-  c->lazy = (c->nranks == 1 ? !c->dist_driver : c->replicated) && c->m > 0 && c->fused_u && c->fused_v && !(tradeoff >= 0.0) &&
+  c->lazy = (c->nranks == 1 ? !c->dist_driver : c->replicated) && c->m > 0 && c->fused_v && !(tradeoff >= 0.0) &&
             c->plan_xv.nw == 4 && c->plan_xtu.nw == 4 && c->vsup_ring && !(c->flags & PRMF_FLAG_EAGER_OBJECTIVE);
   // Column-sharded mode: the update sequence stays as it is (its objective pieces travel with the all-gather), but the
   // record of an iteration is not needed before prmf_end unless the tradeoff feedback is on: V^T V is then reduced by
   // the next X V sweep's prologue and the records of the batch come from one launch at the end (2 launches fewer per
   // iteration).  Decided per rank; the collectives do not depend on it.
-  c->lazy_cs = c->nranks > 1 && !c->replicated && c->m > 0 && c->fused_u && c->NT <= 2 && !(tradeoff >= 0.0) &&
+  c->lazy_cs = c->nranks > 1 && !c->replicated && c->m > 0 && c->NT <= 2 && !(tradeoff >= 0.0) &&
                c->plan_xv.nw == 4 && c->extras_ring && !(c->flags & PRMF_FLAG_EAGER_OBJECTIVE);
   c->batch_open = true;
   return PRMF_OK;
@@ -741,7 +740,7 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
       HIP_TRY(c, hipStreamWaitEvent(s, c->ev_post, 0));
       c->post_pending = false;
     }
-    if (c->fused_u) {
+    {
       bool gram_done = false;
       // the pathway terms of the own columns (they depend on the old V and gamma/delta only) ride in the U epilogue
       // launch as extra workgroups; `mid` then only reduces (this rank's) U^T U
@@ -754,9 +753,6 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
                               c->active_dev, c->col0, 0, c->V, c->hyper, c->gnum, c->gden, s));
         return PRMF_OK;
       }
-    } else {
-      HIP_TRY(c, launch_u_update(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP, c->Gv, s));
-      HIP_TRY(c, launch_pack_factor(fu, c->pack_dtype, c->NT, c->Kpad_xt, c->Up, s));
     }
     HIP_TRY(c, launch_gram(fu, c->gram_partial, c->gram_buf, s));
   } else {
@@ -855,7 +851,7 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
   }
   FactorView fv{c->V, (int)c->n, c->k, c->k, 0};
   if (!c->fused_v) {
-    if (c->fused_u) {
+    {
       bool gram_done = false;
       HIP_TRY(c, launch_v_post(c->V, c->n, c->k, c->v_recv, c->v_send_floats, c->kc, c->KP, c->pack_dtype, c->Vp, c->Kpad_x,
                                (float*)c->gram_partial, &gram_done, s,
@@ -873,9 +869,6 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
         c->cursor++;
         return PRMF_OK;
       }
-    } else {
-      HIP_TRY(c, launch_assemble_v(c->v_recv, c->lr, c->v_send_floats, c->kc, c->n, c->k, c->V, s));
-      HIP_TRY(c, launch_pack_factor(fv, c->pack_dtype, c->NT, c->Kpad_x, c->Vp, s));
     }
   }
   if (c->fused_v && c->gram_v_done) {

@@ -139,9 +139,6 @@ hipError_t launch_transpose_pad(int x_dtype, const void* src, int64_t ld_src, in
 // update.hip
 // ---------------------------------------------------------------------------
 
-// U <- U * (P / (U Gv + U)), P = sum of `splits` slabs     (prmf_runner.py:420-422)
-hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const segmask_t* segmask, int panel_rows,
-                           int64_t slab_stride, int KP, const double* Gv, hipStream_t s);
 // fused U epilogue (any k; k % 4 == 0 takes float4 loads of the factor rows): slab sum + U (V^T V) on the f32 MFMA + update + fragment packing
 // (*gram_done: the kernel also wrote epilogue_blocks(Kpad) per-workgroup partials of F_new^T F_new)
 int epilogue_wpt(int64_t rows, int max_seg, int NT);   // waves sharing a tile's slab sum (1, 2, 4)
@@ -195,8 +192,6 @@ hipError_t launch_objective_terms(const PathwayLibDev& lib, const int32_t* activ
                                   double* colres /*[kc][2]*/, double* scratch /*[kc][max_support]*/,
                                   double* extras_out /*3 doubles in v_send tail*/, hipStream_t s);
 // V[n][k] row-major from the gathered blocks
-hipError_t launch_assemble_v(const float* v_recv, int nranks, int64_t blk_stride, int kc, int64_t n, int k,
-                             float* V, hipStream_t s);
 // objective record + tradeoff feedback
 hipError_t launch_finalize(const double* Gu, const double* Gv, int k, const float* v_recv, int nranks,
                            int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* hyper /*gamma,delta,tradeoff*/,

@@ -25,83 +25,6 @@ unsigned long long* g_epi_stamps = nullptr;   // debug: per-workgroup phase stam
 // float32 machine epsilon used as the clamp value (prmf_runner.py:23)
 #define PRMF_EPS 1.1920928955078125e-07f
 
-// Element (row, col) of a sweep slab (fragment order, see sweep_kernel's epilogue); NT = KP/32.
-__device__ __forceinline__ int64_t slab_index(int64_t row, int col, int NT) {
-  const int64_t tile = row >> 5;
-  const int rr = (int)(row & 31);
-  const int lane = (col & 31) + 32 * ((rr >> 2) & 1);
-  return ((((tile * NT + (col >> 5)) * 4 + (rr >> 3)) * 64 + lane) << 2) + (rr & 3);
-}
-
-// ---------------------------------------------------------------------------
-// U <- U * (X V) / (U (V^T V) + U), 0/0 := 1          (prmf_runner.py:420-422)
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-u_update_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs,
-                const segmask_t* __restrict__ segmask, int panel_rows, int64_t slab_stride, int KP,
-                const double* __restrict__ Gv) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int k4 = (k + 3) & ~3;
-  const int ncg = k4 >> 2;
-  const int RT = 256 / ncg;
-  float* Gs = smem;              // [k][k4]
-  float* Us = smem + k * k4;     // [RT][k4]
-  const int tid = threadIdx.x;
-  for (int i = tid; i < k * k4; i += 256) {
-    int q = i / k4, c = i - q * k4;
-    Gs[i] = c < k ? (float)Gv[q * k + c] : 0.f;
-  }
-  const int cg = tid % ncg, rt = tid / ncg;
-  const int64_t ntiles = (m + RT - 1) / RT;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    __syncthreads();
-    for (int i = tid; i < RT * k4; i += 256) {
-      int rr = i / k4, q = i - rr * k4;
-      int64_t row = tile * RT + rr;
-      Us[i] = (row < m && q < k) ? U[row * k + q] : 0.f;
-    }
-    __syncthreads();
-    const int64_t row = tile * RT + rt;
-    if (rt < RT && row < m) {
-      float den[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* urow = Us + rt * k4;
-      for (int q = 0; q < k; ++q) {
-        const float u = urow[q];
-        const float4 g = *reinterpret_cast<const float4*>(Gs + q * k4 + 4 * cg);
-        den[0] = fmaf(u, g.x, den[0]);
-        den[1] = fmaf(u, g.y, den[1]);
-        den[2] = fmaf(u, g.z, den[2]);
-        den[3] = fmaf(u, g.w, den[3]);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = 4 * cg + j;
-        if (col < k) {
-          float p = 0.f;
-          const int64_t si = slab_index(row, col, KP >> 5);
-          for (segmask_t mk = segmask[row / panel_rows]; mk; mk &= mk - 1)
-            p += slabs[(int64_t)(__ffsll((long long)mk) - 1) * slab_stride + si];
-          const float uu = urow[col];
-          const float d = den[j] + uu;
-          const float ratio = (d != 0.f) ? p / d : 1.f;
-          U[row * k + col] = uu * ratio;
-        }
-      }
-    }
-  }
-}
-
-hipError_t launch_u_update(float* U, int64_t m, int k, const float* slabs, const segmask_t* segmask, int panel_rows,
-                           int64_t slab_stride, int KP, const double* Gv, hipStream_t s) {
-  const int k4 = (k + 3) & ~3;
-  const int RT = 256 / (k4 >> 2);
-  size_t lds = (size_t)(k * k4 + RT * k4) * sizeof(float);
-  int64_t ntiles = (m + RT - 1) / RT;
-  int grid = (int)(ntiles < 2048 ? ntiles : 2048);
-  u_update_kernel<<<grid, 256, lds, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, KP, Gv);
-  return hipGetLastError();
-}
-
 // ---------------------------------------------------------------------------
 // Gram matrix F^T F on the f32 MFMA (v_mfma_f32_32x32x2_f32: exact f32 products).
 // A wave loads a 32-row tile in the MFMA C/D layout (lane (c,h), register i holds
@@ -1617,24 +1540,6 @@ hipError_t launch_objective_terms(const PathwayLibDev& lib, const int32_t* activ
 // ---------------------------------------------------------------------------
 // replicated V (row-major) from the gathered per-rank column blocks
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-assemble_v_kernel(const float* __restrict__ v_recv, int64_t blk_stride, int kc, int64_t n, int k, float* __restrict__ V) {
-  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n * k) return;
-  int64_t j = idx / k;
-  int kk = (int)(idx - j * k);
-  int r = kk / kc, c = kk - r * kc;
-  V[idx] = v_recv[(int64_t)r * blk_stride + j * kc + c];
-}
-
-hipError_t launch_assemble_v(const float* v_recv, int nranks, int64_t blk_stride, int kc, int64_t n, int k, float* V,
-                             hipStream_t s) {
-  (void)nranks;
-  int64_t total = n * k;
-  assemble_v_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(v_recv, blk_stride, kc, n, k, V);
-  return hipGetLastError();
-}
-
 // ---------------------------------------------------------------------------
 // objective record (:362-371) + tradeoff feedback (:542-548)
 //   recon^2 = ||X||^2 - 2 <X^T U, V> + <U^T U, V^T V>
