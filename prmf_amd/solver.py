@@ -517,7 +517,13 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
             obj_data = objs[-1]
             i += modulus
             if obj_data["obj"] < best["obj_data"]["obj"]:           # :747-750
-                best = {"U": U.clone(), "V": V.clone(), "obj_data": obj_data}
+                # best iterate (:747-750): two device-to-device copies into buffers allocated once (31 MB at
+                # 50000 x 20000, k = 64: ~10 us per improving round; the reference copies on the host)
+                if "U" not in best:
+                    best["U"], best["V"] = torch.empty_like(U), torch.empty_like(V)
+                best["U"].copy_(U)
+                best["V"].copy_(V)
+                best["obj_data"] = obj_data
             if candidates_remain:                                   # :754-770
                 if min(len(v) for v in l2p.values()) <= k_latent:
                     Vh = V.cpu().numpy().astype(np.float64)
