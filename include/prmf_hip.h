@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRMF_ABI_VERSION 1
+#define PRMF_ABI_VERSION 2
 
 typedef struct prmf_ctx prmf_ctx;
 
@@ -48,10 +48,27 @@ enum prmf_x_dtype {
 };
 
 /* objective record written per iteration: the keys of the reference's obj_data
- * dict (prmf_runner.py:363-371) in this order, + recon^2 for diagnostics */
-#define PRMF_OBJ_STRIDE 8
+ * dict (prmf_runner.py:363-371) in this order, + recon^2, + how recon was obtained.
+ *
+ * recon normally comes from the Gram identity ||X||^2 - 2<X^T U, V> + <U^T U, V^T V> (the sweeps' products are there
+ * anyway), which is exact to ~1e-7 ||X||^2 -- i.e. recon to ~1e-7 (||X|| / recon)^2 / 2.  The reference materialises
+ * X - U V^T (:337) and never cancels, so when the identity value drops below 2e-3 ||X||^2 (recon / ||X|| < 4.5%) the
+ * library evaluates sum (X - U V^T)^2 directly with one more sweep over X: for the LAST record of a prmf_step /
+ * prmf_end batch (the one the outer loop's convergence test reads, :772-774), and for every record when the tradeoff
+ * feedback is on (recon feeds gamma, :542-548) or PRMF_FLAG_DIRECT_RESIDUAL is set.  PRMF_OBJ_FLAGS says which:
+ *   PRMF_RECON_DIRECT     recon / obj / recon_sq of this record come from the direct residual
+ *                         (PRMF_OBJ_RECON_SQ_IDENTITY keeps the identity value)
+ *   PRMF_RECON_IMPRECISE  identity value below the threshold and NOT replaced (an earlier record of a batch, or a
+ *                         multi-rank step driven through the phase calls without prmf_comm_init): relative error of
+ *                         recon up to ~1e-7 (||X|| / recon)^2
+ *   PRMF_RECON_CLAMPED    the identity value was negative; recon was reported as 0 (never without this bit) */
+#define PRMF_OBJ_STRIDE 10
 enum { PRMF_OBJ_RECON = 0, PRMF_OBJ_MANIFOLD, PRMF_OBJ_IGNORE, PRMF_OBJ_FRO,
-       PRMF_OBJ_GAMMA, PRMF_OBJ_DELTA, PRMF_OBJ_OBJ, PRMF_OBJ_RECON_SQ };
+       PRMF_OBJ_GAMMA, PRMF_OBJ_DELTA, PRMF_OBJ_OBJ, PRMF_OBJ_RECON_SQ,
+       PRMF_OBJ_FLAGS /* PRMF_RECON_* bits as a double */, PRMF_OBJ_RECON_SQ_IDENTITY };
+#define PRMF_RECON_DIRECT 1
+#define PRMF_RECON_IMPRECISE 2
+#define PRMF_RECON_CLAMPED 4
 
 int prmf_abi_version(void);
 
@@ -251,6 +268,14 @@ int prmf_cv_error(prmf_ctx* ctx, const float* dV, double* err_out, void* stream)
 int prmf_quantile_transform(int device, double* dX, int64_t m, int64_t n, int64_t ld, const int64_t* fit_rows,
                             int64_t n_fit, int n_quantiles, void* stream);
 
+/*
+ * Direct reconstruction error of this rank's rows: *out_local = sum_ij (X_g - U_g V^T)_ij^2 over the stored X
+ * (float64 sum; X - U V^T formed on the bf16 MFMA with hi/lo-split factors, X exact), what the reference computes at
+ * prmf_runner.py:337 before the square root.  One sweep over X; needs prmf_set_x only.  dU (m_local x k), dV (n x k):
+ * float32 device buffers.  With nranks > 1 the caller sums *out_local over the ranks.  Synchronises `stream`.
+ */
+int prmf_residual_sq(prmf_ctx* ctx, const float* dU, const float* dV, double* out_local, void* stream);
+
 /* Introspection used by bench.py for the roofline block: launch geometry and
  * per-launch algorithmic bytes of the dominant kernel (the X / X^T sweep). */
 typedef struct prmf_sweep_info {
@@ -278,6 +303,9 @@ int prmf_get_sweep_info(const prmf_ctx* ctx, prmf_sweep_info* out);
  * the gathered per-rank sums (two launches fewer per iteration, bit-identical records); the flag restores the
  * per-iteration form there too. */
 #define PRMF_FLAG_EAGER_OBJECTIVE 0x4u
+/* Every record's recon from the direct residual (one extra sweep over X per iteration; implies the per-iteration
+ * objective): the reference's :337 for the whole trace, whatever the fit. */
+#define PRMF_FLAG_DIRECT_RESIDUAL 0x8u
 /* Switch the per-launch event timing on or off after creation (bench.py times its
  * throughput run without events and a second short run with them). */
 int prmf_set_timing(prmf_ctx* ctx, int enabled);

@@ -1,0 +1,43 @@
+/*
+ * prmf_hip_debug.h -- validation and measurement hooks exported by libprmf_hip.so next to the product ABI
+ * (include/prmf_hip.h).  Nothing on the product path calls them: the full-size parity tests read the sweeps' products
+ * through prmf_debug_slab_sum, the tools under tools/ use the rest.  Same conventions as prmf_hip.h (0 or a negative
+ * prmf_status, never throws).
+ */
+#ifndef PRMF_HIP_DEBUG_H
+#define PRMF_HIP_DEBUG_H
+
+#include "prmf_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Dense row-major copy of the product the last sweep left in its partial slabs: which = 0: P = X V [m_local][k]
+ * (valid between prmf_phase_u and prmf_phase_q), which = 1: Q = X^T U [n][k] (valid between prmf_phase_q and the next
+ * prmf_phase_u).  out_dev: float32 device buffer.  tests/test_gpu_fullsize.py compares both with a float64 restatement
+ * of prmf_runner.py:420 / :424. */
+int prmf_debug_slab_sum(prmf_ctx* ctx, int which, float* out_dev, void* stream);
+
+/* The three terms of the Gram identity behind record `it` of the last deferred-objective batch (single rank, after
+ * prmf_end): *cross = <X^T U, V>, gu / gv = U^T U / V^T V (k*k doubles each, host).  tests/test_gpu_recon.py measures
+ * each against float64.  PRMF_ERR_STATE if the last batch was not a deferred one. */
+int prmf_debug_recon_terms(prmf_ctx* ctx, int it, double* cross, double* gu, double* gv);
+
+/* Device buffer (uint64) receiving per-workgroup start / end wall-clock stamps (and, in a -DPRMF_PHASE_PROF=1 build,
+ * per-wave phase sums) of the next sweep launches; NULL switches it off.  tools/wg_spread.py, tools/sweep_phases.py */
+int prmf_debug_set_stamps(void* dev_buf);
+/* The same for the fused epilogues: 8 stamps per workgroup.  tools/epi_phases.py */
+int prmf_debug_set_epi_stamps(void* dev_buf);
+
+/* Advance the iteration cursor without prmf_phase_post, so that partial iterations can be timed.  tools/sweep_context.py */
+int prmf_debug_bump_cursor(prmf_ctx* ctx);
+
+/* Swap one device buffer between two contexts of identical geometry: 0 X, 1 X^T, 2 slabs, 3 packed V, 4 packed U.
+ * tools/placement_probe.py */
+int prmf_debug_swap(prmf_ctx* a, prmf_ctx* b, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRMF_HIP_DEBUG_H */

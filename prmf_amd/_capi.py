@@ -10,12 +10,15 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libprmf_hip.so")
 
-PRMF_ABI_VERSION = 1
+PRMF_ABI_VERSION = 2
 PRMF_X_F32, PRMF_X_BF16 = 0, 1
-PRMF_OBJ_STRIDE = 8
+PRMF_OBJ_STRIDE = 10
+PRMF_OBJ_FLAGS, PRMF_OBJ_RECON_SQ_IDENTITY = 8, 9
+PRMF_RECON_DIRECT, PRMF_RECON_IMPRECISE, PRMF_RECON_CLAMPED = 1, 2, 4
 PRMF_FLAG_TIMING = 0x1
 PRMF_FLAG_COLUMN_SHARDED = 0x2
 PRMF_FLAG_EAGER_OBJECTIVE = 0x4
+PRMF_FLAG_DIRECT_RESIDUAL = 0x8
 PRMF_DIST_COLUMN_SHARDED, PRMF_DIST_REPLICATED = 0, 1
 PRMF_COMM_ID_BYTES = 128
 OBJ_KEYS = ("recon", "manifold", "ignore", "fro", "gamma", "delta", "obj")
@@ -66,11 +69,22 @@ SIGNATURES = {
     "prmf_step_dist": (_i, [_vp, _vp, _vp, _i, _d, _d, _d, _vp, _vp, _vp]),
     "prmf_score_candidates": (_i, [_vp, _vp, _vp, _vp]),
     "prmf_cv_error": (_i, [_vp, _vp, _vp, _vp]),
+    "prmf_residual_sq": (_i, [_vp, _vp, _vp, C.POINTER(_d), _vp]),
     "prmf_quantile_transform": (_i, [_i, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int64, _i, _vp]),
     "prmf_get_sweep_info": (_i, [_vp, C.POINTER(SweepInfo)]),
     "prmf_set_timing": (_i, [_vp, _i]),
     "prmf_get_timing": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)]),
     "prmf_comm_info": (_i, [_vp, C.POINTER(CommInfo)]),
+}
+
+# validation / measurement hooks (include/prmf_hip_debug.h); not used by the product path
+DEBUG_SIGNATURES = {
+    "prmf_debug_slab_sum": (_i, [_vp, _i, _vp, _vp]),
+    "prmf_debug_recon_terms": (_i, [_vp, _i, C.POINTER(_d), _vp, _vp]),
+    "prmf_debug_set_stamps": (_i, [_vp]),
+    "prmf_debug_set_epi_stamps": (_i, [_vp]),
+    "prmf_debug_bump_cursor": (_i, [_vp]),
+    "prmf_debug_swap": (_i, [_vp, _vp, _i]),
 }
 
 _lib = None
@@ -112,8 +126,10 @@ def load(path=None):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    lib.prmf_debug_slab_sum.restype = _i           # validation hook, not part of the public header
-    lib.prmf_debug_slab_sum.argtypes = [_vp, _i, _vp, _vp]
+    for name, (res, args) in DEBUG_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
     if lib.prmf_abi_version() != PRMF_ABI_VERSION:
         raise PrmfLibraryError("ABI version mismatch: library %d, binding %d" %
                                (lib.prmf_abi_version(), PRMF_ABI_VERSION))

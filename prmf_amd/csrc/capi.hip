@@ -1,6 +1,7 @@
 // C-ABI of libprmf_hip.so (include/prmf_hip.h): context, HBM workspace and the
 // sequencing of one PRMF iteration into four device phases.
 #include "../../include/prmf_hip.h"
+#include "../../include/prmf_hip_debug.h"
 #include "kernels.h"
 
 #include <dlfcn.h>
@@ -20,6 +21,9 @@ using namespace prmf;
 namespace {
 thread_local char g_create_error[512] = "";
 constexpr int MAX_RECORDS = 256;   // objective records kept on the device between begin/end
+static_assert(PRMF_OBJ_STRIDE == REC_STRIDE && PRMF_OBJ_FLAGS == REC_FLAGS && PRMF_OBJ_RECON_SQ_IDENTITY == REC_RECON_SQ_IDENTITY &&
+              PRMF_RECON_DIRECT == REC_FLAG_DIRECT && PRMF_RECON_IMPRECISE == REC_FLAG_IMPRECISE && PRMF_RECON_CLAMPED == REC_FLAG_CLAMPED,
+              "record layout of the header and of the kernels");
 }
 
 struct prmf_ctx {
@@ -132,6 +136,12 @@ struct prmf_ctx {
 
   // RCCL (resolved at run time, see prmf_comm_init)
   ncclComm_t comm = nullptr;
+
+  // direct residual (residual.hip): device request flag, per-wave partials, the (all-reduced) sum
+  int n_cus = 256;
+  int* need_dev = nullptr;
+  double* resid_partial = nullptr;
+  double* resid_sq = nullptr;
 
   // scoring scratch
   double* colnorm = nullptr;
@@ -318,6 +328,45 @@ SweepPrologue mid_prologue(prmf_ctx* c, int it) {
   return p;
 }
 
+#define NCCL_TRY(ctx, expr)                                                                          \
+  do {                                                                                               \
+    ncclResult_t _r = (expr);                                                                        \
+    if (_r != ncclSuccess) return fail(ctx, PRMF_ERR_HIP, "%s: %s", #expr, rccl().GetErrorString(_r)); \
+  } while (0)
+
+// Can this context replace a record's identity-based recon by the direct residual?  One rank: always.  Several ranks:
+// the local sums have to be added up, which the library can only do itself (RCCL communicator, inside prmf_step_dist).
+bool direct_available(const prmf_ctx* c) { return c->nranks == 1 || (c->comm != nullptr && c->dist_driver); }
+bool direct_forced(const prmf_ctx* c) { return (c->flags & PRMF_FLAG_DIRECT_RESIDUAL) != 0; }
+
+// The launches behind a record whose kernel may have raised c->need_dev: sum (X - U V^T)^2 over this rank's rows (the
+// kernels return at once when the flag is clear), the sum over ranks, and the rewrite of the record.
+int direct_residual(prmf_ctx* c, double* record, bool feedback, hipStream_t s) {
+  int nparts = 0;
+  if (c->m > 0) {
+    HIP_TRY(c, launch_residual(c->x_dtype, c->X, c->ldx, c->m, c->n, c->k, c->U, c->V, c->n_cus, c->resid_partial, &nparts,
+                               c->need_dev, s));
+  }
+  if (c->nranks == 1) {
+    HIP_TRY(c, launch_residual_sum(c->resid_partial, nparts, c->need_dev, c->resid_sq, record, c->hyper, feedback, s));
+    return PRMF_OK;
+  }
+  HIP_TRY(c, launch_residual_sum(c->resid_partial, nparts, c->need_dev, c->resid_sq, nullptr, nullptr, false, s));
+  NCCL_TRY(c, rccl().AllReduce(c->resid_sq, c->resid_sq, 1, ncclFloat64, ncclSum, c->comm, s));
+  HIP_TRY(c, launch_record_fix(c->need_dev, c->resid_sq, record, c->hyper, feedback, s));
+  return PRMF_OK;
+}
+
+// per-iteration form: the record of iteration c->cursor, its direct residual if asked for, the tradeoff feedback
+int finalize_record(prmf_ctx* c, const double* loc_partial, int loc_nblocks, const double* loc_colres, hipStream_t s) {
+  double* record = c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE;
+  const bool direct = direct_available(c);
+  HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->lr, c->v_send_floats, c->extras_off, c->norm_x_sq, c->hyper,
+                             record, loc_partial, loc_nblocks, loc_colres, direct ? c->need_dev : nullptr, direct_forced(c), s));
+  if (direct) return direct_residual(c, record, true, s);
+  return PRMF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -371,6 +420,7 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { fail(c, PRMF_ERR_HIP, "hipGetDeviceProperties failed"); return bail(PRMF_ERR_HIP); }
   const int n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  c->n_cus = n_cus;
   SweepTuning tune;                                     // the library's only tuning hook, for the decomposition test
   if (const char* e = getenv("PRMF_SWEEP_XCD")) tune.force_slices = atoi(e);
   c->plan_xv = plan_gemm(x_dtype, m_local > 0 ? m_local : 1, c->Kpad_x, c->NT, n_cus, tune);
@@ -413,6 +463,9 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, &c->hyper, 4))) return bail(rc);
   if ((rc = dev_alloc(c, &c->records, (size_t)MAX_RECORDS * PRMF_OBJ_STRIDE))) return bail(rc);
   if ((rc = dev_alloc(c, &c->colnorm, (size_t)k))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->need_dev, 2))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->resid_partial, (size_t)4 * RESIDUAL_MAX_BLOCKS))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->resid_sq, 2))) return bail(rc);
   if (nranks > 1 && !c->replicated && 3 * nranks <= 256 &&
       (rc = dev_alloc(c, &c->extras_ring, (size_t)MAX_RECORDS * nranks * 3))) return bail(rc);
   {
@@ -479,6 +532,9 @@ int prmf_destroy(prmf_ctx* c) {
   dev_free(c->hyper);
   dev_free(c->records);
   dev_free(c->colnorm);
+  dev_free(c->need_dev);
+  dev_free(c->resid_partial);
+  dev_free(c->resid_sq);
   dev_free(c->Gu_keep);
   dev_free(c->Gv_keep);
   dev_free(c->colnorm2_ring);
@@ -683,13 +739,13 @@ int prmf_begin(prmf_ctx* c, float* dU, float* dV, double gamma, double delta, do
   // U-side reduction stays a launch of its own right after the U epilogue so that the k x k all-reduce can run next to
   // the X^T U sweep.  Column-sharded mode keeps the eager sequence (its objective pieces travel with the all-gather).
   c->lazy = (c->nranks == 1 ? !c->dist_driver : c->replicated) && c->m > 0 && c->fused_v && !(tradeoff >= 0.0) &&
-            c->plan_xv.nw == 4 && c->plan_xtu.nw == 4 && c->vsup_ring && !(c->flags & PRMF_FLAG_EAGER_OBJECTIVE);
+            c->plan_xv.nw == 4 && c->plan_xtu.nw == 4 && c->vsup_ring && !(c->flags & (PRMF_FLAG_EAGER_OBJECTIVE | PRMF_FLAG_DIRECT_RESIDUAL));
   // Column-sharded mode: the update sequence stays as it is (its objective pieces travel with the all-gather), but the
   // record of an iteration is not needed before prmf_end unless the tradeoff feedback is on: V^T V is then reduced by
   // the next X V sweep's prologue and the records of the batch come from one launch at the end (2 launches fewer per
   // iteration).  Decided per rank; the collectives do not depend on it.
   c->lazy_cs = c->nranks > 1 && !c->replicated && c->m > 0 && c->NT <= 2 && !(tradeoff >= 0.0) &&
-               c->plan_xv.nw == 4 && c->extras_ring && !(c->flags & PRMF_FLAG_EAGER_OBJECTIVE);
+               c->plan_xv.nw == 4 && c->extras_ring && !(c->flags & (PRMF_FLAG_EAGER_OBJECTIVE | PRMF_FLAG_DIRECT_RESIDUAL));
   c->batch_open = true;
   return PRMF_OK;
 }
@@ -864,8 +920,7 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
       }
       if (gram_done) {
         HIP_TRY(c, launch_gram_reduce((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x), c->k, c->Gv, s));
-        HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->lr, c->v_send_floats, c->extras_off,
-                                   c->norm_x_sq, c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, nullptr, 0, nullptr, s));
+        if ((rc = finalize_record(c, nullptr, 0, nullptr, s))) return rc;
         c->cursor++;
         return PRMF_OK;
       }
@@ -877,14 +932,12 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
     hipStream_t ps = s;
     HIP_TRY(c, launch_post((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x, c->wpt_v), c->k, c->Gv, c->lib, c->active_dev, c->V,
                            c->vpartial, c->vblocks, c->colres, c->obj_scratch, ps));
-    HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->lr, c->v_send_floats, c->extras_off, c->norm_x_sq,
-                               c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, c->vpartial, c->vblocks, c->colres, ps));
+    if ((rc = finalize_record(c, c->vpartial, c->vblocks, c->colres, ps))) return rc;
     c->cursor++;
     return PRMF_OK;
   }
   HIP_TRY(c, launch_gram(fv, c->gram_partial, c->Gv, s));
-  HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->lr, c->v_send_floats, c->extras_off,
-                             c->norm_x_sq, c->hyper, c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE, nullptr, 0, nullptr, s));
+  if ((rc = finalize_record(c, nullptr, 0, nullptr, s))) return rc;
   c->cursor++;
   return PRMF_OK;
 }
@@ -906,16 +959,21 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
     // the objective records of the whole batch (prmf_runner.py:336-372), two launches
     HIP_TRY(c, launch_objective_all(c->lib, c->active_dev, c->k, c->cursor, c->colnorm2_ring, c->vsup_ring, c->colres_ring,
                                     c->obj_scratch, s));
+    const bool direct = direct_available(c) && c->cursor > 0;
     HIP_TRY(c, launch_records_all(c->Gu_keep, c->Gv_keep, c->k, c->cursor, c->cross_ring, c->colres_ring, c->norm_x_sq, c->hyper,
-                                  c->records, s));
+                                  c->records, direct ? c->need_dev : nullptr, false, s));
+    // the last record of the batch is the one the outer loop acts on: direct residual if its identity value is too small
+    if (direct && (rc = direct_residual(c, c->records + (size_t)(c->cursor - 1) * PRMF_OBJ_STRIDE, false, s))) return rc;
   }
   if (c->lazy_cs) {
     if (c->gv_pending) {
       HIP_TRY(c, launch_prologue_alone(post_prologue(c, c->cursor - 1), s));
       c->gv_pending = false;
     }
+    const bool direct = direct_available(c) && c->cursor > 0;
     HIP_TRY(c, launch_finalize_batch(c->Gu_keep, c->Gv_keep, c->k, c->cursor, c->extras_ring, c->lr, c->norm_x_sq, c->hyper,
-                                     c->records, s));
+                                     c->records, direct ? c->need_dev : nullptr, false, s));
+    if (direct && (rc = direct_residual(c, c->records + (size_t)(c->cursor - 1) * PRMF_OBJ_STRIDE, false, s))) return rc;
   }
   c->batch_open = false;
   if (n_steps > 0)
@@ -1008,12 +1066,6 @@ int prmf_comm_init(prmf_ctx* c, const void* id_in) {
   }
   return PRMF_OK;
 }
-
-#define NCCL_TRY(ctx, expr)                                                                          \
-  do {                                                                                               \
-    ncclResult_t _r = (expr);                                                                        \
-    if (_r != ncclSuccess) return fail(ctx, PRMF_ERR_HIP, "%s: %s", #expr, rccl().GetErrorString(_r)); \
-  } while (0)
 
 int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma, double delta, double tradeoff,
                    double* obj_out, double* gamma_delta_out, void* stream) {
@@ -1162,11 +1214,8 @@ int prmf_cv_error(prmf_ctx* c, const float* dV, double* err_out, void* stream) {
   return PRMF_OK;
 }
 
-/* debug (not in the public header): dense row-major copy of the product the last sweep left in the slabs --
- * which = 0: P = X V [m][k] (valid between prmf_phase_u and prmf_phase_q), which = 1: Q = X^T U [n][k] (valid
- * between prmf_phase_q and the next prmf_phase_u).  The full-size parity tests compare both with a float64
- * restatement (tests/test_gpu_fullsize.py). */
-extern "C" int prmf_debug_slab_sum(prmf_ctx* c, int which, float* out_dev, void* stream) {
+/* validation / measurement hooks: include/prmf_hip_debug.h */
+int prmf_debug_slab_sum(prmf_ctx* c, int which, float* out_dev, void* stream) {
   if (!c || !out_dev || (which != 0 && which != 1)) return PRMF_ERR_ARG;
   if (!c->have_x) return fail(c, PRMF_ERR_STATE, "prmf_set_x has not been called");
   int rc;
@@ -1179,10 +1228,20 @@ extern "C" int prmf_debug_slab_sum(prmf_ctx* c, int which, float* out_dev, void*
   return PRMF_OK;
 }
 
-/* debug (not in the public header): device buffer of 2*grid uint64 start/end stamps of the next sweep launches */
-extern "C" int prmf_debug_set_stamps(void* dev_buf) { prmf::g_sweep_stamps = (unsigned long long*)dev_buf; return 0; }
-/* debug: 8 uint64 phase stamps per workgroup of the next column-split epilogue launches (tools/epi_phases.py) */
-extern "C" int prmf_debug_set_epi_stamps(void* dev_buf) { prmf::g_epi_stamps = (unsigned long long*)dev_buf; return 0; }
+int prmf_debug_set_stamps(void* dev_buf) { prmf::g_sweep_stamps = (unsigned long long*)dev_buf; return 0; }
+int prmf_debug_set_epi_stamps(void* dev_buf) { prmf::g_epi_stamps = (unsigned long long*)dev_buf; return 0; }
+
+int prmf_debug_recon_terms(prmf_ctx* c, int it, double* cross, double* gu, double* gv) {
+  if (!c || !cross || !gu || !gv || it < 0 || it >= c->cursor) return PRMF_ERR_ARG;
+  if (!c->lazy || c->batch_open) return fail(c, PRMF_ERR_STATE, "no finished deferred-objective batch");
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  const size_t kk2 = (size_t)c->k * c->k;
+  HIP_TRY(c, hipMemcpy(cross, c->cross_ring + it, sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(gu, c->Gu_keep + (size_t)it * kk2, kk2 * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(gv, c->Gv_keep + (size_t)it * kk2, kk2 * sizeof(double), hipMemcpyDeviceToHost));
+  return PRMF_OK;
+}
 
 int prmf_quantile_transform(int device, double* dX, int64_t m, int64_t n, int64_t ld, const int64_t* fit_rows,
                             int64_t n_fit, int n_quantiles, void* stream) {
@@ -1217,17 +1276,13 @@ int prmf_quantile_transform(int device, double* dX, int64_t m, int64_t n, int64_
   return PRMF_OK;
 }
 
-/* debug (not in the public header): advance the iteration cursor without running phase_post, so that partial
- * iterations can be timed (tools/sweep_context.py) */
-extern "C" int prmf_debug_bump_cursor(prmf_ctx* c) {
+int prmf_debug_bump_cursor(prmf_ctx* c) {
   if (!c || c->cursor + 1 >= MAX_RECORDS) return PRMF_ERR_ARG;
   c->cursor++;
   return PRMF_OK;
 }
 
-/* debug (not in the public header): swap one device buffer between two contexts of identical geometry
- * (tools/placement_probe.py): 0 X, 1 XT, 2 slabs, 3 Vp, 4 Up */
-extern "C" int prmf_debug_swap(prmf_ctx* a, prmf_ctx* b, int which) {
+int prmf_debug_swap(prmf_ctx* a, prmf_ctx* b, int which) {
   if (!a || !b || a->m != b->m || a->n != b->n || a->k != b->k || a->x_dtype != b->x_dtype) return PRMF_ERR_ARG;
   switch (which) {
     case 0: std::swap(a->X, b->X); break;
@@ -1237,6 +1292,22 @@ extern "C" int prmf_debug_swap(prmf_ctx* a, prmf_ctx* b, int which) {
     case 4: std::swap(a->Up, b->Up); break;
     default: return PRMF_ERR_ARG;
   }
+  return PRMF_OK;
+}
+
+int prmf_residual_sq(prmf_ctx* c, const float* dU, const float* dV, double* out_local, void* stream) {
+  if (!c || !dV || !out_local || (c->m > 0 && !dU)) return PRMF_ERR_ARG;
+  if (!c->have_x) return fail(c, PRMF_ERR_STATE, "prmf_set_x has not been called");
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  *out_local = 0.0;
+  if (c->m <= 0) return PRMF_OK;
+  int nparts = 0;
+  HIP_TRY(c, launch_residual(c->x_dtype, c->X, c->ldx, c->m, c->n, c->k, dU, dV, c->n_cus, c->resid_partial, &nparts, nullptr, s));
+  HIP_TRY(c, launch_residual_sum(c->resid_partial, nparts, nullptr, c->resid_sq + 1, nullptr, nullptr, false, s));
+  HIP_TRY(c, hipMemcpyAsync(out_local, c->resid_sq + 1, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
   return PRMF_OK;
 }
 

@@ -19,6 +19,16 @@ constexpr int K_PAD = 128;                 // reduction length padded to 128 ele
 constexpr int M_PAD = 512;                 // rows padded to the largest workgroup panel (8 waves x 64 rows)
 constexpr int MAX_KP = 128;                // latent columns padded to 32*NT, NT <= 4
 
+// Objective record on the device and across the ABI (include/prmf_hip.h: PRMF_OBJ_*): 10 doubles per iteration
+constexpr int REC_STRIDE = 10;
+constexpr int REC_FLAGS = 8;               // PRMF_RECON_* bits, stored as a double
+constexpr int REC_RECON_SQ_IDENTITY = 9;   // the Gram-identity value of recon^2, kept when the direct residual replaced it
+constexpr int REC_FLAG_DIRECT = 1, REC_FLAG_IMPRECISE = 2, REC_FLAG_CLAMPED = 4;
+// recon^2 from the Gram identity is exact to ~1e-7 ||X||^2 (float32 MFMA accumulation of its three terms): below this
+// fraction of ||X||^2 (recon / ||X|| < 4.5%) its relative error passes ~2.5e-5 and the direct residual takes over
+constexpr double RECON_DIRECT_THRESHOLD = 2e-3;
+constexpr int RESIDUAL_MAX_BLOCKS = 1024;
+
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 static inline int chunk_elems(int x_dtype) { return x_dtype == 1 ? 64 : 32; }   // bf16 : f32
 static inline int elem_bytes(int x_dtype) { return x_dtype == 1 ? 2 : 4; }
@@ -162,8 +172,10 @@ hipError_t launch_objective_all(const PathwayLibDev& lib, const int32_t* active_
                                 const float* vsup, double* colres, double* scratch /* [k][max_support], large supports only */,
                                 hipStream_t s);
 //   Gu_keep / Gv_keep [iters][k*k], cross [iters], colres -> records [iters][8]   (gamma, delta constant over the batch)
+//   `need` (nullable): raised by the LAST record of the batch, see launch_finalize
 hipError_t launch_records_all(const double* Gu_keep, const double* Gv_keep, int k, int iters, const double* cross,
-                              const double* colres, double norm_x_sq, const double* hyper, double* records, hipStream_t s);
+                              const double* colres, double norm_x_sq, const double* hyper, double* records, int* need, bool force,
+                              hipStream_t s);
 // partial Gram: per-wave partials -> partial[gram_blocks][k*k]; reduce -> G (double)
 int gram_blocks(int64_t rows);
 hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStream_t s);
@@ -193,10 +205,12 @@ hipError_t launch_objective_terms(const PathwayLibDev& lib, const int32_t* activ
                                   double* extras_out /*3 doubles in v_send tail*/, hipStream_t s);
 // V[n][k] row-major from the gathered blocks
 // objective record + tradeoff feedback
+// `need` (nullable): raised when this record's identity-based recon^2 is below RECON_DIRECT_THRESHOLD ||X||^2 (or `force`);
+// the tradeoff feedback is then left to record_fix (residual.hip), which runs on the direct value
 hipError_t launch_finalize(const double* Gu, const double* Gv, int k, const float* v_recv, int nranks,
                            int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* hyper /*gamma,delta,tradeoff*/,
-                           double* record /*8 doubles*/, const double* loc_partial, int loc_nblocks,
-                           const double* loc_colres, hipStream_t s);
+                           double* record /*REC_STRIDE doubles*/, const double* loc_partial, int loc_nblocks,
+                           const double* loc_colres, int* need, bool force, hipStream_t s);
 // merged small launches of the single-rank path
 hipError_t launch_mid(const float* gram_partial, int nparts, int k, double* Gu, const PathwayLibDev& lib,
                       const int32_t* active_dev, int col0, int ncols, const float* V, const double* hyper, float* gnum,
@@ -206,13 +220,25 @@ hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_
                          void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, hipStream_t s,
                          double* extras_keep = nullptr, int nranks = 0, int64_t extras_off = 0);
 hipError_t launch_finalize_batch(const double* Gu_keep, const double* Gv_keep, int k, int n_it, const double* extras_ring,
-                                 int nranks, double norm_x_sq, double* hyper, double* records, hipStream_t s);
+                                 int nranks, double norm_x_sq, double* hyper, double* records, int* need, bool force, hipStream_t s);
 hipError_t launch_post(const float* gram_partial, int nparts, int k, double* Gv, const PathwayLibDev& lib,
                        const int32_t* active_dev, const float* V, const double* partial, int nblocks, double* colres,
                        double* scratch, hipStream_t s);
 // candidate scores k x P
 hipError_t launch_score_candidates(const PathwayLibDev& lib, const float* V, int64_t n, int k,
                                    double* colnorm_scratch, double* scores, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// residual.hip: sum (X - U V^T)^2 directly (prmf_runner.py:337), one more sweep over the resident X
+// ---------------------------------------------------------------------------
+// per-wave float64 partials [*nparts_out] (<= 4 * RESIDUAL_MAX_BLOCKS); `need` (nullable device flag): run only if set
+hipError_t launch_residual(int x_dtype, const void* X, int64_t ldx, int64_t m, int64_t n, int k, const float* U, const float* V,
+                           int n_cus, double* partial, int* nparts_out, const int* need, hipStream_t s);
+// out[0] = sum of the partials (0 if `need` is clear); record != null: the record is rewritten from it in the same launch
+hipError_t launch_residual_sum(const double* partial, int nparts, const int* need, double* out, double* record, double* hyper,
+                               bool feedback, hipStream_t s);
+// recon / obj / recon_sq / flags of `record` from the (all-reduced) direct value; the tradeoff feedback if `feedback`
+hipError_t launch_record_fix(const int* need, const double* resid_sq, double* record, double* hyper, bool feedback, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // nnls.hip

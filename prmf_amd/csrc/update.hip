@@ -10,6 +10,7 @@
 //   normalize_laplacian :56-65   restrict scoring :115-127
 #include "kernels.h"
 #include "prologue.h"
+#include "bf16split.h"
 
 #ifndef PRMF_EPI_CS_MIN_NT
 #define PRMF_EPI_CS_MIN_NT 3   // column-split epilogue (one wave per 32-column tile) from this many column tiles (k > 64)
@@ -149,14 +150,6 @@ hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStrea
 //   order needs no data movement at all; the bf16 order (8 consecutive rows per
 //   lane) needs one v_permlane32_swap per register pair.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned pack_bf16_pair(float a, float b) {
-  unsigned short ha = __builtin_bit_cast(unsigned short, (__bf16)a), hb = __builtin_bit_cast(unsigned short, (__bf16)b);
-  return (unsigned)ha | ((unsigned)hb << 16);
-}
-__device__ __forceinline__ float bf16_trunc_back(float a) {
-  unsigned short ha = __builtin_bit_cast(unsigned short, (__bf16)a);
-  return __uint_as_float(((unsigned)ha) << 16);
-}
 
 // un[t][16]: a 32-row tile in C/D layout -> packed fragments of rows [row0, row0+32)
 template <int NT>
@@ -1550,13 +1543,14 @@ __global__ void __launch_bounds__(256)
 finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, int k, const float* __restrict__ v_recv,
                 int nranks, int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* __restrict__ hyper,
                 double* __restrict__ record, const double* __restrict__ loc_partial, int loc_nblocks,
-                const double* __restrict__ loc_colres, const double* __restrict__ extras_ring /* batch form, else null */) {
+                const double* __restrict__ loc_colres, const double* __restrict__ extras_ring /* batch form, else null */,
+                int* __restrict__ need /* nullable: direct-residual request (residual.hip) */, int force) {
   __shared__ double red[5][256];
   const int tid = threadIdx.x;
   if (extras_ring) {                   // batch form (column-sharded mode, records deferred): workgroup = iteration
     Gu += (size_t)blockIdx.x * k * k;
     Gv += (size_t)blockIdx.x * k * k;
-    record += (size_t)blockIdx.x * 8;        // PRMF_OBJ_STRIDE
+    record += (size_t)blockIdx.x * REC_STRIDE;
     extras_ring += (size_t)blockIdx.x * 3 * nranks;
   }
   // five sums, one tree reduction (fixed order: deterministic)
@@ -1603,7 +1597,15 @@ finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, in
     record[5] = delta;
     record[6] = recon + gamma * man + delta * ign + fro;
     record[7] = recon_sq;
-    if (t >= 0.0) {
+    // The identity's recon^2 is exact to ~1e-7 ||X||^2: below RECON_DIRECT_THRESHOLD ||X||^2 the record is marked, and
+    // the last record of a batch (every record in the per-iteration form) asks for the direct residual, which then
+    // replaces recon / obj and drives the tradeoff feedback.  A negative value is never clamped silently.
+    const bool low = recon_sq < RECON_DIRECT_THRESHOLD * norm_x_sq;
+    const bool ask = need && (low || force) && (!extras_ring || blockIdx.x == gridDim.x - 1);
+    record[REC_FLAGS] = (double)((low ? REC_FLAG_IMPRECISE : 0) | (recon_sq < 0.0 ? REC_FLAG_CLAMPED : 0));
+    record[REC_RECON_SQ_IDENTITY] = recon_sq;
+    if (need && (!extras_ring || blockIdx.x == gridDim.x - 1)) *need = ask ? 1 : 0;
+    if (t >= 0.0 && !ask) {
       const double denom = t * man;
       const double g2 = (denom == 0.0) ? 1.0 : ((1.0 - t) * recon) / denom;
       hyper[0] = g2;
@@ -1614,18 +1616,20 @@ finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, in
 
 hipError_t launch_finalize(const double* Gu, const double* Gv, int k, const float* v_recv, int nranks,
                            int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* hyper, double* record,
-                           const double* loc_partial, int loc_nblocks, const double* loc_colres, hipStream_t s) {
+                           const double* loc_partial, int loc_nblocks, const double* loc_colres, int* need, bool force,
+                           hipStream_t s) {
   finalize_kernel<<<1, 256, 0, s>>>(Gu, Gv, k, v_recv, nranks, blk_stride, extras_off, norm_x_sq, hyper, record,
-                                    loc_partial, loc_nblocks, loc_colres, nullptr);
+                                    loc_partial, loc_nblocks, loc_colres, nullptr, need, force ? 1 : 0);
   return hipGetLastError();
 }
 
 // the records of `n_it` iterations at once from the kept Grams and rank extras (column-sharded mode, tradeoff off)
 hipError_t launch_finalize_batch(const double* Gu_keep, const double* Gv_keep, int k, int n_it, const double* extras_ring,
-                                 int nranks, double norm_x_sq, double* hyper, double* records, hipStream_t s) {
+                                 int nranks, double norm_x_sq, double* hyper, double* records, int* need, bool force,
+                                 hipStream_t s) {
   if (n_it <= 0) return hipSuccess;
   finalize_kernel<<<n_it, 256, 0, s>>>(Gu_keep, Gv_keep, k, nullptr, nranks, 0, 0, norm_x_sq, hyper, records, nullptr, 0,
-                                       nullptr, extras_ring);
+                                       nullptr, extras_ring, need, force ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -1689,7 +1693,7 @@ hipError_t launch_objective_all(const PathwayLibDev& lib, const int32_t* active_
 __global__ void __launch_bounds__(256)
 records_all_kernel(const double* __restrict__ Gu_keep, const double* __restrict__ Gv_keep, int k, const double* __restrict__ cross,
                    const double* __restrict__ colres, double norm_x_sq, const double* __restrict__ hyper,
-                   double* __restrict__ records) {
+                   double* __restrict__ records, int* __restrict__ need, int force) {
   __shared__ double red[4][256];
   const int tid = threadIdx.x, it = blockIdx.x;
   const double* Gu = Gu_keep + (int64_t)it * k * k;
@@ -1717,7 +1721,7 @@ records_all_kernel(const double* __restrict__ Gu_keep, const double* __restrict_
     const double gamma = hyper[0], delta = hyper[1];
     const double recon_sq = norm_x_sq - 2.0 * cross[it] + gg;
     const double recon = sqrt(recon_sq > 0.0 ? recon_sq : 0.0);
-    double* record = records + (int64_t)it * 8;
+    double* record = records + (int64_t)it * REC_STRIDE;
     record[0] = recon;
     record[1] = man;
     record[2] = ign;
@@ -1726,13 +1730,18 @@ records_all_kernel(const double* __restrict__ Gu_keep, const double* __restrict_
     record[5] = delta;
     record[6] = recon + gamma * man + delta * ign + fro;
     record[7] = recon_sq;
+    const bool low = recon_sq < RECON_DIRECT_THRESHOLD * norm_x_sq;           // see finalize_kernel
+    record[REC_FLAGS] = (double)((low ? REC_FLAG_IMPRECISE : 0) | (recon_sq < 0.0 ? REC_FLAG_CLAMPED : 0));
+    record[REC_RECON_SQ_IDENTITY] = recon_sq;
+    if (need && it == (int)gridDim.x - 1) *need = (low || force) ? 1 : 0;     // the last record of the batch
   }
 }
 
 hipError_t launch_records_all(const double* Gu_keep, const double* Gv_keep, int k, int iters, const double* cross,
-                              const double* colres, double norm_x_sq, const double* hyper, double* records, hipStream_t s) {
+                              const double* colres, double norm_x_sq, const double* hyper, double* records, int* need, bool force,
+                              hipStream_t s) {
   if (iters <= 0) return hipSuccess;
-  records_all_kernel<<<iters, 256, 0, s>>>(Gu_keep, Gv_keep, k, cross, colres, norm_x_sq, hyper, records);
+  records_all_kernel<<<iters, 256, 0, s>>>(Gu_keep, Gv_keep, k, cross, colres, norm_x_sq, hyper, records, need, force ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -46,7 +46,7 @@ class PrmfEngine(object):
     sharded by latent columns: reduce-scatter + all-gather)."""
 
     def __init__(self, m_local, n, k, x_dtype="f32", device=None, nranks=1, rank=0, timing=False, dist_mode=None,
-                 eager_objective=False):
+                 eager_objective=False, direct_residual=False):
         self.torch = _torch()
         self.lib = _capi.load()
         torch = self.torch
@@ -64,6 +64,9 @@ class PrmfEngine(object):
             flags |= _capi.PRMF_FLAG_COLUMN_SHARDED
         if eager_objective:       # per-iteration objective launches instead of the deferred evaluation (prmf_hip.h)
             flags |= _capi.PRMF_FLAG_EAGER_OBJECTIVE
+        if direct_residual:       # recon of EVERY record from the materialised-residual form of prmf_runner.py:337
+            flags |= _capi.PRMF_FLAG_DIRECT_RESIDUAL
+        self.last_flags = []      # PRMF_RECON_* bits of the records the last step / end call returned
         rc = self.lib.prmf_create(C.byref(self.ctx), self.device, self.m, self.n, self.k, self.x_dtype,
                                   self.nranks, self.rank, flags)
         if rc != _capi.PRMF_OK:
@@ -195,9 +198,19 @@ class PrmfEngine(object):
         self._check(rc)
         return self.records_to_dicts(obj[:n_steps]), (float(gd[0]), float(gd[1]))
 
-    @staticmethod
-    def records_to_dicts(obj):
+    def records_to_dicts(self, obj):
+        """Records -> the reference's obj_data dicts (prmf_runner.py:363-371: exactly its seven keys -- the CLI writes
+        every key to obj.txt); how each recon was obtained (include/prmf_hip.h PRMF_RECON_*) goes to `last_flags`."""
+        self.last_flags = [int(row[_capi.PRMF_OBJ_FLAGS]) for row in obj]
         return [{key: float(row[j]) for j, key in enumerate(_capi.OBJ_KEYS)} for row in obj]
+
+    def residual_sq(self, U, V):
+        """sum (X_g - U_g V^T)^2 over this rank's rows, evaluated directly (prmf_runner.py:337 before the root)."""
+        self._check_factors(U, V)
+        out = C.c_double()
+        self._check(self.lib.prmf_residual_sq(self.ctx, C.c_void_p(U.data_ptr()), C.c_void_p(V.data_ptr()), C.byref(out),
+                                              self._stream()))
+        return out.value
 
     # -- phase interface (multi-rank; driven by prmf_amd.distributed) -------------
     def comm_buffers(self):

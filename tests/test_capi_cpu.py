@@ -10,8 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    txt = open(os.path.join(ROOT, "include", "prmf_hip.h")).read()
+def header_functions(name="prmf_hip.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(prmf_[a-z_]+)\s*\(", txt)))
 
@@ -26,6 +26,15 @@ def test_header_binding_and_library_export_the_same_symbols():
     for n in names:
         assert hasattr(lib, n), n
     assert lib.prmf_abi_version() == _capi.PRMF_ABI_VERSION
+    # the validation hooks have a header of their own; together the two headers name EVERY prmf_* export of the library
+    dbg = header_functions("prmf_hip_debug.h")
+    assert dbg and sorted(_capi.DEBUG_SIGNATURES) == dbg
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r"\b(prmf_[a-z_]+)$", nm, flags=re.M)))
+    assert exported == sorted(names + dbg), set(exported) ^ set(names + dbg)
+    txt = open(os.path.join(ROOT, "include", "prmf_hip.h")).read()
+    assert "#define PRMF_OBJ_STRIDE %d" % _capi.PRMF_OBJ_STRIDE in txt and "#define PRMF_ABI_VERSION %d" % _capi.PRMF_ABI_VERSION in txt
 
 
 def test_error_paths_without_compute():

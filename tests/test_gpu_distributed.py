@@ -216,3 +216,90 @@ def test_in_library_step_two_ranks_through_mock_rccl(k, mode, tmp_path):
         for key in ("recon", "manifold", "ignore", "fro", "obj"):
             assert abs(a[key] - b[key]) <= 1e-4 * max(abs(b[key]), 1e-12), key
 
+
+
+def _share_worker(rank, world, port, workload, mode, mock, steps, outdir, q):
+    """One rank of a `world`-rank run of BASELINE.json's `workload` (rows sharded as bench.py --gpus N shards them),
+    in-library step through the RCCL test double; world == 1: the single-rank prmf_step on the whole matrix."""
+    import math
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PRMF_RCCL_LIB"] = mock
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from prmf_amd import PathwayLibrary, synthetic as syn
+        from prmf_amd.distributed import DistributedPrmf
+        from prmf_amd.solver import PrmfEngine
+        m, n, k, P, x_dtype = syn.CONFIGS[workload]
+        dev = "cuda:0"
+        lo, hi = syn.shard_rows(m, world, rank)
+        Xd = syn.x_rows_torch(torch, dev, 41, n, k, lo, hi, torch.bfloat16 if x_dtype == "bf16" else torch.float32)
+        eng = PrmfEngine(hi - lo, n, k, x_dtype=x_dtype, device=0, nranks=world, rank=rank,
+                         dist_mode=mode if world > 1 else None)
+        nsq = torch.tensor([eng.local_norm_sq(Xd)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(nsq)
+        eng.set_x(Xd, norm_x_sq=float(nsq.item()))
+        del Xd
+        eng.set_library(PathwayLibrary.from_edge_lists(n, syn.tree_pathways(n, P, 300, 41)))
+        eng.set_active([kk % P for kk in range(k)])
+        normx = math.sqrt(float(nsq.item()))
+        U = syn.init_factor_torch(torch, dev, 42, m, k, lo, hi)
+        V = syn.init_factor_torch(torch, dev, 43, n, k)
+        if world > 1:
+            runner = DistributedPrmf(eng, native=True)
+            assert runner.native and eng.comm_info()["comm_nranks"] == world
+            objs, _ = runner.step(U, V, steps, normx / k, 10.0 / normx)
+        else:
+            objs, _ = eng.step(U, V, steps, normx / k, 10.0 / normx)
+        tag = "w%d_r%d" % (world, rank)
+        np.save(os.path.join(outdir, "U_%s.npy" % tag), U.cpu().numpy())
+        np.save(os.path.join(outdir, "V_%s.npy" % tag), V.cpu().numpy())
+        q.put((rank, objs))
+        eng.close()
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("workload,mode", [("c3", "colshard"), ("c3", "replicated"), ("c5shard", "colshard")])
+def test_in_library_step_two_ranks_at_real_share_shapes(workload, mode, tmp_path):
+    """prmf_step_dist with two ranks (RCCL test double) at the shapes a multi-GPU run actually hands a rank: C3 on two
+    ranks (25000 x 20000 per rank, k = 64, P = 300: 4 x 64 KiB-row sweeps, two-slice plans, 5 MB exchanges) and a
+    25000 x 25000, k = 128, P = 1000 problem on two ranks (12500 x 25000 per rank: the column-split epilogues, 12.8 MB
+    exchanges) -- against the single-rank prmf_step on the whole matrix.  The two decompositions sum in different
+    orders (float32), so the bar is 1e-5 on U, V and every objective component after 3 iterations; the replicated
+    state of the two ranks must agree bit for bit."""
+    import subprocess
+    import torch.multiprocessing as mp
+    from measure import rel, relmax, report
+    mock = str(tmp_path / "libmock_rccl.so")
+    cc = subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                         os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "mock_rccl.cpp"), "-o", mock,
+                         "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    ctx = mp.get_context("spawn")
+    steps = 3
+    out = {}
+    for world in (1, 2):
+        q = ctx.SimpleQueue()
+        port = _free_port()
+        procs = [ctx.Process(target=_share_worker, args=(r, world, port, workload, mode, mock, steps, str(tmp_path), q))
+                 for r in range(world)]
+        for p in procs:
+            p.start()
+        out[world] = _collect(procs, q, deadline_s=600)
+    ld = lambda name: np.load(str(tmp_path / name))
+    V0, V1 = ld("V_w2_r0.npy"), ld("V_w2_r1.npy")
+    assert np.array_equal(V0, V1) and out[2][0][0] == out[2][1][0]
+    U2 = np.concatenate([ld("U_w2_r0.npy"), ld("U_w2_r1.npy")])
+    eu, ev = rel(U2, ld("U_w1_r0.npy")), rel(V0, ld("V_w1_r0.npy"))
+    eo = {key: relmax([o[key] for o in out[2][0][0]], [o[key] for o in out[1][0][0]])
+          for key in ("recon", "manifold", "ignore", "fro", "obj")}
+    report("two_ranks_real_share[%s-%s]" % (workload, mode), steps=steps, rel_U=eu, rel_V=ev, **{"rel_" + k_: v for k_, v in eo.items()})
+    assert eu < 1e-5 and ev < 1e-5
+    for key, v in eo.items():
+        assert v < 1e-5, (key, v)

@@ -66,43 +66,37 @@ def test_c2_full_size_vs_oracle():
 
 
 def _fp64_iteration(torch, Xd, U, V, pathways, active, gamma, delta):
-    """One iteration of oracle.update_step in float64 on the GPU (torch), from float32 U, V and the stored X.
-    Returns P = X V, U_new, Q = X^T U_new, V_new (float64 tensors)."""
-    m, n = Xd.shape
-    k = V.shape[1]
-    U64, V64 = U.double(), V.double()
-    chunk = 4096
-    P = torch.empty((m, k), dtype=torch.float64, device=Xd.device)
-    for r0 in range(0, m, chunk):
-        P[r0:r0 + chunk] = Xd[r0:r0 + chunk].double() @ V64                    # :420
-    den = U64 @ (V64.T @ V64) + U64                                            # :421
-    U_new = U64 * torch.where(den != 0, P / den, torch.ones_like(den))         # :422
-    Q = torch.zeros((n, k), dtype=torch.float64, device=Xd.device)
-    for r0 in range(0, m, chunk):
-        Q += Xd[r0:r0 + chunk].double().T @ U_new[r0:r0 + chunk]               # :424
-    den_v = V64 @ (U_new.T @ U_new)                                            # :425
-    gterm = torch.zeros_like(V64)                                              # gamma W v + delta (v+1)^-2 on the support
-    for kk in range(k):
-        edges, w, nodes = pathways[active[kk]]
-        e0 = torch.as_tensor(edges[:, 0], device=Xd.device, dtype=torch.long)
-        e1 = torch.as_tensor(edges[:, 1], device=Xd.device, dtype=torch.long)
-        wt = torch.as_tensor(np.asarray(w, dtype=np.float64), device=Xd.device)
-        S = torch.as_tensor(np.asarray(nodes), device=Xd.device, dtype=torch.long)
-        v = V64[:, kk]
-        wv = torch.zeros(n, dtype=torch.float64, device=Xd.device)
-        wv.index_add_(0, e0, wt * v[e1])
-        wv.index_add_(0, e1, wt * v[e0])
-        deg = torch.zeros(n, dtype=torch.float64, device=Xd.device)
-        deg.index_add_(0, e0, wt)
-        deg.index_add_(0, e1, wt)
-        col = gamma * wv                                                       # :431-434
-        col[S] += delta * (v[S] + 1.0) ** -2                                   # :436-438
-        gterm[:, kk] = col
-        den_v[:, kk] += gamma * deg * v                                        # :435
-    num = Q + gterm                                                            # association of :440
-    den_v = torch.clamp(den_v, min=EPS)                                        # :442
-    V_new = torch.clamp(V64 * (num / den_v), min=EPS)                          # :443-444
-    return P, U_new, Q, V_new
+    """One iteration of oracle.update_step in float64 on the GPU (tests/fp64_model.py), from float32 U, V and the
+    stored X.  Returns P = X V, U_new, Q = X^T U_new, V_new (float64 tensors)."""
+    from fp64_model import Fp64Model
+    return Fp64Model(torch, Xd, pathways, active, gamma, delta).step(U.double(), V.double())
+
+
+def test_fp64_model_equals_oracle():
+    """The torch float64 restatement used at the sizes the NumPy oracle cannot reach, against the oracle itself at a
+    size both run (weighted edges, isolated support nodes, all-zero genes): 4 steps, factors and every record."""
+    import torch
+    import synth
+    from fp64_model import Fp64Model
+    from oracle import prmf_oracle as orc
+    case = synth.small_case(seed=31, m=300, n=900, k=7, P=5, order=60, zero_genes=4, isolated=2)
+    n, k = case["V0"].shape
+    active = [kk % 5 for kk in range(k)]
+    Xd = torch.as_tensor(case["X"], dtype=torch.float32, device="cuda:0")
+    X = Xd.cpu().numpy().astype(np.float64)
+    mdl = Fp64Model(torch, Xd, case["pathways"], active, case["gamma"], case["delta"], chunk=128)
+    U = torch.as_tensor(case["U0"], device="cuda:0")
+    V = torch.as_tensor(case["V0"], device="cuda:0")
+    pws = [orc.pathway_from_edges(n, e, nodes, w) for (e, w, nodes) in case["pathways"]]
+    tr = []
+    Ur, Vr, _ = orc.nmf_manifold_vec_update(X, case["U0"], case["V0"], [pws[p] for p in active], n_steps=4,
+                                            gamma=case["gamma"], delta=case["delta"], trace=tr)
+    for it in range(4):
+        _, U, _, V = mdl.step(U, V)
+        od = mdl.objective(U, V)
+        for key in OBJ_KEYS:
+            assert abs(od[key] - tr[it][key]) <= 1e-11 * abs(tr[it][key]), (it, key)
+    assert rel(U.cpu().numpy(), Ur) < 1e-12 and rel(V.cpu().numpy(), Vr) < 1e-12
 
 
 def _tile_check(torch, name, got, want, tol_tile):
@@ -123,7 +117,8 @@ def _tile_check(torch, name, got, want, tol_tile):
     return {"rel_" + name: r, "tile_" + name: worst, "bad_tiles_" + name: bad}
 
 
-@pytest.mark.parametrize("workload,x_dtype", [("c3", "bf16"), ("c3", "f32"), ("c5shard", "bf16"), ("c5shard", "f32")])
+@pytest.mark.parametrize("workload,x_dtype", [("c3", "bf16"), ("c3", "f32"), ("c5shard", "bf16"), ("c5shard", "f32"),
+                                              ("c5", "bf16")])
 def test_one_iteration_vs_fp64_at_full_size(workload, x_dtype):
     import torch
     eng, Xd, U, V, pathways, active, gamma, delta = _engine(torch, workload, x_dtype, 11)
@@ -154,5 +149,35 @@ def test_one_iteration_vs_fp64_at_full_size(workload, x_dtype):
         assert res["rel_" + name] < tol_arr, (name, res)
         assert res["bad_tiles_" + name] == 0, (name, res)
     assert res["rel_recon"] < 1e-4
+    assert float(V.min()) >= EPS and bool(torch.isfinite(U).all())
+    eng.close()
+
+
+@pytest.mark.parametrize("workload,x_dtype,steps", [("c3", "bf16", 10)])
+def test_whole_round_vs_fp64_at_full_size(workload, x_dtype, steps):
+    """One whole round (the reference's `modulus` = 10 iterations, prmf_runner.py:740) at BASELINE.json's headline size
+    against the float64 restatement run next to it: U, V after the round and all five objective components of EVERY
+    iteration -- recon from the materialised residual as :337 computes it, manifold and ignore from the normalised
+    Laplacians -- at the 1e-4 bar.  Measures the drift of the float32 state over a round at 50000 x 20000."""
+    import torch
+    from fp64_model import Fp64Model
+    eng, Xd, U, V, pathways, active, gamma, delta = _engine(torch, workload, x_dtype, 17)
+    mdl = Fp64Model(torch, Xd, pathways, active, gamma, delta)
+    U64, V64 = U.double(), V.double()
+    objs, _ = eng.step(U, V, steps, gamma, delta)
+    worst = {key: 0.0 for key in OBJ_KEYS}
+    for it in range(steps):
+        _, U64, _, V64 = mdl.step(U64, V64)
+        od = mdl.objective(U64, V64)
+        for key in OBJ_KEYS:
+            worst[key] = max(worst[key], abs(objs[it][key] - od[key]) / abs(od[key]))
+    res = {"rel_" + key: v for key, v in worst.items()}
+    res.update(_tile_check(torch, "U", U, U64, 1e-3))
+    res.update(_tile_check(torch, "V", V, V64, 1e-3))
+    report("whole_round_vs_fp64[%s-%s]" % (workload, x_dtype), steps=steps, **res)
+    assert res["rel_U"] < 1e-4 and res["rel_V"] < 1e-4, res
+    assert res["bad_tiles_U"] == 0 and res["bad_tiles_V"] == 0, res
+    for key in OBJ_KEYS:
+        assert worst[key] < 1e-4, (key, worst)
     assert float(V.min()) >= EPS and bool(torch.isfinite(U).all())
     eng.close()

@@ -86,10 +86,11 @@ def test_xcd_sliced_decomposition_matches_unsliced(xcd, monkeypatch):
         assert abs(x["obj"] - y["obj"]) <= 1e-5 * abs(y["obj"])
 
 
-@pytest.mark.parametrize("workload,x_dtype", [("c3", "bf16"), ("c3", "f32"), ("c5shard", "bf16")])
+@pytest.mark.parametrize("workload,x_dtype", [("c3", "bf16"), ("c3", "f32"), ("c5shard", "bf16"), ("c5", "bf16")])
 def test_full_size_c3_properties(workload, x_dtype):
     """BASELINE.json's headline size (50000 x 20000, k = 64, 300 pathways, bf16 X; also with f32 X) and one rank's
-    share of the 8-GPU configuration (25000 x 25000, k = 128, 1000 pathways): size-independent
+    share of the 8-GPU configuration (25000 x 25000, k = 128, 1000 pathways) and that configuration WHOLE on one GPU
+    (BASELINE.json configs[4]: 200000 x 25000 -- 782 row panels, the sliced X^T U plan with a 98 MB factor): size-independent
     properties instead of an oracle run -- the Gram-identity reconstruction error equals the directly
     computed ||X - U V^T||_F, fro = sum U^2, V >= eps, finite, and two runs are bit-identical."""
     import math

@@ -97,6 +97,40 @@ def test_score_candidates_vs_reference(golden_dir):
     eng.close()
 
 
+def test_score_candidates_at_c5_shape_vs_oracle():
+    """`restrict`'s score matrix (prmf_runner.py:115-127) at the shape of BASELINE.json configs[4] -- 25000 genes,
+    k = 128, P = 1000 pathways of 300 genes -- against oracle.score_latent_pathway_match on sampled (latent, pathway)
+    pairs: every latent column with 24 pathways drawn per column, plus every pathway with one column."""
+    import torch
+    from oracle import prmf_oracle as orc
+    from prmf_amd import PathwayLibrary, synthetic as syn
+    from prmf_amd.solver import PrmfEngine
+    from measure import report
+    n, k, P = 25000, 128, 1000
+    pathways = syn.tree_pathways(n, P, 300, 23)
+    eng = PrmfEngine(64, n, k, x_dtype="bf16")       # scoring needs the library and V only
+    eng.set_library(PathwayLibrary.from_edge_lists(n, pathways))
+    V = syn.init_factor_torch(torch, "cuda:0", 29, n, k)
+    V[::7, 3] = float(np.finfo(np.float32).eps)      # clamped entries as the V update leaves them
+    S = eng.score_candidates(V)
+    eng.close()
+    assert S.shape == (k, P)
+    Vh = V.cpu().numpy().astype(np.float64)
+    rs = np.random.RandomState(5)
+    pairs = [(kk, int(p)) for kk in range(k) for p in rs.choice(P, size=24, replace=False)]
+    pairs += [(int(rs.randint(k)), p) for p in range(P)]
+    cache = {}
+    worst = 0.0
+    for kk, p in pairs:
+        if p not in cache:
+            e, w, nodes = pathways[p]
+            cache[p] = orc.pathway_from_edges(n, e, nodes, w)
+        want = orc.score_latent_pathway_match(Vh[:, kk], cache[p])
+        worst = max(worst, abs(S[kk, p] - want) / max(abs(want), 1e-12))
+    report("score_candidates_c5_shape", pairs=len(pairs), rel_worst=worst)
+    assert worst < 1e-5
+
+
 def _graphs(c):
     import networkx as nx
     from prmf_amd import runner
