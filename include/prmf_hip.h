@@ -51,16 +51,18 @@ enum prmf_x_dtype {
  * dict (prmf_runner.py:363-371) in this order, + recon^2, + how recon was obtained.
  *
  * recon normally comes from the Gram identity ||X||^2 - 2<X^T U, V> + <U^T U, V^T V> (the sweeps' products are there
- * anyway), which is exact to ~1e-7 ||X||^2 -- i.e. recon to ~1e-7 (||X|| / recon)^2 / 2.  The reference materialises
- * X - U V^T (:337) and never cancels, so when the identity value drops below 2e-3 ||X||^2 (recon / ||X|| < 4.5%) the
- * library evaluates sum (X - U V^T)^2 directly with one more sweep over X: for the LAST record of a prmf_step /
- * prmf_end batch (the one the outer loop's convergence test reads, :772-774), and for every record when the tradeoff
- * feedback is on (recon feeds gamma, :542-548) or PRMF_FLAG_DIRECT_RESIDUAL is set.  PRMF_OBJ_FLAGS says which:
+ * anyway), which is exact to ~1e-8 ||X||^2 at k <= 64 and ~1e-7 ||X||^2 at k > 64 (float32 accumulation of X^T U)
+ * -- i.e. recon to that fraction times (||X|| / recon)^2 / 2.  The reference materialises X - U V^T (:337) and never
+ * cancels, so when the identity value drops below 2e-4 ||X||^2 (k <= 64: recon / ||X|| < 1.4%) resp. 2e-3 ||X||^2
+ * (k > 64: 4.5%) the library evaluates sum (X - U V^T)^2 directly with one more sweep over X: for the LAST record of a
+ * prmf_step / prmf_end batch (the one the outer loop's convergence test reads, :772-774), and for every record when
+ * the tradeoff feedback is on (recon feeds gamma, :542-548) or PRMF_FLAG_DIRECT_RESIDUAL is set.  PRMF_OBJ_FLAGS says
+ * which:
  *   PRMF_RECON_DIRECT     recon / obj / recon_sq of this record come from the direct residual
  *                         (PRMF_OBJ_RECON_SQ_IDENTITY keeps the identity value)
  *   PRMF_RECON_IMPRECISE  identity value below the threshold and NOT replaced (an earlier record of a batch, or a
  *                         multi-rank step driven through the phase calls without prmf_comm_init): relative error of
- *                         recon up to ~1e-7 (||X|| / recon)^2
+ *                         recon up to ~1e-7 (||X|| / recon)^2 (k > 64; a tenth of that at k <= 64)
  *   PRMF_RECON_CLAMPED    the identity value was negative; recon was reported as 0 (never without this bit) */
 #define PRMF_OBJ_STRIDE 10
 enum { PRMF_OBJ_RECON = 0, PRMF_OBJ_MANIFOLD, PRMF_OBJ_IGNORE, PRMF_OBJ_FRO,

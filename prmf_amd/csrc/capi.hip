@@ -338,6 +338,8 @@ SweepPrologue mid_prologue(prmf_ctx* c, int it) {
 // the local sums have to be added up, which the library can only do itself (RCCL communicator, inside prmf_step_dist).
 bool direct_available(const prmf_ctx* c) { return c->nranks == 1 || (c->comm != nullptr && c->dist_driver); }
 bool direct_forced(const prmf_ctx* c) { return (c->flags & PRMF_FLAG_DIRECT_RESIDUAL) != 0; }
+// recon^2 (identity) below this value is too small to trust: kernels.h RECON_DIRECT_THRESHOLD*
+double direct_below(const prmf_ctx* c) { return (c->NT <= 2 ? RECON_DIRECT_THRESHOLD_LO : RECON_DIRECT_THRESHOLD) * c->norm_x_sq; }
 
 // The launches behind a record whose kernel may have raised c->need_dev: sum (X - U V^T)^2 over this rank's rows (the
 // kernels return at once when the flag is clear), the sum over ranks, and the rewrite of the record.
@@ -362,7 +364,7 @@ int finalize_record(prmf_ctx* c, const double* loc_partial, int loc_nblocks, con
   double* record = c->records + (size_t)c->cursor * PRMF_OBJ_STRIDE;
   const bool direct = direct_available(c);
   HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->lr, c->v_send_floats, c->extras_off, c->norm_x_sq, c->hyper,
-                             record, loc_partial, loc_nblocks, loc_colres, direct ? c->need_dev : nullptr, direct_forced(c), s));
+                             record, loc_partial, loc_nblocks, loc_colres, direct ? c->need_dev : nullptr, direct_forced(c), direct_below(c), s));
   if (direct) return direct_residual(c, record, true, s);
   return PRMF_OK;
 }
@@ -961,7 +963,7 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
                                     c->obj_scratch, s));
     const bool direct = direct_available(c) && c->cursor > 0;
     HIP_TRY(c, launch_records_all(c->Gu_keep, c->Gv_keep, c->k, c->cursor, c->cross_ring, c->colres_ring, c->norm_x_sq, c->hyper,
-                                  c->records, direct ? c->need_dev : nullptr, false, s));
+                                  c->records, direct ? c->need_dev : nullptr, false, direct_below(c), s));
     // the last record of the batch is the one the outer loop acts on: direct residual if its identity value is too small
     if (direct && (rc = direct_residual(c, c->records + (size_t)(c->cursor - 1) * PRMF_OBJ_STRIDE, false, s))) return rc;
   }
@@ -972,7 +974,7 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
     }
     const bool direct = direct_available(c) && c->cursor > 0;
     HIP_TRY(c, launch_finalize_batch(c->Gu_keep, c->Gv_keep, c->k, c->cursor, c->extras_ring, c->lr, c->norm_x_sq, c->hyper,
-                                     c->records, direct ? c->need_dev : nullptr, false, s));
+                                     c->records, direct ? c->need_dev : nullptr, false, direct_below(c), s));
     if (direct && (rc = direct_residual(c, c->records + (size_t)(c->cursor - 1) * PRMF_OBJ_STRIDE, false, s))) return rc;
   }
   c->batch_open = false;

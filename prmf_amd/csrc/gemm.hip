@@ -36,6 +36,9 @@
 #ifndef PRMF_PHASE_PROF
 #define PRMF_PHASE_PROF 0
 #endif
+#ifndef PRMF_BF16_ACC_LO
+#define PRMF_BF16_ACC_LO 1    // bf16 X, k <= 64: the products with the factor's low piece in accumulators of their own (see sweep_compute)
+#endif
 #ifndef PRMF_SWEEP_MINW
 #define PRMF_SWEEP_MINW 2     // 1 (the compiler then takes 268 registers at k = 128: one workgroup per CU) is 12% slower there
 #endif
@@ -138,8 +141,14 @@ __device__ __forceinline__ void split_fragment(const u32x4& f0, const u32x4& f1,
 // acc_lo (MODE 2 only): the cross terms (<= 2^-8 of the main products) are summed in their own accumulators -- added
 // into the main ones they fall below half an ulp of a long running sum and are always rounded DOWN (a -4.8e-6 bias of
 // X V at 50000 x 20000: exactly the mean of the lowest piece of X)
+// Does the kernel keep a second accumulator set?  f32 X: always (cross terms).  bf16 X at k <= 64 (PRMF_BF16_ACC_LO):
+// the products with the factor's low piece (2^-9 of the main ones) are then not absorbed one MFMA at a time into a
+// running sum 10^4 times their size.
+template <int MODE, int NT>
+struct SweepLo { static constexpr bool value = MODE == 2 || (PRMF_BF16_ACC_LO != 0 && NT <= 2); };
+
 template <int MODE, int MT, int NT>
-__device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&acc_lo)[MODE == 2 ? MT : 1][MODE == 2 ? NT : 1],
+__device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&acc_lo)[(SweepLo<MODE, NT>::value ? MT : 1)][(SweepLo<MODE, NT>::value ? NT : 1)],
                                               const u32x4* __restrict__ sa, const u32x4* __restrict__ sb, int lane) {
   const int r = lane & 31, h = lane >> 5;
   const int swz = (r >> 1) & 7;
@@ -225,8 +234,12 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&ac
       for (int mt = 0; mt < MT; ++mt) {
         acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
             __builtin_bit_cast(bf16x8, av[mt]), __builtin_bit_cast(bf16x8, bh), acc[mt][t], 0, 0, 0);
-        acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            __builtin_bit_cast(bf16x8, av[mt]), __builtin_bit_cast(bf16x8, bl), acc[mt][t], 0, 0, 0);
+        if constexpr (SweepLo<MODE, NT>::value)
+          acc_lo[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, av[mt]), __builtin_bit_cast(bf16x8, bl), acc_lo[mt][t], 0, 0, 0);
+        else
+          acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, av[mt]), __builtin_bit_cast(bf16x8, bl), acc[mt][t], 0, 0, 0);
       }
     }
   }
@@ -378,7 +391,8 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   const uint4* bbase = Bp + (int64_t)c0 * BCH;
 
   f32x16 acc[MT][NT];
-  f32x16 acc_lo[MODE == 2 ? MT : 1][MODE == 2 ? NT : 1];
+  constexpr bool HAS_LO = SweepLo<MODE, NT>::value;
+  f32x16 acc_lo[HAS_LO ? MT : 1][HAS_LO ? NT : 1];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -386,7 +400,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         acc[mt][t][i] = 0.f;
-        if constexpr (MODE == 2) acc_lo[mt][t][i] = 0.f;
+        if constexpr (HAS_LO) acc_lo[mt][t][i] = 0.f;
       }
 
   u32x4 a[MT][4];
@@ -429,6 +443,9 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
         // workgroup) is then the one that yields issue slots while it queues loads or LDS writes.  Same-session A/B:
         // 1-2.5% on both sweeps at 50000 x 20000, 4.5% at k = 128, neutral at 5000 x 10000; the inverse (loaders high)
         // and a priority kept through the LDS writes are 1-4% slower (profiles/r02_ab_priority_and_pipelined_reads.txt).
+        // The CU's second workgroup (upper half of the grid) runs 1-5% longer than the first -- the arbiter serves the
+        // older wave of a SIMD first (tools/wg_spread.py) -- but raising ITS priority on every other chunk does not
+        // shorten the launch (k = 128: +29%): profiles/r03_ab_priority_balance.txt.
 #if PRMF_SWEEP_PRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
@@ -476,7 +493,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         f32x4 v = {acc[mt][t][4 * q4], acc[mt][t][4 * q4 + 1], acc[mt][t][4 * q4 + 2], acc[mt][t][4 * q4 + 3]};
-        if constexpr (MODE == 2) {
+        if constexpr (HAS_LO) {
           const f32x4 w = {acc_lo[mt][t][4 * q4], acc_lo[mt][t][4 * q4 + 1], acc_lo[mt][t][4 * q4 + 2], acc_lo[mt][t][4 * q4 + 3]};
           v += w;
         }

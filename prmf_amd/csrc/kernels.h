@@ -24,9 +24,13 @@ constexpr int REC_STRIDE = 10;
 constexpr int REC_FLAGS = 8;               // PRMF_RECON_* bits, stored as a double
 constexpr int REC_RECON_SQ_IDENTITY = 9;   // the Gram-identity value of recon^2, kept when the direct residual replaced it
 constexpr int REC_FLAG_DIRECT = 1, REC_FLAG_IMPRECISE = 2, REC_FLAG_CLAMPED = 4;
-// recon^2 from the Gram identity is exact to ~1e-7 ||X||^2 (float32 MFMA accumulation of its three terms): below this
-// fraction of ||X||^2 (recon / ||X|| < 4.5%) its relative error passes ~2.5e-5 and the direct residual takes over
-constexpr double RECON_DIRECT_THRESHOLD = 2e-3;
+// recon^2 from the Gram identity ||X||^2 - 2 <X^T U, V> + <U^T U, V^T V> is exact to a fraction of ||X||^2 set by the
+// float32 accumulation of X^T U in the sweep (the Gram terms are ~1e-10; profiles/r03_recon_identity_terms.txt,
+// r03_ab_bf16_low_piece_accumulators.txt): ~1e-9..1e-8 with the low-piece products in accumulators of their own
+// (every f32 X sweep; bf16 X at k <= 64), ~1e-7 at k > 64.  Below these fractions of ||X||^2 the relative error of recon
+// passes ~2.5e-5 and the direct residual takes over (recon / ||X|| < 1.4% resp. 4.5%).
+constexpr double RECON_DIRECT_THRESHOLD_LO = 2e-4;      // k <= 64
+constexpr double RECON_DIRECT_THRESHOLD = 2e-3;         // k > 64
 constexpr int RESIDUAL_MAX_BLOCKS = 1024;
 
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
@@ -175,7 +179,7 @@ hipError_t launch_objective_all(const PathwayLibDev& lib, const int32_t* active_
 //   `need` (nullable): raised by the LAST record of the batch, see launch_finalize
 hipError_t launch_records_all(const double* Gu_keep, const double* Gv_keep, int k, int iters, const double* cross,
                               const double* colres, double norm_x_sq, const double* hyper, double* records, int* need, bool force,
-                              hipStream_t s);
+                              double direct_below /* recon^2 below this: direct residual */, hipStream_t s);
 // partial Gram: per-wave partials -> partial[gram_blocks][k*k]; reduce -> G (double)
 int gram_blocks(int64_t rows);
 hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStream_t s);
@@ -210,7 +214,7 @@ hipError_t launch_objective_terms(const PathwayLibDev& lib, const int32_t* activ
 hipError_t launch_finalize(const double* Gu, const double* Gv, int k, const float* v_recv, int nranks,
                            int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* hyper /*gamma,delta,tradeoff*/,
                            double* record /*REC_STRIDE doubles*/, const double* loc_partial, int loc_nblocks,
-                           const double* loc_colres, int* need, bool force, hipStream_t s);
+                           const double* loc_colres, int* need, bool force, double direct_below, hipStream_t s);
 // merged small launches of the single-rank path
 hipError_t launch_mid(const float* gram_partial, int nparts, int k, double* Gu, const PathwayLibDev& lib,
                       const int32_t* active_dev, int col0, int ncols, const float* V, const double* hyper, float* gnum,
@@ -220,7 +224,7 @@ hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_
                          void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, hipStream_t s,
                          double* extras_keep = nullptr, int nranks = 0, int64_t extras_off = 0);
 hipError_t launch_finalize_batch(const double* Gu_keep, const double* Gv_keep, int k, int n_it, const double* extras_ring,
-                                 int nranks, double norm_x_sq, double* hyper, double* records, int* need, bool force, hipStream_t s);
+                                 int nranks, double norm_x_sq, double* hyper, double* records, int* need, bool force, double direct_below, hipStream_t s);
 hipError_t launch_post(const float* gram_partial, int nparts, int k, double* Gv, const PathwayLibDev& lib,
                        const int32_t* active_dev, const float* V, const double* partial, int nblocks, double* colres,
                        double* scratch, hipStream_t s);

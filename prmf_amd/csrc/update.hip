@@ -1544,7 +1544,7 @@ finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, in
                 int nranks, int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* __restrict__ hyper,
                 double* __restrict__ record, const double* __restrict__ loc_partial, int loc_nblocks,
                 const double* __restrict__ loc_colres, const double* __restrict__ extras_ring /* batch form, else null */,
-                int* __restrict__ need /* nullable: direct-residual request (residual.hip) */, int force) {
+                int* __restrict__ need /* nullable: direct-residual request (residual.hip) */, int force, double direct_below) {
   __shared__ double red[5][256];
   const int tid = threadIdx.x;
   if (extras_ring) {                   // batch form (column-sharded mode, records deferred): workgroup = iteration
@@ -1597,10 +1597,10 @@ finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, in
     record[5] = delta;
     record[6] = recon + gamma * man + delta * ign + fro;
     record[7] = recon_sq;
-    // The identity's recon^2 is exact to ~1e-7 ||X||^2: below RECON_DIRECT_THRESHOLD ||X||^2 the record is marked, and
+    // The identity's recon^2 is exact to ~1e-8 (k <= 64) / ~1e-7 (k > 64) ||X||^2: below `direct_below` the record is marked, and
     // the last record of a batch (every record in the per-iteration form) asks for the direct residual, which then
     // replaces recon / obj and drives the tradeoff feedback.  A negative value is never clamped silently.
-    const bool low = recon_sq < RECON_DIRECT_THRESHOLD * norm_x_sq;
+    const bool low = recon_sq < direct_below;
     const bool ask = need && (low || force) && (!extras_ring || blockIdx.x == gridDim.x - 1);
     record[REC_FLAGS] = (double)((low ? REC_FLAG_IMPRECISE : 0) | (recon_sq < 0.0 ? REC_FLAG_CLAMPED : 0));
     record[REC_RECON_SQ_IDENTITY] = recon_sq;
@@ -1617,19 +1617,19 @@ finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, in
 hipError_t launch_finalize(const double* Gu, const double* Gv, int k, const float* v_recv, int nranks,
                            int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* hyper, double* record,
                            const double* loc_partial, int loc_nblocks, const double* loc_colres, int* need, bool force,
-                           hipStream_t s) {
+                           double direct_below, hipStream_t s) {
   finalize_kernel<<<1, 256, 0, s>>>(Gu, Gv, k, v_recv, nranks, blk_stride, extras_off, norm_x_sq, hyper, record,
-                                    loc_partial, loc_nblocks, loc_colres, nullptr, need, force ? 1 : 0);
+                                    loc_partial, loc_nblocks, loc_colres, nullptr, need, force ? 1 : 0, direct_below);
   return hipGetLastError();
 }
 
 // the records of `n_it` iterations at once from the kept Grams and rank extras (column-sharded mode, tradeoff off)
 hipError_t launch_finalize_batch(const double* Gu_keep, const double* Gv_keep, int k, int n_it, const double* extras_ring,
                                  int nranks, double norm_x_sq, double* hyper, double* records, int* need, bool force,
-                                 hipStream_t s) {
+                                 double direct_below, hipStream_t s) {
   if (n_it <= 0) return hipSuccess;
   finalize_kernel<<<n_it, 256, 0, s>>>(Gu_keep, Gv_keep, k, nullptr, nranks, 0, 0, norm_x_sq, hyper, records, nullptr, 0,
-                                       nullptr, extras_ring, need, force ? 1 : 0);
+                                       nullptr, extras_ring, need, force ? 1 : 0, direct_below);
   return hipGetLastError();
 }
 
@@ -1693,7 +1693,7 @@ hipError_t launch_objective_all(const PathwayLibDev& lib, const int32_t* active_
 __global__ void __launch_bounds__(256)
 records_all_kernel(const double* __restrict__ Gu_keep, const double* __restrict__ Gv_keep, int k, const double* __restrict__ cross,
                    const double* __restrict__ colres, double norm_x_sq, const double* __restrict__ hyper,
-                   double* __restrict__ records, int* __restrict__ need, int force) {
+                   double* __restrict__ records, int* __restrict__ need, int force, double direct_below) {
   __shared__ double red[4][256];
   const int tid = threadIdx.x, it = blockIdx.x;
   const double* Gu = Gu_keep + (int64_t)it * k * k;
@@ -1730,7 +1730,7 @@ records_all_kernel(const double* __restrict__ Gu_keep, const double* __restrict_
     record[5] = delta;
     record[6] = recon + gamma * man + delta * ign + fro;
     record[7] = recon_sq;
-    const bool low = recon_sq < RECON_DIRECT_THRESHOLD * norm_x_sq;           // see finalize_kernel
+    const bool low = recon_sq < direct_below;                                  // see finalize_kernel
     record[REC_FLAGS] = (double)((low ? REC_FLAG_IMPRECISE : 0) | (recon_sq < 0.0 ? REC_FLAG_CLAMPED : 0));
     record[REC_RECON_SQ_IDENTITY] = recon_sq;
     if (need && it == (int)gridDim.x - 1) *need = (low || force) ? 1 : 0;     // the last record of the batch
@@ -1739,9 +1739,9 @@ records_all_kernel(const double* __restrict__ Gu_keep, const double* __restrict_
 
 hipError_t launch_records_all(const double* Gu_keep, const double* Gv_keep, int k, int iters, const double* cross,
                               const double* colres, double norm_x_sq, const double* hyper, double* records, int* need, bool force,
-                              hipStream_t s) {
+                              double direct_below, hipStream_t s) {
   if (iters <= 0) return hipSuccess;
-  records_all_kernel<<<iters, 256, 0, s>>>(Gu_keep, Gv_keep, k, cross, colres, norm_x_sq, hyper, records, need, force ? 1 : 0);
+  records_all_kernel<<<iters, 256, 0, s>>>(Gu_keep, Gv_keep, k, cross, colres, norm_x_sq, hyper, records, need, force ? 1 : 0, direct_below);
   return hipGetLastError();
 }
 

@@ -1,8 +1,8 @@
 """Reconstruction error when X is well fitted (VERDICT r2 / ADVICE r1: the Gram identity cancels).
 
 The reference computes recon = ||X - U V^T||_F on the materialised residual (script/prmf_runner.py:337) and never
-cancels.  The library's records normally use ||X||^2 - 2<X^T U, V> + <U^T U, V^T V>, exact to ~1e-7 ||X||^2; when that
-value is below 2e-3 ||X||^2 the last record of a batch (every record with the tradeoff feedback or
+cancels.  The library's records normally use ||X||^2 - 2<X^T U, V> + <U^T U, V^T V>, exact to ~1e-8 (k <= 64) or ~1e-7
+(k > 64) of ||X||^2; when that value is below 2e-4 resp. 2e-3 ||X||^2 the last record of a batch (every record with the tradeoff feedback or
 PRMF_FLAG_DIRECT_RESIDUAL) takes the direct residual instead -- one more sweep over X (prmf_amd/csrc/residual.hip) --
 and the flags of the record say so.  These tests drive a noise-free low-rank X down to recon / ||X|| ~ 1e-3.
 """
@@ -99,6 +99,7 @@ def test_recon_of_a_well_fitted_x(m, n, k, x_dtype):
     Ur, Vr = case["U0"], case["V0"]
     worst_own = worst_orc = worst_parts = 0.0
     ratio = []
+    n_direct = 0
     for batch in range(3):
         objs, _ = eng.step(U, V, 5, gamma, delta)
         flags = list(eng.last_flags)
@@ -106,10 +107,20 @@ def test_recon_of_a_well_fitted_x(m, n, k, x_dtype):
         Ur, Vr, _ = orc.nmf_manifold_vec_update(X, Ur, Vr, active, n_steps=5, gamma=gamma, delta=delta, trace=tr)
         own = math.sqrt(direct_fp64(torch, Xd, U, V))
         ratio.append(own / nx)
-        assert own / nx < 0.04, "the case is meant to be well fitted (the direct residual takes over below 4.5%)"
-        assert flags[-1] & DIRECT and not flags[-1] & IMPRECISE, flags
-        assert all(f & IMPRECISE and not f & DIRECT for f in flags[:-1]), flags
-        worst_own = max(worst_own, abs(objs[-1]["recon"] - own) / own)
+        # the direct residual takes over below 2e-4 ||X||^2 (k <= 64: recon / ||X|| < 1.4%) resp. 2e-3 (k > 64: 4.5%)
+        thr = 2e-4 if k <= 64 else 2e-3
+        assert (own / nx) ** 2 < thr or batch > 0, "the case is meant to start well fitted"
+        if (own / nx) ** 2 < 0.8 * thr:
+            assert flags[-1] & DIRECT and not flags[-1] & IMPRECISE, flags
+            n_direct += 1
+        elif (own / nx) ** 2 > 1.25 * thr:
+            assert flags[-1] == 0, flags
+        assert all(not f & DIRECT for f in flags[:-1]), flags
+        e_own = abs(objs[-1]["recon"] - own) / own
+        # a direct record is exact to ~1e-6; an identity-based one just above the threshold carries the ~2.5e-5 the
+        # threshold was chosen for
+        assert e_own < (1e-5 if flags[-1] & DIRECT else 6e-5), (e_own, flags[-1])
+        worst_own = max(worst_own, e_own)
         worst_orc = max(worst_orc, abs(objs[-1]["recon"] - tr[-1]["recon"]) / tr[-1]["recon"])
         for key in ("manifold", "ignore", "fro"):
             worst_parts = max(worst_parts, abs(objs[-1][key] - tr[-1][key]) / abs(tr[-1][key]))
@@ -117,7 +128,7 @@ def test_recon_of_a_well_fitted_x(m, n, k, x_dtype):
         assert od["obj"] == pytest.approx(od["recon"] + od["gamma"] * od["manifold"] + od["delta"] * od["ignore"] + od["fro"], rel=1e-13)
     report("recon_well_fitted[%dx%d-k%d-%s]" % (m, n, k, x_dtype), recon_over_normx=ratio, rel_recon_vs_own_fp64=worst_own,
            rel_recon_vs_oracle=worst_orc, rel_other_vs_oracle=worst_parts, rel_U=rel(U.cpu().numpy(), Ur), rel_V=rel(V.cpu().numpy(), Vr))
-    assert worst_own < 1e-5
+    assert n_direct >= 1
     assert worst_orc < 1e-4
     assert worst_parts < 1e-4
     eng.close()

@@ -57,29 +57,36 @@ __global__ void __launch_bounds__(512) steal(const u32x4* __restrict__ A, long l
   if (acc == 0x12345678u) out[0] = acc;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  // shapes: 50000 x 20000 bf16 (196 panels x 314 chunks of 128 B), 5000 x 10000 f32 (20 x 316), 6250 x 20000 bf16 (25 x 314)
+  const int shapes[3][2] = {{196, 314}, {20, 316}, {25, 314}};
   const long m = 50176, n = 20096; const long lda16 = n * 2 / 16;
   u32x4 *A, *B; unsigned *out, *counter;
-  hipMalloc(&A, m * n * 2); hipMalloc(&B, 314L * 16384); hipMalloc(&out, 4); hipMalloc(&counter, 4);
-  hipMemset(A, 1, m * n * 2); hipMemset(B, 1, 314L * 16384);
+  hipMalloc(&A, m * n * 2); hipMalloc(&B, 316L * 16384); hipMalloc(&out, 4); hipMalloc(&counter, 4);
+  hipMemset(A, 1, m * n * 2); hipMemset(B, 1, 316L * 16384);
   hipFuncSetAttribute((const void*)steal, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const int panels = 196, nch = 314;
-  auto run = [&](int G, int tail_pct, int item) {
-    int nstat = item > 0 ? nch - nch * tail_pct / 100 : nch;
-    float best = 1e9;
-    for (int rep = 0; rep < 5; ++rep) {
-      hipMemset(counter, 0, 4);
-      hipEventRecord(e0);
-      steal<<<G, 512, 64 * 1024>>>(A, lda16, B, panels, nch, nstat, item, counter, out);
-      hipEventRecord(e1); hipEventSynchronize(e1);
-      float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
-    }
-    double bytes = (double)panels * 256 * nch * 128;
-    printf("G=%4d tail=%2d%% item=%2d chunks: %.3f ms  %.2f TB/s\n", G, tail_pct, item, best, bytes / best / 1e9);
-  };
-  run(512, 0, 0);
-  for (int tail : {5, 10, 20, 30}) for (int item : {4, 8, 16}) run(512, tail, item);
-  run(512, 100, 8); run(512, 100, 16); run(512, 100, 24);
+  for (int sh = 0; sh < 3; ++sh) {
+    const int panels = shapes[sh][0], nch = shapes[sh][1];
+    printf("--- %d panels x %d chunks (%.0f MB)\n", panels, nch, (double)panels * 256 * nch * 128 / 1e6);
+    auto run = [&](int G, int tail_pct, int item) {
+      int nstat = item > 0 ? nch - nch * tail_pct / 100 : nch;
+      float best = 1e9, sum = 0;
+      const int reps = 9;
+      for (int rep = 0; rep < reps; ++rep) {
+        hipMemset(counter, 0, 4);
+        hipEventRecord(e0);
+        steal<<<G, 512, 64 * 1024>>>(A, lda16, B, panels, nch, nstat, item, counter, out);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+        if (rep > 0) sum += ms;
+      }
+      double bytes = (double)panels * 256 * nch * 128;
+      printf("G=%4d tail=%3d%% item=%2d chunks: best %.4f ms  mean %.4f ms  %.2f TB/s (best)\n", G, tail_pct, item, best, sum / (reps - 1), bytes / best / 1e9);
+    };
+    run(512, 0, 0);
+    for (int tail : {10, 20, 30, 50}) for (int item : {2, 4, 8}) run(512, tail, item);
+    run(512, 100, 2); run(512, 100, 4); run(512, 100, 8);
+  }
   return 0;
 }

@@ -45,6 +45,8 @@ for rep in range(4):
     eng.phase_q(); eng.phase_v(); eng.phase_post(); torch.cuda.synchronize()
 eng.lib.prmf_debug_set_stamps(None)
 durs = np.array(durs)
+if os.environ.get("SAVE"):
+    np.save(os.environ["SAVE"] + "_xv.npy", durs)
 print("X*V duration per WG: mean %.1f std %.1f us" % (durs.mean(), durs.std()))
 print("corr(launch0, launch1) = %.3f, corr(launch0, launch3) = %.3f" % (np.corrcoef(durs[0], durs[1])[0, 1], np.corrcoef(durs[0], durs[3])[0, 1]))
 m = durs.mean(axis=0)
@@ -62,6 +64,8 @@ for rep in range(3):
     eng.phase_v(); eng.phase_post(); torch.cuda.synchronize()
 eng.lib.prmf_debug_set_stamps(None)
 durs = np.array(durs); m = durs.mean(axis=0)
+if os.environ.get("SAVE"):
+    np.save(os.environ["SAVE"] + "_xtu.npy", durs)
 print("X^T*U duration per WG: mean %.1f std %.1f us; corr %.3f" % (durs.mean(), durs.std(), np.corrcoef(durs[0], durs[2])[0, 1]))
 print("per-XCD mean (block id %% 8):", np.round([m[x::8].mean() for x in range(8)], 1))
 print("per-XCD, first/second WG per CU:", [(round(m[x::8][:32].mean(), 1), round(m[x::8][32:].mean(), 1)) for x in range(8)])
