@@ -81,10 +81,10 @@ const char* prmf_last_error(const prmf_ctx* ctx);
 /*
  * One context per GPU / rank.  X is row-sharded over `nranks` ranks: this rank
  * holds `m_local` of the samples; n (genes) and k (latent) are global.  With
- * nranks > 1 every rank updates all of V from the all-reduced X^T U (default), or,
- * with PRMF_FLAG_COLUMN_SHARDED in `flags`, the k latent columns (and their active
- * pathway Laplacians) are sharded for the V-update: rank r owns columns
- * [r*kc, min(k,(r+1)*kc)), kc = ceil(k/nranks) -- see prmf_comm_sizes.
+ * nranks > 1 the k latent columns (and their active pathway Laplacians) are sharded
+ * for the V-update (default): rank r owns columns [r*kc, min(k,(r+1)*kc)),
+ * kc = ceil(k/nranks) -- see prmf_comm_sizes; with PRMF_FLAG_REPLICATED in `flags`
+ * every rank updates all of V from the all-reduced X^T U instead.
  * Replaces: the shapes implied by X/U/V at prmf_runner.py:417-418.
  * Limits: 1 <= k <= 128 (PRMF_ERR_UNSUPPORTED above); x_dtype PRMF_X_F32 or PRMF_X_BF16.
  */
@@ -152,24 +152,27 @@ int prmf_step(prmf_ctx* ctx, float* dU, float* dV, int n_steps,
 /* ------------------------------------------------------------------------
  * Multi-rank form of one iteration: four device phases with collectives
  * between them, driven by the host over torch.distributed (RCCL), or issued by
- * the library itself (prmf_step_dist).  Replicated mode (default):
+ * the library itself (prmf_step_dist).  Column-sharded mode (default):
  *
  *   prmf_phase_u    P = X_g V ; U_g update ; partial U_g^T U_g      -> gram buffer
  *        all_reduce(gram, SUM)                       k*k doubles
- *   prmf_phase_q    Q_g = X_g^T U_g (n x k)                         -> q_send
- *        all_reduce(q_send, SUM, in place)           n*k floats
- *   prmf_phase_v    V update (all columns) from the reduced Q, objective pieces
- *   prmf_phase_post V^T V, objective record
- *
- * Column-sharded mode (PRMF_FLAG_COLUMN_SHARDED):
- *
- *   prmf_phase_u    as above;  all_reduce(gram, SUM)
- *   prmf_phase_q    Q_g laid out by owner column block              -> q_send
+ *   prmf_phase_q    Q_g = X_g^T U_g laid out by owner column block  -> q_send
  *        reduce_scatter(q_send -> q_recv, SUM)       n*kc floats per rank
  *   prmf_phase_v    graph terms + divide + clamps for the OWN columns,
- *                   own-column objective pieces                     -> v_send
- *        all_gather(v_send -> v_recv)                n*kc+8 floats per rank
- *   prmf_phase_post rebuild replicated V, V^T V, objective record
+ *                   their per-workgroup sums in the tail            -> v_send
+ *        all_gather(v_send -> v_recv)                v_send_floats per rank
+ *   prmf_phase_post rebuild replicated V, packed V, V^T V partials, objective state
+ *
+ * Replicated mode (PRMF_FLAG_REPLICATED):
+ *
+ *   prmf_phase_u    as above;  all_reduce(gram, SUM)
+ *   prmf_phase_q    Q_g = X_g^T U_g (n x k)                         -> q_send
+ *        all_reduce(q_send, SUM, in place)           n*k floats
+ *   prmf_phase_v    V update (all columns) from the reduced Q
+ *   prmf_phase_post objective state
+ *
+ * (prmf_step_dist issues the all_reduce of the gram buffer AFTER prmf_phase_q, in one RCCL group with the exchange of
+ * Q: the X^T U sweep's prologue reduces the local partials, so prmf_phase_u has nothing to hand over.)
  *
  * prmf_step is exactly this sequence with the collectives elided.
  * ---------------------------------------------------------------------- */
@@ -179,20 +182,21 @@ typedef struct prmf_comm_sizes {
   int64_t gram_doubles;     /* all_reduce buffer (float64)                    */
   int64_t q_send_floats;    /* nranks * q_recv_floats                         */
   int64_t q_recv_floats;    /* n * kc                                         */
-  int64_t v_send_floats;    /* n * kc + 8 (objective partials in the tail)    */
+  int64_t v_send_floats;    /* n * kc, then the tail: column-sharded mode: the own-column update's per-workgroup
+                               sums ([<= 256][kc + 1] doubles); always: 4 doubles of objective pieces */
   int64_t v_recv_floats;    /* nranks * v_send_floats                         */
   int32_t kc;               /* latent columns updated per rank                */
   int32_t mode;             /* PRMF_DIST_*: which exchanges the caller performs */
 } prmf_comm_sizes;
 
 /* Exchanges between the phases (host-driven form; prmf_step_dist issues the same ones itself):
- *   PRMF_DIST_REPLICATED (default for nranks > 1): every rank updates all of V.
- *       phase_u; all_reduce(gram, float64 sum); phase_q; all_reduce(q_send, float32 sum, in place;
- *       q_recv aliases q_send, n*k floats); phase_v; phase_post.  v_send / v_recv are not exchanged.
- *   PRMF_DIST_COLUMN_SHARDED (PRMF_FLAG_COLUMN_SHARDED at creation): rank r
- *       updates latent columns [r*kc, (r+1)*kc) and their pathway Laplacians.
- *       phase_u; all_reduce(gram); phase_q; reduce_scatter(q_send -> q_recv, sum); phase_v;
- *       all_gather(v_send -> v_recv); phase_post. */
+ *   PRMF_DIST_COLUMN_SHARDED (default for nranks > 1): rank r updates latent columns
+ *       [r*kc, (r+1)*kc) and their pathway Laplacians.
+ *       phase_u; all_reduce(gram, float64 sum); phase_q; reduce_scatter(q_send -> q_recv, float32 sum); phase_v;
+ *       all_gather(v_send -> v_recv); phase_post.
+ *   PRMF_DIST_REPLICATED (PRMF_FLAG_REPLICATED at creation): every rank updates all of V.
+ *       phase_u; all_reduce(gram); phase_q; all_reduce(q_send, float32 sum, in place; q_recv aliases q_send,
+ *       n*k floats); phase_v; phase_post.  v_send / v_recv are not exchanged. */
 #define PRMF_DIST_COLUMN_SHARDED 0
 #define PRMF_DIST_REPLICATED 1
 
@@ -295,7 +299,8 @@ int prmf_get_sweep_info(const prmf_ctx* ctx, prmf_sweep_info* out);
  * prmf_begin..prmf_end span (prmf_step = one span per <=256 iterations); needs
  * timing enabled (PRMF_FLAG_TIMING at creation or prmf_set_timing). */
 #define PRMF_FLAG_TIMING 0x1u
-#define PRMF_FLAG_COLUMN_SHARDED 0x2u   /* nranks > 1: shard the V update by latent columns (see prmf_comm_sizes) */
+#define PRMF_FLAG_REPLICATED 0x2u       /* nranks > 1: every rank updates all of V from the all-reduced X^T U instead of
+                                           sharding the V update by latent columns (see prmf_comm_sizes) */
 /* Single rank, tradeoff off: by default the iteration is 4 launches (the k x k reductions and the pathway terms run as
  * prologues of the two sweeps) and the objective records of all iterations since prmf_begin are evaluated in prmf_end
  * from per-iteration state kept on the device -- same arithmetic, bit-identical records.  This flag keeps the
@@ -317,8 +322,8 @@ int prmf_get_timing(const prmf_ctx* ctx, double* ms_xv, double* ms_xtu, double* 
  * library, the size / rank RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank; -1 if the
  * collectives are host-driven), the V-update mode, and -- with timing enabled -- the average device time per iteration
  * of the four phases of the last prmf_step_dist batch, each including the exchange that follows it on the caller's
- * stream: [0] phase_u, [1] phase_q + reduce-scatter / all-reduce of Q, [2] phase_v + all-gather, [3] phase_post
- * (the k x k all-reduce runs on a side stream next to phase_q).  -1 when not measured. */
+ * stream: [0] phase_u, [1] phase_q + the grouped exchange (k x k all-reduce of U^T U with the reduce-scatter /
+ * all-reduce of Q), [2] phase_v + all-gather, [3] phase_post.  -1 when not measured. */
 typedef struct prmf_comm_info_t {
   int32_t in_library;
   int32_t comm_nranks;

@@ -16,7 +16,7 @@ PRMF_OBJ_STRIDE = 10
 PRMF_OBJ_FLAGS, PRMF_OBJ_RECON_SQ_IDENTITY = 8, 9
 PRMF_RECON_DIRECT, PRMF_RECON_IMPRECISE, PRMF_RECON_CLAMPED = 1, 2, 4
 PRMF_FLAG_TIMING = 0x1
-PRMF_FLAG_COLUMN_SHARDED = 0x2
+PRMF_FLAG_REPLICATED = 0x2
 PRMF_FLAG_EAGER_OBJECTIVE = 0x4
 PRMF_FLAG_DIRECT_RESIDUAL = 0x8
 PRMF_DIST_COLUMN_SHARDED, PRMF_DIST_REPLICATED = 0, 1

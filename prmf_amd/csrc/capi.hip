@@ -34,10 +34,10 @@ struct prmf_ctx {
   int pack_dtype = 0;                 // fragment layout of the packed factors (= x_dtype unless split_f32)
   bool split_f32 = false;             // f32 X multiplied as three bf16 pieces on the bf16 MFMA (see prmf_create)
   int nranks = 1, rank = 0;
-  // Layout ranks: how many column blocks the V update is split into.  Column-sharded mode: lr = nranks (each rank
-  // updates kc = ceil(k / nranks) columns; reduce-scatter of Q, all-gather of V).  Replicated mode (default for
-  // nranks > 1): lr = 1 -- every rank updates all of V from the all-reduced Q with the single-rank fused kernels;
-  // exchanges: all-reduce of U^T U (k x k float64) and all-reduce of Q (n x k float32).
+  // Layout ranks: how many column blocks the V update is split into.  Column-sharded mode (default for nranks > 1):
+  // lr = nranks (each rank updates kc = ceil(k / nranks) columns; reduce-scatter of Q, all-gather of V).  Replicated mode
+  // (PRMF_FLAG_REPLICATED): lr = 1 -- every rank updates all of V from the all-reduced Q with the single-rank fused
+  // kernels; exchanges: all-reduce of U^T U (k x k float64) and all-reduce of Q (n x k float32).
   int lr = 1;
   bool replicated = false;
   int kc = 0, col0 = 0, ncols = 0;
@@ -70,39 +70,44 @@ struct prmf_ctx {
 
   // comm buffers
   float *q_send = nullptr, *q_recv = nullptr, *v_send = nullptr, *v_recv = nullptr;
-  int64_t extras_off = 0, v_send_floats = 0;
+  // Layout of a rank's all-gather block (v_send): [n * kc floats: own columns of V_new][pad to 8 B]
+  //   column-sharded mode only: [vblocks][kc + 1] doubles -- per-workgroup sums of the own-column V update (partial_off)
+  //   [4 doubles: <Q, V_new>, manifold, ignore of the own columns -- per-iteration objective only] (extras_off)
+  int64_t partial_off = 0, extras_off = 0, v_send_floats = 0;
 
   // pathway library
   PathwayLibDev lib{};
   std::vector<void*> lib_allocs;
   bool have_lib = false, have_active = false;
   int32_t* active_dev = nullptr;
-  int32_t* pos = nullptr;
+  int32_t* pos = nullptr;             // [n][kc]: position of gene j in the active support of own column c, or -1
+  int32_t* pos_all = nullptr;         // column-sharded mode: the same for all k columns [n][k] (deferred objective)
   float *gnum = nullptr, *gden = nullptr;
   double* obj_scratch = nullptr;      // [kc][max_support]
+  double* obj_scratch_all = nullptr;  // [k][max_support] (deferred objective, supports too large for LDS); = obj_scratch if kc == k
   double* colres = nullptr;           // [kc][2]
-  double* vpartial = nullptr;         // [v_update_blocks][kc+1]
+  double* vpartial = nullptr;         // [vblocks][kc+1]  (column-sharded mode: lives in the tail of v_send, see vpartial_of)
   int vblocks = 0;
   int wpt_u = 1, wpt_v = 1;           // waves per tile in the fused epilogues (cooperative slab sum)
   bool fused_v = false, gram_v_done = false;
   // fused_v: the V epilogue straight from the sweep's slabs (one column block: single rank or replicated mode)
   bool graph_done = false;            // the pathway terms of this iteration were already computed in phase_u (merged launch)
 
-  // Deferred objective + sweep prologues (single rank, fused epilogues, tradeoff off; `lazy` is decided per batch in
-  // prmf_begin).  The iteration is then 4 launches: sweep X V [prologue: V^T V reduce + column norms / <Q,V> of the
-  // previous iteration] -> U epilogue -> sweep X^T U [prologue: U^T U reduce + pathway terms] -> V epilogue; what the
-  // objective record needs is kept per iteration in the rings below and evaluated for the whole batch in prmf_end.
+  // Deferred objective + sweep prologues (tradeoff off; `lazy` is decided per batch in prmf_begin).  One rank: the
+  // iteration is 4 launches: sweep X V [prologue: V^T V reduce + column norms / <Q,V> of the previous iteration] ->
+  // U epilogue (+ pathway terms) -> sweep X^T U [prologue: U^T U reduce] -> V epilogue; what the objective record
+  // needs is kept per iteration in the rings below and evaluated for the whole batch in prmf_end.  Several ranks: the
+  // same, with the V side split by the mode (replicated: dense-Q sum + fused V epilogue; column-sharded: dense-Q sum,
+  // own-column update, assemble / pack / Gram of the gathered V) -- see prmf_step_dist.
   bool lazy = false;
-  bool gv_pending = false;            // the V epilogue's V^T V partials / per-wave sums are not reduced yet
+  bool gv_pending = false;            // the V side's V^T V partials / per-workgroup sums are not reduced yet
   bool batch_open = false;
-  bool dist_driver = false;           // inside prmf_step_dist: collectives sit between the phases, keep the eager sequence
+  bool dist_driver = false;           // inside prmf_step_dist: the library issues the collectives itself
   int nparts_u = 0, nparts_v = 0;     // Gram partials the U / V side writes per iteration
   double* Gu_keep = nullptr;          // [MAX_RECORDS][k*k]
   double* Gv_keep = nullptr;          // [MAX_RECORDS][k*k]
   double* colnorm2_ring = nullptr;    // [MAX_RECORDS][k]
   double* cross_ring = nullptr;       // [MAX_RECORDS]
-  double* extras_ring = nullptr;      // column-sharded mode: [MAX_RECORDS][nranks][3] gathered <Q,V>, manifold, ignore
-  bool lazy_cs = false;               // column-sharded mode with the records deferred to prmf_end (see prmf_begin)
   double* colres_ring = nullptr;      // [MAX_RECORDS][k][2]
   float* vsup_ring = nullptr;         // [MAX_RECORDS][k][max_support]   (allocated with the pathway library)
 
@@ -125,14 +130,6 @@ struct prmf_ctx {
   std::vector<hipEvent_t> ev_phase;    // [MAX_RECORDS][5]: iteration start, after phase_u, phase_q (+ exchange), phase_v (+ exchange), phase_post
   double ms_phase[4] = {0, 0, 0, 0};
   int phase_timed_iters = 0;
-
-  // Auxiliary stream: in the multi-rank step the latency-bound k x k all-reduce of U^T U runs here next to the
-  // X^T U sweep and is joined before phase_v (prmf_step_dist).  (Round 1 could also move the single-rank small
-  // kernels here; every cross-stream event edge cost ~5 us, more than it hid -- they are sweep prologues now.)
-  hipStream_t aux = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_post = nullptr;
-  bool internal_driver = false;
-  bool mid_pending = false, post_pending = false;
 
   // RCCL (resolved at run time, see prmf_comm_init)
   ncclComm_t comm = nullptr;
@@ -164,6 +161,8 @@ struct RcclApi {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;        // optional (reporting only)
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;     // optional
+  ncclResult_t (*GroupStart)() = nullptr;                             // optional: without them the two exchanges after
+  ncclResult_t (*GroupEnd)() = nullptr;                               //   phase_q are two launches instead of one
   bool ok = false;
 };
 RcclApi& rccl() {
@@ -185,6 +184,8 @@ RcclApi& rccl() {
     PRMF_SYM(GetErrorString, "ncclGetErrorString");
     PRMF_SYM(CommCount, "ncclCommCount");
     PRMF_SYM(CommUserRank, "ncclCommUserRank");
+    PRMF_SYM(GroupStart, "ncclGroupStart");
+    PRMF_SYM(GroupEnd, "ncclGroupEnd");
 #undef PRMF_SYM
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.ReduceScatter && a.AllGather && a.GetErrorString;
     return a;
@@ -296,11 +297,18 @@ SweepPrologue post_prologue(prmf_ctx* c, int it) {
   p.k = c->k;
   p.G = c->Gv;
   p.G_keep = c->Gv_keep + (size_t)slot * c->k * c->k;
-  if (!c->lazy_cs) {                   // (column-sharded: these sums come with the all-gather, see extras_ring)
+  p.colnorm2 = c->colnorm2_ring + (size_t)slot * c->k;
+  p.cross = c->cross_ring + slot;
+  if (c->fused_v) {
     p.vpartial = c->vpartial;
     p.nwaves = c->vblocks;
-    p.colnorm2 = c->colnorm2_ring + (size_t)slot * c->k;
-    p.cross = c->cross_ring + slot;
+  } else {                             // column-sharded: every rank's sums arrived in the tail of its all-gather block
+    p.gath = c->v_recv;
+    p.gath_stride = c->v_send_floats;
+    p.gath_off = c->partial_off;
+    p.gath_nblk = c->vblocks;
+    p.gath_kc = c->kc;
+    p.gath_nranks = c->lr;
   }
   if (c->nranks > 1) {                 // multi-rank: the kept U^T U is the all-reduced one
     p.gu_src = c->gram_buf;
@@ -402,12 +410,14 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   c->nranks = nranks;
   c->rank = rank;
   c->flags = flags;
-  c->replicated = nranks > 1 && !(flags & PRMF_FLAG_COLUMN_SHARDED);
+  c->replicated = nranks > 1 && (flags & PRMF_FLAG_REPLICATED);
   c->lr = c->replicated ? 1 : nranks;
   c->kc = (k + c->lr - 1) / c->lr;
   c->col0 = (c->replicated ? 0 : rank) * c->kc;
   c->ncols = c->col0 >= k ? 0 : (c->col0 + c->kc <= k ? c->kc : k - c->col0);
-  c->extras_off = round_up(n * c->kc, 2);
+  c->fused_v = c->lr == 1;
+  c->partial_off = round_up(n * c->kc, 2);
+  c->extras_off = c->partial_off + (c->fused_v ? 0 : 2 * (int64_t)v_update_blocks(n) * (c->kc + 1));
   c->v_send_floats = c->extras_off + 8;
   int rc = PRMF_OK;
   auto bail = [&](int code) {
@@ -456,11 +466,11 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, &c->Gv, (size_t)k * k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->active_dev, (size_t)k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->pos, (size_t)n * c->kc, false))) return bail(rc);
-  c->fused_v = c->lr == 1;
   c->wpt_u = epilogue_wpt(c->Kpad_xt, c->plan_xv.max_seg, c->NT);
   c->wpt_v = epilogue_wpt(c->Kpad_x, c->plan_xtu.max_seg, c->NT);
   c->vblocks = c->fused_v ? v_epilogue_waves(n, c->wpt_v) : v_update_blocks(n);
-  if ((rc = dev_alloc(c, &c->vpartial, (size_t)c->vblocks * (c->kc + 1)))) return bail(rc);
+  if (c->fused_v && (rc = dev_alloc(c, &c->vpartial, (size_t)c->vblocks * (c->kc + 1)))) return bail(rc);
+  if (!c->fused_v && (rc = dev_alloc(c, &c->pos_all, (size_t)n * k, false))) return bail(rc);
   if ((rc = dev_alloc(c, &c->colres, (size_t)c->kc * 2))) return bail(rc);
   if ((rc = dev_alloc(c, &c->hyper, 4))) return bail(rc);
   if ((rc = dev_alloc(c, &c->records, (size_t)MAX_RECORDS * PRMF_OBJ_STRIDE))) return bail(rc);
@@ -468,27 +478,14 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, &c->need_dev, 2))) return bail(rc);
   if ((rc = dev_alloc(c, &c->resid_partial, (size_t)4 * RESIDUAL_MAX_BLOCKS))) return bail(rc);
   if ((rc = dev_alloc(c, &c->resid_sq, 2))) return bail(rc);
-  if (nranks > 1 && !c->replicated && 3 * nranks <= 256 &&
-      (rc = dev_alloc(c, &c->extras_ring, (size_t)MAX_RECORDS * nranks * 3))) return bail(rc);
-  {
-    if ((rc = dev_alloc(c, &c->Gu_keep, (size_t)(MAX_RECORDS + 1) * k * k, false))) return bail(rc);
-    if ((rc = dev_alloc(c, &c->Gv_keep, (size_t)(MAX_RECORDS + 1) * k * k, false))) return bail(rc);
-  }
-  if (nranks == 1 || c->replicated) {
-    if ((rc = dev_alloc(c, &c->colnorm2_ring, (size_t)(MAX_RECORDS + 1) * k))) return bail(rc);
-    if ((rc = dev_alloc(c, &c->cross_ring, (size_t)MAX_RECORDS + 1))) return bail(rc);
-    if ((rc = dev_alloc(c, &c->colres_ring, (size_t)MAX_RECORDS * k * 2))) return bail(rc);
-  }
+  if ((rc = dev_alloc(c, &c->Gu_keep, (size_t)(MAX_RECORDS + 1) * k * k, false))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->Gv_keep, (size_t)(MAX_RECORDS + 1) * k * k, false))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->colnorm2_ring, (size_t)(MAX_RECORDS + 1) * k))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->cross_ring, (size_t)MAX_RECORDS + 1))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->colres_ring, (size_t)MAX_RECORDS * k * 2))) return bail(rc);
   if (hipHostMalloc((void**)&c->hyper_host, 4 * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&c->records_host, (size_t)MAX_RECORDS * PRMF_OBJ_STRIDE * sizeof(double)) != hipSuccess) {
     fail(c, PRMF_ERR_HIP, "hipHostMalloc failed");
-    return bail(PRMF_ERR_HIP);
-  }
-  if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming) != hipSuccess) {
-    fail(c, PRMF_ERR_HIP, "aux stream / events could not be created");
     return bail(PRMF_ERR_HIP);
   }
   if ((flags & PRMF_FLAG_TIMING) && (rc = prmf_set_timing(c, 1))) return bail(rc);
@@ -519,15 +516,13 @@ int prmf_destroy(prmf_ctx* c) {
     }
   }
   if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
-  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
-  if (c->ev_post) (void)hipEventDestroy(c->ev_post);
-  if (c->aux) (void)hipStreamDestroy(c->aux);
   for (void* p : c->lib_allocs) dev_free(p);
   dev_free(c->active_dev);
   dev_free(c->pos);
+  dev_free(c->pos_all);
   dev_free(c->gnum);
   dev_free(c->gden);
+  if (c->obj_scratch_all != c->obj_scratch) dev_free(c->obj_scratch_all);
   dev_free(c->obj_scratch);
   dev_free(c->colres);
   dev_free(c->vpartial);
@@ -541,7 +536,6 @@ int prmf_destroy(prmf_ctx* c) {
   dev_free(c->Gv_keep);
   dev_free(c->colnorm2_ring);
   dev_free(c->cross_ring);
-  dev_free(c->extras_ring);
   dev_free(c->colres_ring);
   dev_free(c->vsup_ring);
   dev_free(c->scores_dev);
@@ -612,6 +606,8 @@ int prmf_set_pathway_library(prmf_ctx* c, int P, const int64_t* sup_ptr, const i
   c->lib_allocs.clear();
   dev_free(c->gnum); c->gnum = nullptr;
   dev_free(c->gden); c->gden = nullptr;
+  if (c->obj_scratch_all != c->obj_scratch) dev_free(c->obj_scratch_all);
+  c->obj_scratch_all = nullptr;
   dev_free(c->obj_scratch); c->obj_scratch = nullptr;
   dev_free(c->vsup_ring); c->vsup_ring = nullptr;
   c->have_lib = false;
@@ -654,7 +650,9 @@ int prmf_set_pathway_library(prmf_ctx* c, int P, const int64_t* sup_ptr, const i
   if ((rc = dev_alloc(c, &c->gnum, (size_t)c->kc * max_sup))) return rc;
   if ((rc = dev_alloc(c, &c->gden, (size_t)c->kc * max_sup))) return rc;
   if ((rc = dev_alloc(c, &c->obj_scratch, (size_t)c->kc * max_sup))) return rc;
-  if ((c->nranks == 1 || c->replicated) && (rc = dev_alloc(c, &c->vsup_ring, (size_t)MAX_RECORDS * c->k * max_sup))) return rc;
+  c->obj_scratch_all = c->obj_scratch;
+  if (c->kc != c->k && (rc = dev_alloc(c, &c->obj_scratch_all, (size_t)c->k * max_sup))) return rc;
+  if ((rc = dev_alloc(c, &c->vsup_ring, (size_t)MAX_RECORDS * c->k * max_sup))) return rc;
   c->have_lib = true;
   return PRMF_OK;
 }
@@ -673,6 +671,7 @@ int prmf_set_active(prmf_ctx* c, const int32_t* k_to_lapl, void* stream) {
   // the k indices travel as kernel arguments: no staging buffer, no stream synchronisation
   HIP_TRY(c, launch_set_active(c->active_dev, k_to_lapl, c->k, s));
   HIP_TRY(c, launch_build_pos(c->lib, c->active_dev, c->col0, c->ncols, c->kc, c->n, c->pos, s));
+  if (c->pos_all) HIP_TRY(c, launch_build_pos(c->lib, c->active_dev, 0, c->k, c->k, c->n, c->pos_all, s));
   c->have_active = true;
   return PRMF_OK;
 }
@@ -733,24 +732,25 @@ int prmf_begin(prmf_ctx* c, float* dU, float* dV, double gamma, double delta, do
   HIP_TRY(c, launch_set_hyper(c->hyper, gamma, delta, tradeoff, s));   // kernel arguments: no staging, no sync
   c->cursor = 0;
   c->graph_done = false;
-  c->mid_pending = c->post_pending = false;
   if (!c->prepared && (rc = prepare(c, s))) return rc;
-  // objective deferred to prmf_end + reductions folded into the sweeps: single rank, fused MFMA epilogues, default
-  // 4-wave sweep workgroups, tradeoff feedback off (with it on, gamma/delta of step t+1 need the record of step t)
-  // Multi-rank, replicated mode: the same deferral (every rank holds all of V and the all-reduced U^T U and X^T U), but the
-  // U-side reduction stays a launch of its own right after the U epilogue so that the k x k all-reduce can run next to
-  // the X^T U sweep.  Column-sharded mode keeps the eager sequence (its objective pieces travel with the all-gather).
-  c->lazy = (c->nranks == 1 ? !c->dist_driver : c->replicated) && c->m > 0 && c->fused_v && !(tradeoff >= 0.0) &&
-            c->plan_xv.nw == 4 && c->plan_xtu.nw == 4 && c->vsup_ring && !(c->flags & (PRMF_FLAG_EAGER_OBJECTIVE | PRMF_FLAG_DIRECT_RESIDUAL));
-  // Column-sharded mode: the update sequence stays as it is (its objective pieces travel with the all-gather), but the
-  // record of an iteration is not needed before prmf_end unless the tradeoff feedback is on: V^T V is then reduced by
-  // the next X V sweep's prologue and the records of the batch come from one launch at the end (2 launches fewer per
-  // iteration).  Decided per rank; the collectives do not depend on it.
-  c->lazy_cs = c->nranks > 1 && !c->replicated && c->m > 0 && c->NT <= 2 && !(tradeoff >= 0.0) &&
-               c->plan_xv.nw == 4 && c->extras_ring && !(c->flags & (PRMF_FLAG_EAGER_OBJECTIVE | PRMF_FLAG_DIRECT_RESIDUAL));
+  // Objective deferred to prmf_end + reductions folded into the sweeps' prologues: whenever the tradeoff feedback is
+  // off (with it on, gamma / delta of step t + 1 need the record of step t) -- one rank and both multi-rank modes.
+  // Decided per rank; the exchanges do not depend on it.
+  c->lazy = !(tradeoff >= 0.0) && c->plan_xv.nw == 4 && c->plan_xtu.nw == 4 && c->vsup_ring &&
+            !(c->flags & (PRMF_FLAG_EAGER_OBJECTIVE | PRMF_FLAG_DIRECT_RESIDUAL));
   c->batch_open = true;
   return PRMF_OK;
 }
+
+namespace {
+double* vpartial_of(const prmf_ctx* c) {     // per-workgroup sums of the V update: own buffer, or the tail of v_send
+  return c->fused_v ? c->vpartial : reinterpret_cast<double*>(c->v_send + c->partial_off);
+}
+// Does the X^T U sweep's prologue reduce this rank's U^T U partials?  One rank: always (deferred form).  Several ranks:
+// when the library issues the collectives itself -- the k x k all-reduce then follows the sweep, in one RCCL group with
+// the exchange of Q.  Host-driven phase calls all-reduce U^T U between phase_u and phase_q, so phase_u reduces it.
+bool gram_in_sweep(const prmf_ctx* c) { return c->lazy && c->m > 0 && (c->nranks == 1 || c->dist_driver); }
+}  // namespace
 
 int prmf_phase_u(prmf_ctx* c, void* stream) {
   int rc;
@@ -759,67 +759,43 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
   if (c->cursor >= MAX_RECORDS) return fail(c, PRMF_ERR_STATE, "more than %d iterations between prmf_begin and prmf_end", MAX_RECORDS);
   if ((rc = set_device(c))) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (c->m > 0) {
-    const bool timing = (c->flags & PRMF_FLAG_TIMING) != 0;
-    if ((c->lazy || c->lazy_cs) && c->gv_pending && c->cursor == 0) {   // cannot happen through prmf_begin/prmf_end; keep V^T V right anyway
-      HIP_TRY(c, launch_prologue_alone(post_prologue(c, -1), s));
+  if (c->m <= 0) {                     // a rank without samples: no sweep to host the V-side reductions
+    if (c->lazy && c->gv_pending) {
+      HIP_TRY(c, launch_prologue_alone(post_prologue(c, c->cursor - 1), s));
       c->gv_pending = false;
-    }
-    SweepPrologue pro;
-    if ((c->lazy || c->lazy_cs) && c->gv_pending) {
-      pro = post_prologue(c, c->cursor - 1);
-      if (c->lazy_cs) c->gv_pending = false;
-    }
-    if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 0], s));
-    // P = X V                                             (prmf_runner.py:420)
-    HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xv, c->X, c->ldx, c->m, c->Vp, c->NT, c->slabs, c->slab_stride_p, s, c->split_f32,
-                           pro.kind != PROLOGUE_NONE ? &pro : nullptr));
-    if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 1], s));
-    // U <- U * P / (U Gv + U)                              (:421-422)
-    FactorView fu{c->U, (int)c->m, c->k, c->k, 0};
-    if (c->lazy) {
-      c->gv_pending = false;
-      bool gram_done = false;
-      const GraphJob gj = graph_job(c);   // the pathway terms ride in the U epilogue launch (extra workgroups)
-      HIP_TRY(c, launch_u_epilogue(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP,
-                                   c->Gv, c->pack_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, c->wpt_u, s, &gj));
-      c->nparts_u = epilogue_blocks(c->Kpad_xt, c->wpt_u);
-      if (!gram_done) {                // k > 64: the epilogue has no registers left for the Gram tiles
-        HIP_TRY(c, launch_gram_partials(fu, (float*)c->gram_partial, s));
-        c->nparts_u = gram_blocks(fu.rows);
-      }
-      c->graph_done = true;
-      if (c->nranks > 1)               // the caller all-reduces U^T U next: reduce the local partials now
-        HIP_TRY(c, launch_mid((const float*)c->gram_partial, c->nparts_u, c->k, c->gram_buf, c->lib, c->active_dev, c->col0,
-                              0, c->V, c->hyper, c->gnum, c->gden, s));
-      return PRMF_OK;                  // one rank: U^T U and the pathway terms come from the X^T U sweep's prologue
-    }
-    if (c->post_pending) {            // V^T V (and gamma/delta) of the previous iteration come from the aux stream
-      HIP_TRY(c, hipStreamWaitEvent(s, c->ev_post, 0));
-      c->post_pending = false;
-    }
-    {
-      bool gram_done = false;
-      // the pathway terms of the own columns (they depend on the old V and gamma/delta only) ride in the U epilogue
-      // launch as extra workgroups; `mid` then only reduces (this rank's) U^T U
-      const GraphJob gj = graph_job(c);
-      HIP_TRY(c, launch_u_epilogue(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP,
-                                   c->Gv, c->pack_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, c->wpt_u, s, &gj));
-      c->graph_done = true;
-      if (gram_done) {
-        HIP_TRY(c, launch_mid((const float*)c->gram_partial, epilogue_blocks(c->Kpad_xt, c->wpt_u), c->k, c->gram_buf, c->lib,
-                              c->active_dev, c->col0, 0, c->V, c->hyper, c->gnum, c->gden, s));
-        return PRMF_OK;
-      }
-    }
-    HIP_TRY(c, launch_gram(fu, c->gram_partial, c->gram_buf, s));
-  } else {
-    if (c->post_pending) {
-      HIP_TRY(c, hipStreamWaitEvent(s, c->ev_post, 0));
-      c->post_pending = false;
     }
     HIP_TRY(c, hipMemsetAsync(c->gram_buf, 0, (size_t)c->k * c->k * sizeof(double), s));
+    return PRMF_OK;
   }
+  const bool timing = (c->flags & PRMF_FLAG_TIMING) != 0;
+  if (c->lazy && c->gv_pending && c->cursor == 0) {   // cannot happen through prmf_begin/prmf_end; keep V^T V right anyway
+    HIP_TRY(c, launch_prologue_alone(post_prologue(c, -1), s));
+    c->gv_pending = false;
+  }
+  SweepPrologue pro;
+  if (c->lazy && c->gv_pending) pro = post_prologue(c, c->cursor - 1);
+  if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 0], s));
+  // P = X V                                             (prmf_runner.py:420)
+  HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xv, c->X, c->ldx, c->m, c->Vp, c->NT, c->slabs, c->slab_stride_p, s, c->split_f32,
+                         pro.kind != PROLOGUE_NONE ? &pro : nullptr));
+  if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 1], s));
+  c->gv_pending = false;
+  // U <- U * P / (U Gv + U)                              (:421-422); the pathway terms of the own columns (they depend on
+  // the old V and gamma / delta only) ride in the same launch as extra workgroups
+  FactorView fu{c->U, (int)c->m, c->k, c->k, 0};
+  bool gram_done = false;
+  const GraphJob gj = graph_job(c);
+  HIP_TRY(c, launch_u_epilogue(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP,
+                               c->Gv, c->pack_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, c->wpt_u, s, &gj));
+  c->graph_done = true;
+  c->nparts_u = epilogue_blocks(c->Kpad_xt, c->wpt_u);
+  if (!gram_done) {
+    HIP_TRY(c, launch_gram_partials(fu, (float*)c->gram_partial, s));
+    c->nparts_u = gram_blocks(fu.rows);
+  }
+  if (!gram_in_sweep(c))               // U^T U (this rank's) now: the per-iteration objective, or a host-driven all-reduce, reads it next
+    HIP_TRY(c, launch_mid((const float*)c->gram_partial, c->nparts_u, c->k, c->gram_buf, c->lib, c->active_dev, c->col0, 0, c->V,
+                          c->hyper, c->gnum, c->gden, s));
   return PRMF_OK;
 }
 
@@ -833,12 +809,12 @@ int prmf_phase_q(prmf_ctx* c, void* stream) {
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 2], s));
     // Q = X^T U_new                                       (:424)
     SweepPrologue pro;
-    const bool mid_in_sweep = c->lazy && c->nranks == 1;
-    if (mid_in_sweep) pro = mid_prologue(c, c->cursor);
+    const bool in_sweep = gram_in_sweep(c);
+    if (in_sweep) pro = mid_prologue(c, c->cursor);
     HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xtu, c->XT, c->ldxt, c->n, c->Up, c->NT, c->slabs, c->slab_stride_q, s, c->split_f32,
-                           mid_in_sweep ? &pro : nullptr));
+                           in_sweep ? &pro : nullptr));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 3], s));
-    // the replicated multi-rank mode all-reduces Q, so it needs the summed dense form even on the fused path
+    // both multi-rank modes exchange Q, so they need its summed dense form (by owner column block)
     if (!c->fused_v || c->replicated)
       HIP_TRY(c, launch_slab_sum_blocks(c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP, c->n, c->k, c->kc,
                                         c->lr, c->q_send, c->plan_xtu.max_seg, s));
@@ -853,47 +829,38 @@ int prmf_phase_v(prmf_ctx* c, void* stream) {
   if ((rc = check_ready(c))) return rc;
   if ((rc = set_device(c))) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (c->mid_pending) {               // U^T U and the pathway terms were computed next to the X^T U sweep
-    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_mid, 0));
-    c->mid_pending = false;
-  }
-  if (c->lazy) {
-    // pathway terms and U^T U came from the sweep's prologue; the objective pieces are deferred to prmf_end
+  // sparse pathway terms on the OLD V                    (:431-438) -- normally done next to the U epilogue
+  if (!c->graph_done)
+    HIP_TRY(c, launch_graph_terms(c->lib, c->active_dev, c->col0, c->ncols, c->V, c->k, c->hyper, c->gnum, c->gden, s));
+  c->graph_done = false;
+  // V_own <- V * (Q + gnum) / max(V Gu + gden, eps)      (:425, :440-444)
+  if (c->fused_v) {
+    // one column block (single rank / replicated): V updated in place straight from the sweep's slabs (or the all-reduced
+    // dense Q), packed for the next sweep in the same pass; deferred objective: V_new on the supports goes to the ring
     HIP_TRY(c, launch_v_epilogue(c->V, c->n, c->k, c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP,
                                  c->gram_buf, c->pos, c->gnum, c->gden, c->lib.max_support, c->pack_dtype, c->Vp, c->Kpad_x,
                                  c->vpartial, (float*)c->gram_partial, &c->gram_v_done, c->replicated ? c->q_recv : nullptr,
-                                 c->vsup_ring + (size_t)c->cursor * c->k * c->lib.max_support, c->wpt_v, s));
-    c->graph_done = false;
+                                 c->lazy ? c->vsup_ring + (size_t)c->cursor * c->k * c->lib.max_support : nullptr, c->wpt_v, s));
     c->nparts_v = epilogue_blocks(c->Kpad_x, c->wpt_v);
     if (!c->gram_v_done) {
       FactorView fv{c->V, (int)c->n, c->k, c->k, 0};
       HIP_TRY(c, launch_gram_partials(fv, (float*)c->gram_partial, s));
       c->nparts_v = gram_blocks(fv.rows);
+      c->gram_v_done = true;
     }
-    c->gv_pending = true;
-    return PRMF_OK;
+    if (c->lazy) {
+      c->gv_pending = true;
+      return PRMF_OK;
+    }
+    return PRMF_OK;                    // per-iteration form: phase_post reduces V^T V and writes the record
   }
-  // sparse pathway terms on the OLD V                    (:431-438)
-  if (!c->graph_done)
-    HIP_TRY(c, launch_graph_terms(c->lib, c->active_dev, c->col0, c->ncols, c->V, c->k, c->hyper, c->gnum, c->gden, s));
-  c->graph_done = false;
-  // V_own <- V * (Q + gnum) / max(V Gu + gden, eps)      (:425, :440-444)
-  double* extras = reinterpret_cast<double*>(c->v_send + c->extras_off);
-  if (c->fused_v) {
-    // single rank: V updated in place straight from the sweep's slabs, packed for the next sweep in the same pass
-    HIP_TRY(c, launch_v_epilogue(c->V, c->n, c->k, c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP,
-                                 c->gram_buf, c->pos, c->gnum, c->gden, c->lib.max_support, c->pack_dtype, c->Vp, c->Kpad_x,
-                                 c->vpartial, (float*)c->gram_partial, &c->gram_v_done,
-                                 c->replicated ? c->q_recv : nullptr, nullptr, c->wpt_v, s));
-    if (!c->gram_v_done)   // otherwise the objective pieces ride along with the V^T V reduction in phase_post
-      HIP_TRY(c, launch_objective_terms(c->lib, c->active_dev, 0, c->k, c->k, c->n, c->V, c->vpartial, c->vblocks, c->colres,
-                                        c->obj_scratch, extras, s));
-    return PRMF_OK;
-  }
+  // column-sharded: the own columns into this rank's all-gather block, its per-workgroup sums into the block's tail
+  double* vp = vpartial_of(c);
   HIP_TRY(c, launch_v_update(c->V, c->n, c->k, c->col0, c->ncols, c->kc, c->q_recv, c->gram_buf, c->pos, c->gnum, c->gden,
-                             c->lib.max_support, c->v_send, c->vpartial, s));
-  HIP_TRY(c, launch_objective_terms(c->lib, c->active_dev, c->col0, c->ncols, c->kc, c->n, c->v_send, c->vpartial,
-                                    c->vblocks, c->colres, c->obj_scratch, extras, s));
+                             c->lib.max_support, c->v_send, vp, s));
+  if (!c->lazy)                        // per-iteration objective: this rank's <Q,V>, manifold, ignore travel too
+    HIP_TRY(c, launch_objective_terms(c->lib, c->active_dev, c->col0, c->ncols, c->kc, c->n, c->v_send, vp, c->vblocks, c->colres,
+                                      c->obj_scratch, reinterpret_cast<double*>(c->v_send + c->extras_off), s));
   return PRMF_OK;
 }
 
@@ -903,44 +870,35 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
   if ((rc = set_device(c))) return rc;
   if (c->cursor >= MAX_RECORDS) return fail(c, PRMF_ERR_STATE, "more than %d iterations between prmf_begin and prmf_end", MAX_RECORDS);
   hipStream_t s = (hipStream_t)stream;
-  if (c->lazy) {                       // nothing to launch: the next X V sweep (or prmf_end) closes this iteration
-    c->cursor++;
-    return PRMF_OK;
-  }
   FactorView fv{c->V, (int)c->n, c->k, c->k, 0};
   if (!c->fused_v) {
-    {
-      bool gram_done = false;
-      HIP_TRY(c, launch_v_post(c->V, c->n, c->k, c->v_recv, c->v_send_floats, c->kc, c->KP, c->pack_dtype, c->Vp, c->Kpad_x,
-                               (float*)c->gram_partial, &gram_done, s,
-                               c->lazy_cs ? c->extras_ring + (size_t)c->cursor * c->lr * 3 : nullptr, c->lr, c->extras_off));
-      if (gram_done && c->lazy_cs) {   // V^T V: the next X V sweep's prologue (or prmf_end); record: prmf_end
-        c->nparts_v = epilogue_blocks(c->Kpad_x);
-        c->gv_pending = true;
-        c->cursor++;
-        return PRMF_OK;
-      }
-      if (gram_done) {
-        HIP_TRY(c, launch_gram_reduce((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x), c->k, c->Gv, s));
-        if ((rc = finalize_record(c, nullptr, 0, nullptr, s))) return rc;
-        c->cursor++;
-        return PRMF_OK;
-      }
+    // column-sharded: the gathered column blocks -> replicated V, packed fragments, V^T V partials, and (deferred
+    // objective) V_new on the active supports of all k columns
+    bool gram_done = false;
+    HIP_TRY(c, launch_v_post(c->V, c->n, c->k, c->v_recv, c->v_send_floats, c->kc, c->KP, c->pack_dtype, c->Vp, c->Kpad_x,
+                             (float*)c->gram_partial, &gram_done, c->lazy ? c->pos_all : nullptr,
+                             c->lazy ? c->vsup_ring + (size_t)c->cursor * c->k * c->lib.max_support : nullptr, c->lib.max_support, s));
+    c->nparts_v = epilogue_blocks(c->Kpad_x);
+    if (!gram_done) {
+      HIP_TRY(c, launch_gram_partials(fv, (float*)c->gram_partial, s));
+      c->nparts_v = gram_blocks(fv.rows);
     }
-  }
-  if (c->fused_v && c->gram_v_done) {
-    // V^T V, the objective pieces and the record are first read by the NEXT iteration's U epilogue (and by
-    // prmf_end): next to the following X V sweep when driven internally
-    hipStream_t ps = s;
-    HIP_TRY(c, launch_post((const float*)c->gram_partial, epilogue_blocks(c->Kpad_x, c->wpt_v), c->k, c->Gv, c->lib, c->active_dev, c->V,
-                           c->vpartial, c->vblocks, c->colres, c->obj_scratch, ps));
-    if ((rc = finalize_record(c, c->vpartial, c->vblocks, c->colres, ps))) return rc;
+    if (!c->lazy) {
+      HIP_TRY(c, launch_gram_reduce((const float*)c->gram_partial, c->nparts_v, c->k, c->Gv, s));
+      if ((rc = finalize_record(c, nullptr, 0, nullptr, s))) return rc;
+    } else {
+      c->gv_pending = true;            // V^T V + the gathered sums: the next X V sweep's prologue, or prmf_end
+    }
     c->cursor++;
     return PRMF_OK;
   }
-  HIP_TRY(c, launch_gram(fv, c->gram_partial, c->Gv, s));
-  if ((rc = finalize_record(c, nullptr, 0, nullptr, s))) return rc;
-  c->cursor++;
+  if (!c->lazy) {
+    // per-iteration form: V^T V, the objective pieces of all columns and the record (+ tradeoff feedback)
+    HIP_TRY(c, launch_post((const float*)c->gram_partial, c->nparts_v, c->k, c->Gv, c->lib, c->active_dev, c->V,
+                           c->vpartial, c->vblocks, c->colres, c->obj_scratch, s));
+    if ((rc = finalize_record(c, c->vpartial, c->vblocks, c->colres, s))) return rc;
+  }
+  c->cursor++;                         // deferred form: nothing to launch, the next X V sweep (or prmf_end) closes the iteration
   return PRMF_OK;
 }
 
@@ -950,9 +908,6 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
   int rc;
   if ((rc = set_device(c))) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (c->mid_pending) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_mid, 0));
-  if (c->post_pending) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_post, 0));
-  c->mid_pending = c->post_pending = false;
   if (c->lazy) {
     if (c->gv_pending) {               // no sweep follows the last iteration: its V side is closed by a launch of its own
       HIP_TRY(c, launch_prologue_alone(post_prologue(c, c->cursor - 1), s));
@@ -960,21 +915,11 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
     }
     // the objective records of the whole batch (prmf_runner.py:336-372), two launches
     HIP_TRY(c, launch_objective_all(c->lib, c->active_dev, c->k, c->cursor, c->colnorm2_ring, c->vsup_ring, c->colres_ring,
-                                    c->obj_scratch, s));
+                                    c->obj_scratch_all, s));
     const bool direct = direct_available(c) && c->cursor > 0;
     HIP_TRY(c, launch_records_all(c->Gu_keep, c->Gv_keep, c->k, c->cursor, c->cross_ring, c->colres_ring, c->norm_x_sq, c->hyper,
                                   c->records, direct ? c->need_dev : nullptr, false, direct_below(c), s));
     // the last record of the batch is the one the outer loop acts on: direct residual if its identity value is too small
-    if (direct && (rc = direct_residual(c, c->records + (size_t)(c->cursor - 1) * PRMF_OBJ_STRIDE, false, s))) return rc;
-  }
-  if (c->lazy_cs) {
-    if (c->gv_pending) {
-      HIP_TRY(c, launch_prologue_alone(post_prologue(c, c->cursor - 1), s));
-      c->gv_pending = false;
-    }
-    const bool direct = direct_available(c) && c->cursor > 0;
-    HIP_TRY(c, launch_finalize_batch(c->Gu_keep, c->Gv_keep, c->k, c->cursor, c->extras_ring, c->lr, c->norm_x_sq, c->hyper,
-                                     c->records, direct ? c->need_dev : nullptr, false, direct_below(c), s));
     if (direct && (rc = direct_residual(c, c->records + (size_t)(c->cursor - 1) * PRMF_OBJ_STRIDE, false, s))) return rc;
   }
   c->batch_open = false;
@@ -1010,15 +955,10 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
 int prmf_step(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma, double delta, double tradeoff,
               double* obj_out, double* gamma_delta_out, void* stream) {
   if (!c) return PRMF_ERR_ARG;
-  if (c->nranks != 1) return fail(c, PRMF_ERR_STATE, "prmf_step is the single-rank form; use the phase calls with nranks > 1");
+  if (c->nranks != 1) return fail(c, PRMF_ERR_STATE, "prmf_step is the single-rank form; use prmf_step_dist or the phase calls with nranks > 1");
   if (n_steps < 0) return fail(c, PRMF_ERR_ARG, "n_steps < 0");
   int done = 0;
   int rc;
-  struct Internal {
-    prmf_ctx* c;
-    explicit Internal(prmf_ctx* c_) : c(c_) { c->internal_driver = true; }
-    ~Internal() { c->internal_driver = false; }
-  } internal(c);
   while (done < n_steps || (n_steps == 0 && done == 0)) {
     int batch = n_steps - done < MAX_RECORDS ? n_steps - done : MAX_RECORDS;
     if ((rc = prmf_begin(c, dU, dV, gamma, delta, tradeoff, stream))) return rc;
@@ -1076,12 +1016,12 @@ int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma,
   if (n_steps < 0) return fail(c, PRMF_ERR_ARG, "n_steps < 0");
   hipStream_t s = (hipStream_t)stream;
   const RcclApi& N = rccl();
-  const bool overlap = c->aux != nullptr;
+  const bool grouped = N.GroupStart && N.GroupEnd;
   int done = 0, rc;
   struct Internal {
     prmf_ctx* c;
-    explicit Internal(prmf_ctx* c_) : c(c_) { c->internal_driver = c->dist_driver = true; }
-    ~Internal() { c->internal_driver = c->dist_driver = false; }
+    explicit Internal(prmf_ctx* c_) : c(c_) { c->dist_driver = true; }
+    ~Internal() { c->dist_driver = false; }
   } internal(c);
   while (done < n_steps) {
     const int batch = n_steps - done < MAX_RECORDS ? n_steps - done : MAX_RECORDS;
@@ -1092,35 +1032,24 @@ int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma,
       if (ptime) HIP_TRY(c, hipEventRecord(c->ev_phase[pe + 0], s));
       if ((rc = prmf_phase_u(c, stream))) return rc;
       if (ptime) HIP_TRY(c, hipEventRecord(c->ev_phase[pe + 1], s));
-      // The k x k all-reduce is latency-bound and its result is first needed by phase_v: it runs on the side
-      // stream next to the X^T U sweep (which depends only on the local U) and is joined before phase_v.
-      if (c->mid_pending) {
-        // the Gram reduction already runs on the aux stream: the all-reduce follows it there
-        NCCL_TRY(c, N.AllReduce(c->gram_buf, c->gram_buf, (size_t)c->k * c->k, ncclFloat64, ncclSum, c->comm, c->aux));
-        HIP_TRY(c, hipEventRecord(c->ev_mid, c->aux));          // phase_v joins on this
-      } else if (overlap) {
-        HIP_TRY(c, hipEventRecord(c->ev_fork, s));
-        HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-        NCCL_TRY(c, N.AllReduce(c->gram_buf, c->gram_buf, (size_t)c->k * c->k, ncclFloat64, ncclSum, c->comm, c->aux));
-        HIP_TRY(c, hipEventRecord(c->ev_mid, c->aux));
-        c->mid_pending = true;
-      } else {
-        NCCL_TRY(c, N.AllReduce(c->gram_buf, c->gram_buf, (size_t)c->k * c->k, ncclFloat64, ncclSum, c->comm, s));
-      }
       if ((rc = prmf_phase_q(c, stream))) return rc;
-      if (c->replicated) {
-        // every rank gets the full Q and runs the fused single-rank V update on it: no third exchange
+      // Exchange 1, ONE RCCL group (one launch): the k x k all-reduce of U^T U (reduced locally by the X^T U sweep's
+      // prologue; first read by the V update) together with the exchange of Q -- reduce-scatter by owner column block,
+      // or all-reduce in place in the replicated mode.  The latency-bound 32 KB message rides with the bandwidth-bound
+      // one instead of waiting on a side stream for the persistent sweep grid to leave it a CU
+      // (profiles/r03_side_stream_cosched.txt).
+      if (grouped) NCCL_TRY(c, N.GroupStart());
+      NCCL_TRY(c, N.AllReduce(c->gram_buf, c->gram_buf, (size_t)c->k * c->k, ncclFloat64, ncclSum, c->comm, s));
+      if (c->replicated)
         NCCL_TRY(c, N.AllReduce(c->q_send, c->q_send, (size_t)c->n * c->k, ncclFloat32, ncclSum, c->comm, s));
-        if (ptime) HIP_TRY(c, hipEventRecord(c->ev_phase[pe + 2], s));
-        if ((rc = prmf_phase_v(c, stream))) return rc;
-      } else {
-        if (c->nranks > 1 || c->q_recv != c->q_send)
-          NCCL_TRY(c, N.ReduceScatter(c->q_send, c->q_recv, (size_t)c->n * c->kc, ncclFloat32, ncclSum, c->comm, s));
-        if (ptime) HIP_TRY(c, hipEventRecord(c->ev_phase[pe + 2], s));
-        if ((rc = prmf_phase_v(c, stream))) return rc;
-        if (c->nranks > 1 || c->v_recv != c->v_send)
-          NCCL_TRY(c, N.AllGather(c->v_send, c->v_recv, (size_t)c->v_send_floats, ncclFloat32, c->comm, s));
-      }
+      else if (c->nranks > 1 || c->q_recv != c->q_send)
+        NCCL_TRY(c, N.ReduceScatter(c->q_send, c->q_recv, (size_t)c->n * c->kc, ncclFloat32, ncclSum, c->comm, s));
+      if (grouped) NCCL_TRY(c, N.GroupEnd());
+      if (ptime) HIP_TRY(c, hipEventRecord(c->ev_phase[pe + 2], s));
+      if ((rc = prmf_phase_v(c, stream))) return rc;
+      // Exchange 2 (column-sharded mode): all-gather of the updated own columns (+ their sums in the tail)
+      if (!c->replicated && (c->nranks > 1 || c->v_recv != c->v_send))
+        NCCL_TRY(c, N.AllGather(c->v_send, c->v_recv, (size_t)c->v_send_floats, ncclFloat32, c->comm, s));
       if (ptime) HIP_TRY(c, hipEventRecord(c->ev_phase[pe + 3], s));
       if ((rc = prmf_phase_post(c, stream))) return rc;
       if (ptime) HIP_TRY(c, hipEventRecord(c->ev_phase[pe + 4], s));

@@ -79,6 +79,12 @@ struct SweepPrologue {
   int nwaves = 0;
   double* colnorm2 = nullptr;           // [k]
   double* cross = nullptr;              // [1]
+  // column-sharded multi-rank mode: the V update's per-workgroup sums arrive with the all-gather instead -- rank r's block
+  // of the gathered buffer ends in [gath_nblk][gath_kc + 1] doubles (own-column sums of squares, <Q, V_new> last)
+  const float* gath = nullptr;          // v_recv
+  int64_t gath_stride = 0;              // floats per rank block
+  int64_t gath_off = 0;                 // float offset of the partials inside a block
+  int gath_nblk = 0, gath_kc = 0, gath_nranks = 0;
   const double* gu_src = nullptr;       // multi-rank: the ALL-REDUCED U^T U of the closed iteration (still in the exchange
   double* gu_keep = nullptr;            //   buffer) is copied to its kept slot here; null with one rank
   // PROLOGUE_MID (before X^T U): pathway terms of the V update on the old V
@@ -220,11 +226,10 @@ hipError_t launch_mid(const float* gram_partial, int nparts, int k, double* Gu, 
                       const int32_t* active_dev, int col0, int ncols, const float* V, const double* hyper, float* gnum,
                       float* gden, hipStream_t s);
 // multi-rank phase_post in one pass: gathered blocks -> V, packed fragments, V^T V partials
+//   pos_all / vsup (nullable): V_new on the active supports of ALL k columns for the deferred objective (pos_all: [n][k])
 hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_t blk_stride, int kc, int KP, int x_dtype,
-                         void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, hipStream_t s,
-                         double* extras_keep = nullptr, int nranks = 0, int64_t extras_off = 0);
-hipError_t launch_finalize_batch(const double* Gu_keep, const double* Gv_keep, int k, int n_it, const double* extras_ring,
-                                 int nranks, double norm_x_sq, double* hyper, double* records, int* need, bool force, double direct_below, hipStream_t s);
+                         void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, const int32_t* pos_all, float* vsup,
+                         int max_support, hipStream_t s);
 hipError_t launch_post(const float* gram_partial, int nparts, int k, double* Gv, const PathwayLibDev& lib,
                        const int32_t* active_dev, const float* V, const double* partial, int nblocks, double* colres,
                        double* scratch, hipStream_t s);

@@ -122,6 +122,27 @@ __device__ __forceinline__ void colcross_job(const double* __restrict__ vpartial
   }
 }
 
+// The same two sums in the column-sharded multi-rank mode, from the partials every rank's own-column V update appended
+// to its block of the all-gather: column c belongs to rank c / kc; <Q, V_new> is summed rank-major.
+__device__ __forceinline__ void colcross_gathered_job(const SweepPrologue& p, int c, double* red) {
+  if (c < p.k) {
+    const double* part = reinterpret_cast<const double*>(p.gath + (int64_t)(c / p.gath_kc) * p.gath_stride + p.gath_off);
+    double s = 0.0;
+    for (int b = threadIdx.x; b < p.gath_nblk; b += 256) s += part[(int64_t)b * (p.gath_kc + 1) + (c % p.gath_kc)];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) p.colnorm2[c] = s;
+    return;
+  }
+  double tot = 0.0;                    // per rank first, then the ranks in order: the order of the per-iteration form
+  for (int r = 0; r < p.gath_nranks; ++r) {
+    const double* part = reinterpret_cast<const double*>(p.gath + (int64_t)r * p.gath_stride + p.gath_off);
+    double s = 0.0;
+    for (int b = threadIdx.x; b < p.gath_nblk; b += 256) s += part[(int64_t)b * (p.gath_kc + 1) + p.gath_kc];
+    tot += block_sum_256(s, red);
+  }
+  if (threadIdx.x == 0) *p.cross = tot;
+}
+
 // The prologue a sweep launch runs before its main loop (see the header comment).  `lds` is scratch
 // of at least 2 KiB + 4 * max_support bytes for the LDS form of the pathway terms (else global gathers).
 __device__ __forceinline__ void run_sweep_prologue(const SweepPrologue& p, char* lds, int lds_bytes) {
@@ -131,9 +152,11 @@ __device__ __forceinline__ void run_sweep_prologue(const SweepPrologue& p, char*
   for (int j = blockIdx.x; j < nj; j += gridDim.x) gram_reduce_job(p.gram_partial, p.nparts, kk2, p.G, p.G_keep, j, red);
   if (p.kind == PROLOGUE_POST) {
     // workgroups from the far end of the grid first: at small k they are the ones without a Gram job
-    if (p.vpartial)                  // column-sharded multi-rank mode: these sums arrive with the all-gather instead
+    if (p.vpartial)
       for (int c = (int)(gridDim.x - 1 - blockIdx.x); c <= p.k; c += gridDim.x)
         colcross_job(p.vpartial, p.nwaves, p.k, c, p.colnorm2, p.cross, red);
+    else if (p.gath)                 // column-sharded multi-rank mode: the sums arrived with the all-gather
+      for (int c = (int)(gridDim.x - 1 - blockIdx.x); c <= p.k; c += gridDim.x) colcross_gathered_job(p, c, red);
     if (p.gu_keep)
       for (int e = (int)(blockIdx.x * 256 + threadIdx.x); e < kk2; e += (int)(gridDim.x * 256)) p.gu_keep[e] = p.gu_src[e];
   } else if (p.kind == PROLOGUE_MID) {

@@ -1089,10 +1089,8 @@ template <int NT, bool GRAM>
 __global__ void __launch_bounds__(256)
 v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ v_recv, int64_t blk_stride, int kc,
               void* __restrict__ packed, int64_t ntiles_pack, float* __restrict__ gram_partial,
-              double* __restrict__ extras_keep /* null or [nranks][3] */, int nranks, int64_t extras_off) {
+              const int32_t* __restrict__ pos_all /* null or [n][k] */, float* __restrict__ vsup /* [k][max_support] */, int max_support) {
   constexpr int NP = NT * (NT + 1) / 2;
-  if (extras_keep && blockIdx.x == 0 && (int)threadIdx.x < 3 * nranks)   // deferred records: <Q,V>, manifold, ignore of every rank
-    extras_keep[threadIdx.x] = reinterpret_cast<const double*>(v_recv + (int64_t)(threadIdx.x / 3) * blk_stride + extras_off)[threadIdx.x % 3];
   __shared__ float red[GRAM ? 4 : 1][16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
@@ -1119,6 +1117,10 @@ v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__
         if (row < n && col < k) {
           v = v_recv[cb + row * kc];
           V[row * k + col] = v;
+          if (pos_all) {             // V_new on the active supports, for the deferred objective (prmf_end)
+            const int ps = pos_all[row * k + col];
+            if (ps >= 0) vsup[(unsigned)col * (unsigned)max_support + (unsigned)ps] = v;
+          }
         }
         vn[t][i] = v;
       }
@@ -1132,15 +1134,15 @@ v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__
 }
 
 hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_t blk_stride, int kc, int KP, int x_dtype,
-                         void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, hipStream_t s,
-                         double* extras_keep, int nranks, int64_t extras_off) {
-  if ((extras_keep && 3 * nranks > 256) || x_dtype != 1) return hipErrorInvalidValue;
+                         void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, const int32_t* pos_all, float* vsup,
+                         int max_support, hipStream_t s) {
+  if (x_dtype != 1 || (pos_all && !vsup)) return hipErrorInvalidValue;
   const int NT = KP / 32;
   const int64_t ntiles = Kpad / 32;
   const int grid = epilogue_blocks(Kpad);
   *gram_done = NT <= 2;
 #define PRMF_VPOST(NTV, GR)                                                                                      \
-  v_post_kernel<NTV, GR><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, extras_keep, nranks, extras_off)
+  v_post_kernel<NTV, GR><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, pos_all, vsup, max_support)
   switch (NT) {
     case 1: PRMF_VPOST(1, true); break;
     case 2: PRMF_VPOST(2, true); break;
@@ -1316,7 +1318,7 @@ hipError_t launch_graph_terms(const PathwayLibDev& lib, const int32_t* active_de
 // ---------------------------------------------------------------------------
 // V update for the own columns   (:424-425, :440-444)
 // ---------------------------------------------------------------------------
-constexpr int VUPD_MAX_BLOCKS = 1024;
+constexpr int VUPD_MAX_BLOCKS = 256;   // its per-workgroup sums travel in the tail of the all-gather: keep them few
 static inline int v_update_rt(int ncols) {
   int ncg = ((ncols + 3) & ~3) >> 2;
   if (ncg < 1) ncg = 1;
@@ -1543,16 +1545,10 @@ __global__ void __launch_bounds__(256)
 finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, int k, const float* __restrict__ v_recv,
                 int nranks, int64_t blk_stride, int64_t extras_off, double norm_x_sq, double* __restrict__ hyper,
                 double* __restrict__ record, const double* __restrict__ loc_partial, int loc_nblocks,
-                const double* __restrict__ loc_colres, const double* __restrict__ extras_ring /* batch form, else null */,
+                const double* __restrict__ loc_colres,
                 int* __restrict__ need /* nullable: direct-residual request (residual.hip) */, int force, double direct_below) {
   __shared__ double red[5][256];
   const int tid = threadIdx.x;
-  if (extras_ring) {                   // batch form (column-sharded mode, records deferred): workgroup = iteration
-    Gu += (size_t)blockIdx.x * k * k;
-    Gv += (size_t)blockIdx.x * k * k;
-    record += (size_t)blockIdx.x * REC_STRIDE;
-    extras_ring += (size_t)blockIdx.x * 3 * nranks;
-  }
   // five sums, one tree reduction (fixed order: deterministic)
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // <Gu,Gv>, trace Gu, cross, manifold, ignore
   for (int i = tid; i < k * k; i += 256) acc[0] += Gu[i] * Gv[i];
@@ -1580,8 +1576,7 @@ finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, in
     double cross = lcross, man = lman, ign = lign;
     if (!loc_partial)
       for (int r = 0; r < nranks; ++r) {
-        const double* ex = extras_ring ? extras_ring + 3 * r
-                                       : reinterpret_cast<const double*>(v_recv + (int64_t)r * blk_stride + extras_off);
+        const double* ex = reinterpret_cast<const double*>(v_recv + (int64_t)r * blk_stride + extras_off);
         cross += ex[0];
         man += ex[1];
         ign += ex[2];
@@ -1601,10 +1596,10 @@ finalize_kernel(const double* __restrict__ Gu, const double* __restrict__ Gv, in
     // the last record of a batch (every record in the per-iteration form) asks for the direct residual, which then
     // replaces recon / obj and drives the tradeoff feedback.  A negative value is never clamped silently.
     const bool low = recon_sq < direct_below;
-    const bool ask = need && (low || force) && (!extras_ring || blockIdx.x == gridDim.x - 1);
+    const bool ask = need && (low || force);
     record[REC_FLAGS] = (double)((low ? REC_FLAG_IMPRECISE : 0) | (recon_sq < 0.0 ? REC_FLAG_CLAMPED : 0));
     record[REC_RECON_SQ_IDENTITY] = recon_sq;
-    if (need && (!extras_ring || blockIdx.x == gridDim.x - 1)) *need = ask ? 1 : 0;
+    if (need) *need = ask ? 1 : 0;
     if (t >= 0.0 && !ask) {
       const double denom = t * man;
       const double g2 = (denom == 0.0) ? 1.0 : ((1.0 - t) * recon) / denom;
@@ -1619,17 +1614,7 @@ hipError_t launch_finalize(const double* Gu, const double* Gv, int k, const floa
                            const double* loc_partial, int loc_nblocks, const double* loc_colres, int* need, bool force,
                            double direct_below, hipStream_t s) {
   finalize_kernel<<<1, 256, 0, s>>>(Gu, Gv, k, v_recv, nranks, blk_stride, extras_off, norm_x_sq, hyper, record,
-                                    loc_partial, loc_nblocks, loc_colres, nullptr, need, force ? 1 : 0, direct_below);
-  return hipGetLastError();
-}
-
-// the records of `n_it` iterations at once from the kept Grams and rank extras (column-sharded mode, tradeoff off)
-hipError_t launch_finalize_batch(const double* Gu_keep, const double* Gv_keep, int k, int n_it, const double* extras_ring,
-                                 int nranks, double norm_x_sq, double* hyper, double* records, int* need, bool force,
-                                 double direct_below, hipStream_t s) {
-  if (n_it <= 0) return hipSuccess;
-  finalize_kernel<<<n_it, 256, 0, s>>>(Gu_keep, Gv_keep, k, nullptr, nranks, 0, 0, norm_x_sq, hyper, records, nullptr, 0,
-                                       nullptr, extras_ring, need, force ? 1 : 0, direct_below);
+                                    loc_partial, loc_nblocks, loc_colres, need, force ? 1 : 0, direct_below);
   return hipGetLastError();
 }
 

@@ -1,26 +1,29 @@
 """Multi-GPU form of the PRMF iteration: one process per GPU, X row-sharded,
 collectives over torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
 
-Replicated mode (default): every rank updates all of V with the fused single-rank
-kernels, two exchanges per iteration
+Column-sharded mode (default; BASELINE.json's partition): the k latent columns and
+their pathway Laplacians are sharded for the V-update, three exchanges
 
     phase_u   P = X_g V, U_g update, partial U_g^T U_g
         all_reduce(gram)                  k*k float64
-    phase_q   Q_g = X_g^T U_g  (n x k, this rank's rows of X only)
-        all_reduce(q_send)                n*k float32, in place
-    phase_v   V update (all columns) + objective pieces
-    phase_post  V^T V, objective record
+    phase_q   Q_g = X_g^T U_g by owner column block
+        reduce_scatter(q_send -> q_recv)  n*kc float32 per rank
+    phase_v   own-column V update, its per-workgroup sums in the block's tail
+        all_gather(v_send -> v_recv)      v_send_floats float32 per rank
+    phase_post  replicated V, packed V, V^T V partials
 
-Column-sharded mode (engine created with dist_mode="colshard"): the k latent
-columns and their pathway Laplacians are sharded for the V-update, three exchanges
+Replicated mode (engine created with dist_mode="replicated"): every rank updates all
+of V with the fused single-rank kernels, two exchanges
 
     phase_u   as above
         all_reduce(gram)                  k*k float64
-    phase_q   Q_g = X_g^T U_g by owner column block
-        reduce_scatter(q_send -> q_recv)  n*kc float32 per rank
-    phase_v   own-column V update + objective pieces
-        all_gather(v_send -> v_recv)      n*kc+8 float32 per rank
-    phase_post  replicated V, V^T V, objective record
+    phase_q   Q_g = X_g^T U_g  (n x k, this rank's rows of X only)
+        all_reduce(q_send)                n*k float32, in place
+    phase_v   V update (all columns)
+    phase_post  (nothing to launch)
+
+When the library issues the collectives itself (native=True: `prmf_step_dist`) the k x k
+all-reduce moves behind phase_q, into one RCCL group with the exchange of Q.
 
 The reference has no counterpart (single process, script/prmf_runner.py:419-449);
 the math of each phase is the same lines split by rows of X / columns of V.

@@ -11,7 +11,16 @@ Same flags, exit codes, stdout lines and output files as the reference CLI
 
 The solve itself is prmf_amd.solver.nmf_pathway (HIP kernels on the GPU).  Added
 flags (the reference's are unchanged): --x-dtype {f32,bf16}; --data also accepts a .npy matrix
-(samples x genes, no header: needs --nodelist).
+(samples x genes, no header: needs --nodelist); --n-gpus N / --dist-mode.
+
+Multi-GPU (one process per GPU, torch.distributed over RCCL): either start the script under the launcher yourself,
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 script/prmf_runner.py ...
+
+or pass --n-gpus 8, which does exactly that as a child process before this process has touched a GPU.  Every rank
+parses the same inputs; X is row-sharded over the ranks inside nmf_pathway, V is replicated; rank 0 is the only one
+that prints and writes U.csv / V.csv / obj.txt (U is gathered to it).  Without --seed rank 0 draws one and
+broadcasts it, so that all ranks consume identical legacy RNG streams in the host stages.
 
 Reference quirks that are kept on purpose: --delta,
 --tolerence, --node-attribute and --m-samples are parsed but unused; graph nodes
@@ -228,7 +237,7 @@ def hold_out(X, samples, fraction):
     return X[train], X[test], [samples[i] for i in train]
 
 
-def initial_factors(args, X, manifolds, nodelist):
+def initial_factors(args, X, manifolds, nodelist, write=True):
     """--manifolds-init: U0 / V0 from one pathway indicator per latent factor through two NNLS solves (:1022-1064);
     fewer than k given -> the rest drawn with random.sample, more -> np.random.choice (the reference's RNG calls)."""
     chosen = list(args.manifolds_init)
@@ -247,8 +256,9 @@ def initial_factors(args, X, manifolds, nodelist):
         us.append(u)
         vs.append(v_new)
     sys.stdout.write("Using the following manifolds for initialization:\n{}\n".format("\n".join(chosen)))
-    with open(os.path.join(args.outdir, 'init_pathways.txt'), 'w') as fh:
-        fh.write("\n".join(chosen))
+    if write:
+        with open(os.path.join(args.outdir, 'init_pathways.txt'), 'w') as fh:
+            fh.write("\n".join(chosen))
     return np.concatenate(us, axis=1), np.concatenate(vs, axis=1)
 
 
@@ -282,8 +292,58 @@ Solve an optimization problem of the form
     add_prmf_arguments(parser)
     parser.add_argument("--x-dtype", default="f32", choices=["f32", "bf16"],
                         help="storage type of X on the GPU (bf16 halves the HBM traffic of the sweeps; factors stay float32)")
+    parser.add_argument("--n-gpus", type=int, default=1,
+                        help="shard the solve over N GPUs of this node: re-launches this command under torch.distributed.run "
+                             "(one process per GPU); not needed when the command is already started by that launcher")
+    parser.add_argument("--dist-mode", default=None, choices=["colshard", "replicated"],
+                        help="multi-GPU V update: sharded by latent columns (default) or replicated on every rank")
     args = parser.parse_args(argv)
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.n_gpus > 1:
+        # launcher mode: nothing in this process has touched the GPU (or imported torch); the ranks are children
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.n_gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(sys.argv[0])]
+        cmd += list(sys.argv[1:] if argv is None else argv)
+        sys.exit(subprocess.call(cmd))
+    rank, group_ready = 0, False
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # PRMF_DIST_BACKEND=gloo PRMF_SHARE_GPU=1: rehearsal on a one-GPU box (tests), ranks share cuda:0
+        backend = os.environ.get("PRMF_DIST_BACKEND", "nccl")
+        dev_index = 0 if os.environ.get("PRMF_SHARE_GPU") else local_rank
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:%d" % dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        torch.cuda.set_device(dev_index)
+        group_ready = True
+        if args.seed is None:      # one seed for all ranks (the reference leaves the streams unseeded: any seed is as good)
+            box = [random.randrange(2 ** 31) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            args.seed = box[0]
+        if rank != 0:              # rank 0 speaks for the job
+            sys.stdout = open(os.devnull, "w")
+    try:
+        _run(args, rank, world)
+    finally:
+        if group_ready:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def _run(args, rank, world):
     manifolds = ManifoldSet.from_args(args)
     if args.seed is not None:                              # both legacy streams, as the reference seeds them
         np.random.seed(int(args.seed))
@@ -299,12 +359,15 @@ Solve an optimization problem of the form
         X = quantile_transform(X)
     U_init = V_init = None
     if args.manifolds_init is not None:
-        U_init, V_init = initial_factors(args, X, manifolds, nodelist)
+        U_init, V_init = initial_factors(args, X, manifolds, nodelist, write=rank == 0)
 
     from .solver import measure_cv_performance, nmf_pathway
     U, V, obj_data = nmf_pathway(X, manifolds.graphs, nodelist=nodelist, gamma=args.gamma,       # the GPU solve (:1067)
                                  tradeoff=None if args.tradeoff == -1 else args.tradeoff, k_latent=args.k_latent,
-                                 U_init=U_init, V_init=V_init, verbose=args.verbose, x_dtype=args.x_dtype)
+                                 U_init=U_init, V_init=V_init, verbose=args.verbose, x_dtype=args.x_dtype,
+                                 dist_mode=args.dist_mode)
+    if rank != 0:                                          # every rank holds the same U, V, obj_data; rank 0 writes them
+        return
     if X_test is not None:                                 # :1073-1079: one sweep + batched NNLS (prmf/__init__.py:768-798)
         errs = measure_cv_performance(V, X_test, x_dtype=args.x_dtype)
         np.savetxt(os.path.join(args.outdir, 'test_error.csv'), errs, delimiter=",")

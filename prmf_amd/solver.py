@@ -41,9 +41,9 @@ class PrmfEngine(object):
 
     nranks > 1: X is row-sharded (this rank holds m_local samples) and the
     phase_* methods are driven by prmf_amd.distributed with collectives between
-    them; see include/prmf_hip.h.  dist_mode: "replicated" (default: every rank
-    updates all of V from the all-reduced X^T U) or "colshard" (the V update is
-    sharded by latent columns: reduce-scatter + all-gather)."""
+    them; see include/prmf_hip.h.  dist_mode: "colshard" (default: the V update is
+    sharded by latent columns -- reduce-scatter of X^T U, all-gather of V) or
+    "replicated" (every rank updates all of V from the all-reduced X^T U)."""
 
     def __init__(self, m_local, n, k, x_dtype="f32", device=None, nranks=1, rank=0, timing=False, dist_mode=None,
                  eager_objective=False, direct_residual=False):
@@ -60,8 +60,8 @@ class PrmfEngine(object):
         flags = _capi.PRMF_FLAG_TIMING if timing else 0
         if dist_mode not in (None, "replicated", "colshard"):
             raise ValueError("dist_mode must be 'replicated' or 'colshard'")
-        if dist_mode == "colshard":
-            flags |= _capi.PRMF_FLAG_COLUMN_SHARDED
+        if dist_mode == "replicated":
+            flags |= _capi.PRMF_FLAG_REPLICATED
         if eager_objective:       # per-iteration objective launches instead of the deferred evaluation (prmf_hip.h)
             flags |= _capi.PRMF_FLAG_EAGER_OBJECTIVE
         if direct_residual:       # recon of EVERY record from the materialised-residual form of prmf_runner.py:337
@@ -462,30 +462,105 @@ def force_distinct_lapls(V, library, latent_to_pathway_data, k_to_lapl, gamma, d
     return latent_to_pathway_data
 
 
+class _Ranks(object):
+    """Which rank of which process group this call of nmf_pathway is (one process per GPU, torch.distributed).  The
+    reference has no counterpart (one process, script/prmf_runner.py:556); the rules that keep N ranks one solve:
+    rank 0's legacy RNG is THE stream -- what it draws (U_init / V_init, the per-round pathway samples) is broadcast --
+    and everything else every rank computes itself from replicated state (V, the records), so all ranks take the same
+    decisions without further exchange."""
+
+    def __init__(self, group):
+        self.group, self.world, self.rank, self.dist = group, 1, 0, None
+        try:
+            import torch.distributed as dist
+        except ImportError:
+            return
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            self.dist, self.world, self.rank = dist, dist.get_world_size(group), dist.get_rank(group)
+
+    @property
+    def multi(self):
+        return self.world > 1
+
+    def src(self):
+        return self.dist.get_global_rank(self.group, 0) if self.group is not None else 0
+
+    def from_rank0(self, obj):
+        """rank 0's value of a small host object on every rank"""
+        if not self.multi:
+            return obj
+        box = [obj if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=self.src(), group=self.group)
+        return box[0]
+
+    def sum_float(self, torch, value, device):
+        if not self.multi:
+            return float(value)
+        on_gpu = self.dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([value], dtype=torch.float64, device=device if on_gpu else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return float(t.item())
+
+    def gather_rows(self, torch, t, m):
+        """row shards (sizes differ by at most one) -> the full m x k matrix on every rank, as a host array"""
+        if not self.multi:
+            return t.cpu().numpy()
+        from .synthetic import shard_rows
+        on_gpu = self.dist.get_backend(self.group) == "nccl"
+        rows = max(shard_rows(m, self.world, r)[1] - shard_rows(m, self.world, r)[0] for r in range(self.world))
+        pad = torch.zeros((rows, t.shape[1]), dtype=t.dtype, device=t.device if on_gpu else "cpu")
+        pad[:t.shape[0]] = t if on_gpu else t.cpu()
+        out = [torch.empty_like(pad) for _ in range(self.world)]
+        self.dist.all_gather(out, pad, group=self.group)
+        parts = []
+        for r in range(self.world):
+            lo, hi = shard_rows(m, self.world, r)
+            parts.append(out[r][:hi - lo].cpu().numpy())
+        return np.concatenate(parts, axis=0)
+
+
 def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3, max_iter=1000, nodelist=None,
                 modulus=10, U_init=None, V_init=None, verbose=False, x_dtype="f32", library=None, round_log=None,
-                trace=None):
+                trace=None, group=None, dist_mode=None):
     """Same call and return value as the reference's nmf_pathway (prmf_runner.py:556).
 
     Extra keyword-only arguments: x_dtype ("f32" | "bf16" storage of X on the
     GPU), library (a prebuilt PathwayLibrary instead of Gs), round_log / trace
     (lists that receive the per-round active assignment / per-iteration records).
     Randomness comes from the legacy global numpy stream in the reference's order:
-    rand(m,k), rand(n,k) (:651-653), one multinomial draw per latent per round (:723)."""
+    rand(m,k), rand(n,k) (:651-653), one multinomial draw per latent per round (:723).
+
+    Multi-GPU: called by every rank of an initialised torch.distributed process group (one process per GPU; `group`,
+    default the world) with the same arguments, the solve is sharded -- rank r keeps rows shard_rows(m, N, r) of X and
+    U on its GPU, V is replicated, each iteration exchanges the k x k Gram U^T U and the n x k product X^T U over RCCL
+    (prmf_amd.distributed; dist_mode "colshard" (default) or "replicated").  Rank 0's RNG stream is the solve's: its
+    draws are broadcast.  Every rank returns the same (U, V, obj_data) -- U gathered to all m rows; only rank 0 prints."""
     from scipy.stats import multinomial
+    ranks = _Ranks(group)
+    say = print if ranks.rank == 0 else (lambda *a, **kw: None)
     X = np.asarray(X)
     m, n = X.shape
-    engine = PrmfEngine(m, n, k_latent, x_dtype=x_dtype)
+    lo, hi = 0, m
+    if ranks.multi:
+        from .synthetic import shard_rows
+        lo, hi = shard_rows(m, ranks.world, ranks.rank)
+    engine = PrmfEngine(hi - lo, n, k_latent, x_dtype=x_dtype, nranks=ranks.world, rank=ranks.rank,
+                        dist_mode=dist_mode if ranks.multi else None)
     try:
         torch = engine.torch
-        norm_X = math.sqrt(engine.set_x(X))                       # :640 (of the X the GPU holds)
-        print("norm(X) = {}".format(norm_X))                      # :641
-        gamma = gamma * norm_X / k_latent                         # :644
-        delta = delta * 10 / norm_X                               # :645
+        dev = "cuda:%d" % engine.device
+        Xd = engine.device_tensor(X[lo:hi], engine.torch_x_dtype)
+        norm_sq = ranks.sum_float(torch, engine.local_norm_sq(Xd), dev)
+        engine.set_x(Xd, norm_x_sq=norm_sq)
+        del Xd
+        norm_X = math.sqrt(norm_sq)                                 # :640 (of the X the GPUs hold)
+        say("norm(X) = {}".format(norm_X))                          # :641
+        gamma = gamma * norm_X / k_latent                           # :644
+        delta = delta * 10 / norm_X                                 # :645
         if U_init is None:
-            U_init = 3 * (1 - np.random.rand(m, k_latent))
+            U_init = ranks.from_rank0(3 * (1 - np.random.rand(m, k_latent)) if ranks.rank == 0 else None)
         if V_init is None:
-            V_init = 3 * (1 - np.random.rand(n, k_latent))
+            V_init = ranks.from_rank0(3 * (1 - np.random.rand(n, k_latent)) if ranks.rank == 0 else None)
         if U_init.shape != (m, k_latent):
             raise ValueError("Invalid U_init with shape {} != (m_obs, k_latent) = {}".format(U_init.shape, (m, k_latent)))
         if V_init.shape != (n, k_latent):
@@ -493,8 +568,15 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
         if library is None:
             library = PathwayLibrary.from_graphs(Gs, nodelist)    # :670-696
         engine.set_library(library)
-        U = engine.device_tensor(U_init, torch.float32)
+        U = engine.device_tensor(U_init[lo:hi], torch.float32)
         V = engine.device_tensor(V_init, torch.float32)
+        if ranks.multi:
+            import os
+            from .distributed import DistributedPrmf
+            # PRMF_RCCL_LIB (the RCCL test double): the in-library step although the process group is not "nccl"
+            step = DistributedPrmf(engine, group=group, native=True if os.environ.get("PRMF_RCCL_LIB") else None).step
+        else:
+            step = engine.step
 
         l2p = {k: [(p, 1) for p in range(library.P)] for k in range(k_latent)}     # :700
         converged, candidates_remain = False, True
@@ -503,28 +585,30 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
         i = 0
         k_to_lapl = {}
         while i < max_iter and (candidates_remain or not converged):
-            for k in range(k_latent):                              # :717-729
-                inds = [x[0] for x in l2p[k]]
-                scores = np.array([x[1] for x in l2p[k]])
-                sample = multinomial.rvs(1, scores / np.sum(scores))
-                k_to_lapl[k] = inds[np.where(sample != 0)[0][0]]
+            if ranks.rank == 0:
+                for k in range(k_latent):                          # :717-729
+                    inds = [x[0] for x in l2p[k]]
+                    scores = np.array([x[1] for x in l2p[k]])
+                    sample = multinomial.rvs(1, scores / np.sum(scores))
+                    k_to_lapl[k] = inds[np.where(sample != 0)[0][0]]
+            k_to_lapl = ranks.from_rank0(k_to_lapl)
             if round_log is not None:
                 round_log.append([int(k_to_lapl[k]) for k in range(k_latent)])
             if verbose:
-                print('--------------------------------------------')
-                print('Latent/Pathway association at this iteration')
-                print('--------------------------------------------')
+                say('--------------------------------------------')
+                say('Latent/Pathway association at this iteration')
+                say('--------------------------------------------')
                 for k, lapl_ind in k_to_lapl.items():
-                    print(k, lapl_ind)
-                print('--------------------------------------------')
+                    say(k, lapl_ind)
+                say('--------------------------------------------')
             engine.set_active([k_to_lapl[k] for k in range(k_latent)])
-            objs, (g2, d2) = engine.step(U, V, modulus, gamma, delta, tradeoff)          # :740 / :742
+            objs, (g2, d2) = step(U, V, modulus, gamma, delta, tradeoff)                 # :740 / :742
             if tradeoff is not None:
                 gamma, delta = g2, d2
             for s, od in enumerate(objs):
-                print(i + s + 1, od["obj"])
+                say(i + s + 1, od["obj"])
                 if verbose:
-                    print(od)
+                    say(od)
                 if trace is not None:
                     trace.append(od)
             obj_data = objs[-1]
@@ -537,24 +621,26 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
                 best["U"].copy_(U)
                 best["V"].copy_(V)
                 best["obj_data"] = obj_data
-            if candidates_remain:                                   # :754-770
+            if candidates_remain:                                   # :754-770  (V is replicated: every rank decides alike)
                 if min(len(v) for v in l2p.values()) <= k_latent:
                     Vh = V.cpu().numpy().astype(np.float64)
                     l2p = force_distinct_lapls(Vh, library, l2p, dict(k_to_lapl), gamma, delta)
                     candidates_remain = False
                 else:
-                    sys.stderr.write('Before restrict: ' + str(datetime.datetime.now()) + '\n')     # :762
+                    if ranks.rank == 0:
+                        sys.stderr.write('Before restrict: ' + str(datetime.datetime.now()) + '\n')     # :762
                     l2p = restrict(engine.score_candidates(V), l2p)
-                    sys.stderr.write('After restrict: ' + str(datetime.datetime.now()) + '\n')      # :764
+                    if ranks.rank == 0:
+                        sys.stderr.write('After restrict: ' + str(datetime.datetime.now()) + '\n')      # :764
                     candidates_remain = any(len(v) > 1 for v in l2p.values())
-                if verbose:
+                if verbose and ranks.rank == 0:
                     print_latent_to_pathway_data(l2p)                                              # :759, :770
             prev_obj, obj = obj, obj_data["obj"]
             converged = abs(obj - prev_obj) / obj < tol              # :772-774
         if best["obj_data"]["obj"] < obj_data["obj"]:                # :778-782
-            print('Local optima at convergence (or after max iterations) is not the best among all iterates; returning best instead')
+            say('Local optima at convergence (or after max iterations) is not the best among all iterates; returning best instead')
             U, V, obj_data = best["U"], best["V"], best["obj_data"]
-        U_out = U.cpu().numpy().astype(np.float64)
+        U_out = ranks.gather_rows(torch, U, m).astype(np.float64)
         V_out = V.cpu().numpy().astype(np.float64)
         obj_data = dict(obj_data)
         obj_data["latent_to_pathway_data"] = l2p

@@ -146,6 +146,10 @@ ncclResult_t ncclCommUserRank(const ncclComm_t c, int* rank) {
   return ncclSuccess;
 }
 
+// the mock executes every collective synchronously at the call, so a group is just its members in order
+ncclResult_t ncclGroupStart() { return ncclSuccess; }
+ncclResult_t ncclGroupEnd() { return ncclSuccess; }
+
 const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "mock rccl error"; }
 
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t c, hipStream_t s) {

@@ -106,8 +106,10 @@ def test_two_ranks_match_single_rank(k, x_dtype, mode):
 
 @pytest.mark.parametrize("k,x_dtype", [(64, "bf16"), (16, "f32")])
 def test_column_sharded_deferred_records_equal_eager(k, x_dtype):
-    """Column-sharded mode: the records evaluated at prmf_end from the kept Grams and gathered rank extras (V^T V reduced
-    by the next sweep's prologue) against the per-iteration form (PRMF_FLAG_EAGER_OBJECTIVE): bit for bit, factors too."""
+    """Column-sharded mode: the records evaluated at prmf_end from the kept Grams, the gathered per-workgroup sums and
+    V_new on the supports (V^T V and the sums reduced by the next sweep's prologue) against the per-iteration form
+    (PRMF_FLAG_EAGER_OBJECTIVE): the factors bit for bit, the records to the last bits (the per-iteration form adds
+    manifold / ignore per rank first, the deferred one over all k columns at once)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = []
@@ -120,7 +122,9 @@ def test_column_sharded_deferred_records_equal_eager(k, x_dtype):
         out.append(_collect(procs, q))
     for r in range(2):
         assert np.array_equal(out[0][r][0], out[1][r][0]) and np.array_equal(out[0][r][1], out[1][r][1])
-        assert out[0][r][2] == out[1][r][2]
+        for a, b in zip(out[0][r][2], out[1][r][2]):
+            for key in a:
+                assert abs(a[key] - b[key]) <= 1e-13 * abs(b[key]), (key, a[key], b[key])
 
 
 def test_in_library_rccl_step_single_rank():
