@@ -416,9 +416,9 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   c->col0 = (c->replicated ? 0 : rank) * c->kc;
   c->ncols = c->col0 >= k ? 0 : (c->col0 + c->kc <= k ? c->kc : k - c->col0);
   c->fused_v = c->lr == 1;
-  c->partial_off = round_up(n * c->kc, 2);
+  c->partial_off = round_up(n * c->kc, 4);     // blocks and their parts stay 16-B aligned (the staged loads of v_post)
   c->extras_off = c->partial_off + (c->fused_v ? 0 : 2 * (int64_t)v_update_blocks(n) * (c->kc + 1));
-  c->v_send_floats = c->extras_off + 8;
+  c->v_send_floats = round_up(c->extras_off + 8, 4);
   int rc = PRMF_OK;
   auto bail = [&](int code) {
     std::snprintf(g_create_error, sizeof g_create_error, "%s", c->err);

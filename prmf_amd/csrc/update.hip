@@ -1085,16 +1085,22 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
 
 // Multi-rank phase_post in one pass: the gathered per-rank column blocks -> row-major V (caller's buffer),
 // packed fragments for the next sweep, V^T V partials (GRAM).  Same tile machinery as the epilogues.
-template <int NT, bool GRAM>
+// STAGED (kc % 4 == 0): a tile's share of every rank block is one contiguous run of 32 kc floats; the wave copies the
+// runs with 16-B loads into a private LDS tile and reads its C/D-layout values from there.  Read straight from the
+// blocks in the C/D layout, one load instruction touched 2 rows x 32 / kc blocks with kc * 4 bytes each (32 B at eight
+// ranks of k = 64): 25.5 us per iteration at 20000 genes against 18 us for the whole fused V epilogue.
+template <int NT, bool GRAM, bool STAGED>
 __global__ void __launch_bounds__(256)
 v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ v_recv, int64_t blk_stride, int kc,
               void* __restrict__ packed, int64_t ntiles_pack, float* __restrict__ gram_partial,
               const int32_t* __restrict__ pos_all /* null or [n][k] */, float* __restrict__ vsup /* [k][max_support] */, int max_support) {
-  constexpr int NP = NT * (NT + 1) / 2;
+  constexpr int NP = NT * (NT + 1) / 2, KP = 32 * NT, PITCH = KP + 4;
   __shared__ float red[GRAM ? 4 : 1][16][64];
+  __shared__ float stage[STAGED ? 4 : 1][STAGED ? 32 * PITCH : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
   const int64_t wstride = (int64_t)gridDim.x * 4;
+  const int nblocks_src = (k + kc - 1) / kc;
   f32x16 g[GRAM ? NP : 1];
   if constexpr (GRAM) {
 #pragma unroll
@@ -1105,6 +1111,20 @@ v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles_pack; tile += wstride) {
     const int64_t row0 = tile * 32;
     float vn[NT][16];
+    if constexpr (STAGED) {
+      float* T = stage[wave];
+      const int rows_here = row0 < n ? (int)(n - row0 < 32 ? n - row0 : 32) : 0;
+      const int run4 = rows_here * kc / 4;                  // float4 per rank block
+      for (int b = 0; b < nblocks_src; ++b) {
+        const float4* src = reinterpret_cast<const float4*>(v_recv + (int64_t)b * blk_stride + row0 * kc);
+        for (int f = lane; f < run4; f += 64) {
+          const float4 x = src[f];
+          const int e = 4 * f, rr = e / kc, cc = e - rr * kc;
+          float* d = T + rr * PITCH + b * kc + cc;
+          d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+        }
+      }
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int col = 32 * t + c;
@@ -1112,10 +1132,12 @@ v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__
       const int64_t cb = (int64_t)(colc / kc) * blk_stride + (colc % kc);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int64_t row = row0 + rr;
         float v = 0.f;
         if (row < n && col < k) {
-          v = v_recv[cb + row * kc];
+          if constexpr (STAGED) v = stage[wave][rr * PITCH + col];
+          else v = v_recv[cb + row * kc];
           V[row * k + col] = v;
           if (pos_all) {             // V_new on the active supports, for the deferred objective (prmf_end)
             const int ps = pos_all[row * k + col];
@@ -1141,8 +1163,12 @@ hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_
   const int64_t ntiles = Kpad / 32;
   const int grid = epilogue_blocks(Kpad);
   *gram_done = NT <= 2;
+  const bool staged = (kc & 3) == 0 && (blk_stride & 3) == 0;
 #define PRMF_VPOST(NTV, GR)                                                                                      \
-  v_post_kernel<NTV, GR><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, pos_all, vsup, max_support)
+  do {                                                                                                           \
+    if (staged) v_post_kernel<NTV, GR, true><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, pos_all, vsup, max_support); \
+    else v_post_kernel<NTV, GR, false><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, pos_all, vsup, max_support); \
+  } while (0)
   switch (NT) {
     case 1: PRMF_VPOST(1, true); break;
     case 2: PRMF_VPOST(2, true); break;
@@ -1316,119 +1342,139 @@ hipError_t launch_graph_terms(const PathwayLibDev& lib, const int32_t* active_de
 }
 
 // ---------------------------------------------------------------------------
-// V update for the own columns   (:424-425, :440-444)
+// V update for the own columns   (:424-425, :440-444), column-sharded multi-rank mode
+//   V_own <- V_own * (Q_own + gnum) / max(V (U^T U)[:, own] + gden, eps), clamp at eps
+// One wave per 32-row tile, as the fused epilogues: den = V_tile (A layout, all k columns) x G[:, own columns] on the
+// f32 MFMA, the element-wise update in the C/D layout (lane = own column, registers = rows), own columns written to
+// this rank's all-gather block, per-workgroup float64 sums of squares / <Q, V_new> to its tail.
+// (The first version -- one thread per (row, 4 columns), scalar dot products from an LDS copy of the rows, 157 workgroups
+// at 20000 genes -- took 19.5 us per iteration for 8 own columns: profiles/r03_share8_kernel_stats.txt.)
 // ---------------------------------------------------------------------------
 constexpr int VUPD_MAX_BLOCKS = 256;   // its per-workgroup sums travel in the tail of the all-gather: keep them few
-static inline int v_update_rt(int ncols) {
-  int ncg = ((ncols + 3) & ~3) >> 2;
-  if (ncg < 1) ncg = 1;
-  return 256 / ncg;
-}
 int v_update_blocks(int64_t n) {
-  // worst case (ncols=128): 8 rows per tile
-  int64_t t = (n + 7) / 8;
-  return (int)(t < VUPD_MAX_BLOCKS ? t : VUPD_MAX_BLOCKS);
+  const int64_t blocks = ((n + 31) / 32 + 3) / 4;
+  return (int)(blocks < 1 ? 1 : (blocks < VUPD_MAX_BLOCKS ? blocks : VUPD_MAX_BLOCKS));
 }
 
+// NT: 32-column tiles of all k columns; NTO: 32-column tiles of the own columns (kc <= 32 NTO)
+template <int NT, int NTO, bool VEC4>
 __global__ void __launch_bounds__(256)
-v_update_kernel(const float* __restrict__ V, int64_t n, int k, int col0, int ncols, int kc,
-                const float* __restrict__ q_recv, const double* __restrict__ Gu, const int32_t* __restrict__ pos,
-                const float* __restrict__ gnum, const float* __restrict__ gden, int max_support,
-                float* __restrict__ v_send, double* __restrict__ partial, int nblocks_alloc) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int k4 = (k + 3) & ~3;
-  const int nc4 = (ncols + 3) & ~3;
-  const int ncg = nc4 >> 2;
-  const int RT = 256 / ncg;
-  float* Gs = smem;              // [k][nc4]   own columns of U^T U
-  float* Vs = smem + k * nc4;    // [RT][k4]
-  const int tid = threadIdx.x;
-  for (int i = tid; i < k * nc4; i += 256) {
-    int q = i / nc4, c = i - q * nc4;
-    Gs[i] = c < ncols ? (float)Gu[q * k + col0 + c] : 0.f;
+v_update_kernel(const float* __restrict__ V, int64_t n, int k, int col0, int ncols, int kc, const float* __restrict__ q_recv,
+                const double* __restrict__ Gu, const int32_t* __restrict__ pos, const float* __restrict__ gnum,
+                const float* __restrict__ gden, int max_support, float* __restrict__ v_send, double* __restrict__ partial) {
+  constexpr int KP = 32 * NT, HALF = KP / 2, OW = 32 * NTO;
+  __shared__ float Gs[KP * OW];                  // G[:, col0 .. col0 + ncols), zero beyond
+  __shared__ double red[4][OW + 1];
+  for (int i = threadIdx.x; i < KP * OW; i += 256) {
+    const int q = i / OW, oc = i - q * OW;
+    Gs[i] = (q < k && oc < ncols) ? (float)Gu[q * k + col0 + oc] : 0.f;
   }
-  const int cg = tid % ncg, rt = tid / ncg;
-  double colsq[4] = {0.0, 0.0, 0.0, 0.0};
-  double cross = 0.0;
-  const int64_t ntiles = (n + RT - 1) / RT;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    __syncthreads();
-    for (int i = tid; i < RT * k4; i += 256) {
-      int rr = i / k4, q = i - rr * k4;
-      int64_t row = tile * RT + rr;
-      Vs[i] = (row < n && q < k) ? V[row * k + q] : 0.f;
-    }
-    __syncthreads();
-    const int64_t row = tile * RT + rt;
-    if (rt < RT && row < n) {
-      float den[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* vrow = Vs + rt * k4;
-      for (int q = 0; q < k; ++q) {
-        const float v = vrow[q];
-        const float4 g = *reinterpret_cast<const float4*>(Gs + q * nc4 + 4 * cg);
-        den[0] = fmaf(v, g.x, den[0]);
-        den[1] = fmaf(v, g.y, den[1]);
-        den[2] = fmaf(v, g.z, den[2]);
-        den[3] = fmaf(v, g.w, den[3]);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int c = lane & 31, h = lane >> 5, r = lane & 31;
+  double colsq[NTO], cross = 0.0;
+#pragma unroll
+  for (int to = 0; to < NTO; ++to) colsq[to] = 0.0;
+  const int64_t ntiles = (n + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = tile * 32;
+    float ua[16 * NT];
+    load_tile_a_layout<NT, VEC4>(V, n, k, row0, lane, ua);
+    f32x16 den[NTO];
+#pragma unroll
+    for (int to = 0; to < NTO; ++to)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) den[to][i] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < HALF; ++s2)
+#pragma unroll
+      for (int to = 0; to < NTO; ++to)
+        den[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[s2], Gs[(s2 + HALF * h) * OW + 32 * to + r], den[to], 0, 0, 0);
+    const int last = (int)((n - row0 < 32 ? n - row0 : 32) - 1);
+#pragma unroll
+    for (int to = 0; to < NTO; ++to) {
+      const int oc = 32 * to + c, occ = oc < ncols ? oc : ncols - 1;       // own column (clamped for the loads)
+      float qv[16], vv[16], gn[16], gd[16];
+      int ps[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int64_t row = row0 + (rr < last ? rr : last);
+        qv[i] = q_recv[row * kc + occ];
+        vv[i] = V[row * k + col0 + occ];
+        ps[i] = pos[row * kc + occ];
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = 4 * cg + j;
-        if (c < ncols) {
-          const float qv = q_recv[row * kc + c];
-          float num = qv, d = den[j];
-          const int ps = pos[row * kc + c];
-          if (ps >= 0) {
-            num += gnum[(int64_t)c * max_support + ps];
-            d += gden[(int64_t)c * max_support + ps];
-          }
-          if (d < PRMF_EPS) d = PRMF_EPS;
-          float vn = vrow[col0 + c] * (num / d);
-          if (vn < PRMF_EPS) vn = PRMF_EPS;
-          v_send[row * kc + c] = vn;
-          colsq[j] += (double)vn * (double)vn;
-          cross += (double)qv * (double)vn;
+      for (int i = 0; i < 16; ++i) {          // branch-free gathers: off-support entries read element 0 and are masked
+        const unsigned goff = ps[i] >= 0 ? (unsigned)occ * (unsigned)max_support + (unsigned)ps[i] : 0u;
+        gn[i] = gnum[goff];
+        gd[i] = gden[goff];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int64_t row = row0 + rr;
+        const bool on = ps[i] >= 0, valid = row < n && oc < ncols;
+        const float num = qv[i] + (on ? gn[i] : 0.f);
+        float d = den[to][i] + (on ? gd[i] : 0.f);
+        if (d < PRMF_EPS) d = PRMF_EPS;                              // :442
+        float vn = vv[i] * (num / d);                                // :443
+        if (vn < PRMF_EPS) vn = PRMF_EPS;                            // :444
+        if (valid) {
+          v_send[row * kc + oc] = vn;
+          colsq[to] += (double)vn * (double)vn;
+          cross += (double)qv[i] * (double)vn;
         }
       }
     }
   }
-  // deterministic block reduction: per own column over row-threads, cross over all
-  __syncthreads();
-  double* red = reinterpret_cast<double*>(smem);   // reuse: needs 256*5 doubles = 10 KB (host sizes LDS)
+  // per-workgroup sums (fixed order: half-waves, lanes, then the 4 waves): own-column sums of squares, <Q, V_new> last
 #pragma unroll
-  for (int j = 0; j < 4; ++j) red[tid * 5 + j] = colsq[j];
-  red[tid * 5 + 4] = cross;
+  for (int to = 0; to < NTO; ++to) {
+    const double tot = colsq[to] + __shfl_xor(colsq[to], 32);
+    if (h == 0) red[wave][32 * to + c] = tot;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cross += __shfl_xor(cross, off);
+  if (lane == 0) red[wave][OW] = cross;
   __syncthreads();
   double* out = partial + (int64_t)blockIdx.x * (kc + 1);
-  if (tid < ncols) {
-    const int mycg = tid >> 2, myj = tid & 3;
-    double s = 0.0;
-    for (int r2 = 0; r2 < RT; ++r2) s += red[(r2 * ncg + mycg) * 5 + myj];
-    out[tid] = s;
+  for (int j = threadIdx.x; j <= kc; j += 256) {
+    const int src = j < kc ? j : OW;
+    out[j] = (j < kc && j >= ncols) ? 0.0 : ((red[0][src] + red[1][src]) + red[2][src]) + red[3][src];
   }
-  if (tid == 255) {
-    double s = 0.0;
-    for (int t2 = 0; t2 < 256; ++t2) s += red[t2 * 5 + 4];
-    out[kc] = s;
-  }
-  (void)nblocks_alloc;
 }
 
 hipError_t launch_v_update(const float* V, int64_t n, int k, int col0, int ncols, int kc, const float* q_recv,
                            const double* Gu, const int32_t* pos, const float* gnum, const float* gden, int max_support,
                            float* v_send, double* partial, hipStream_t s) {
-  const int nblk = v_update_blocks(n);
-  hipError_t e = hipMemsetAsync(partial, 0, (size_t)nblk * (kc + 1) * sizeof(double), s);
-  if (e != hipSuccess) return e;
-  if (ncols <= 0) return hipSuccess;
-  const int k4 = (k + 3) & ~3, nc4 = (ncols + 3) & ~3;
-  const int RT = v_update_rt(ncols);
-  size_t lds = (size_t)(k * nc4 + RT * k4) * sizeof(float);
-  if (lds < 256 * 5 * sizeof(double)) lds = 256 * 5 * sizeof(double);
-  int64_t ntiles = (n + RT - 1) / RT;
-  int grid = (int)(ntiles < nblk ? ntiles : nblk);
-  v_update_kernel<<<grid, 256, lds, s>>>(V, n, k, col0, ncols, kc, q_recv, Gu, pos, gnum, gden, max_support, v_send,
-                                         partial, nblk);
+  const int nblk = v_update_blocks(n);           // every workgroup writes its row of `partial` (zeros if it had no tile)
+  if (ncols <= 0) return hipMemsetAsync(partial, 0, (size_t)nblk * (kc + 1) * sizeof(double), s);
+  const int NT = (k + 31) / 32, NTO = (kc + 31) / 32;
+  const bool vec4 = (k & 3) == 0;
+#define PRMF_VUPD(NTV, NTOV)                                                                                             \
+  do {                                                                                                                    \
+    if (vec4) v_update_kernel<NTV, NTOV, true><<<nblk, 256, 0, s>>>(V, n, k, col0, ncols, kc, q_recv, Gu, pos, gnum, gden, max_support, v_send, partial); \
+    else v_update_kernel<NTV, NTOV, false><<<nblk, 256, 0, s>>>(V, n, k, col0, ncols, kc, q_recv, Gu, pos, gnum, gden, max_support, v_send, partial); \
+  } while (0)
+  if (NTO == 1) {
+    switch (NT) {
+      case 1: PRMF_VUPD(1, 1); break;
+      case 2: PRMF_VUPD(2, 1); break;
+      case 3: PRMF_VUPD(3, 1); break;
+      case 4: PRMF_VUPD(4, 1); break;
+      default: return hipErrorInvalidValue;
+    }
+  } else if (NTO == 2) {                         // kc in (32, 64]: two ranks at k > 64
+    switch (NT) {
+      case 3: PRMF_VUPD(3, 2); break;
+      case 4: PRMF_VUPD(4, 2); break;
+      default: return hipErrorInvalidValue;
+    }
+  } else {
+    return hipErrorInvalidValue;                 // kc > 64 needs nranks == 1, which takes the fused epilogue
+  }
+#undef PRMF_VUPD
   return hipGetLastError();
 }
 

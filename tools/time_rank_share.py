@@ -6,7 +6,7 @@ import numpy as np, torch
 from prmf_amd import PathwayLibrary, synthetic as syn
 from prmf_amd.solver import PrmfEngine
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-m, n, k, P = 50000, 20000, 64, 300
+m, n, k, P = syn.CONFIGS[os.environ.get("WL", "c3")][:4]        # the global problem the ranks share
 dev = "cuda:0"
 lo, hi = syn.shard_rows(m, N, 0)
 Xd = syn.x_rows_torch(torch, dev, 0, n, k, lo, hi, torch.bfloat16)
