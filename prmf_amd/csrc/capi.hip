@@ -102,6 +102,7 @@ struct prmf_ctx {
   bool lazy = false;
   bool gv_pending = false;            // the V side's V^T V partials / per-workgroup sums are not reduced yet
   bool batch_open = false;
+  bool tradeoff_on = false;           // this batch runs the gamma / delta feedback (prmf_begin)
   bool dist_driver = false;           // inside prmf_step_dist: the library issues the collectives itself
   int nparts_u = 0, nparts_v = 0;     // Gram partials the U / V side writes per iteration
   double* Gu_keep = nullptr;          // [MAX_RECORDS][k*k]
@@ -345,9 +346,19 @@ SweepPrologue mid_prologue(prmf_ctx* c, int it) {
 // Can this context replace a record's identity-based recon by the direct residual?  One rank: always.  Several ranks:
 // the local sums have to be added up, which the library can only do itself (RCCL communicator, inside prmf_step_dist).
 bool direct_available(const prmf_ctx* c) { return c->nranks == 1 || (c->comm != nullptr && c->dist_driver); }
-bool direct_forced(const prmf_ctx* c) { return (c->flags & PRMF_FLAG_DIRECT_RESIDUAL) != 0; }
+// Every record from the direct residual: on request (PRMF_FLAG_DIRECT_RESIDUAL), and whenever the tradeoff feedback is on --
+// gamma = delta = (1 - t) recon / (t manifold) (prmf_runner.py:542-548) feeds recon back into the update every step, and
+// the identity's error (on the reference's 100 x 1000 test problem 2e-5: the 16-bit packed factors do not average out
+// over 600 entries of U) was amplified to 1.7e-3 on the objective trace over 1000 iterations, where a float64 run whose
+// only float32 part is the state drifts 5e-7 (tests/test_oracle_golden.py::test_tradeoff_trace_conditioning).
+bool direct_forced(const prmf_ctx* c) { return (c->flags & PRMF_FLAG_DIRECT_RESIDUAL) != 0 || c->tradeoff_on; }
 // recon^2 (identity) below this value is too small to trust: kernels.h RECON_DIRECT_THRESHOLD*
-double direct_below(const prmf_ctx* c) { return (c->NT <= 2 ? RECON_DIRECT_THRESHOLD_LO : RECON_DIRECT_THRESHOLD) * c->norm_x_sq; }
+// plus the part of the error that comes from the 16-bit packed factors: it averages over the min(m, n) k entries of the
+// smaller factor only (2.6e-7 ||X||^2 measured at 100 x 1000, k = 6: profiles/r03_recon_identity_terms.txt)
+double direct_below(const prmf_ctx* c) {
+  const double entries = (double)(c->m < c->n ? (c->m > 0 ? c->m : 1) : c->n) * c->k;
+  return ((c->NT <= 2 ? RECON_DIRECT_THRESHOLD_LO : RECON_DIRECT_THRESHOLD) + RECON_DIRECT_FACTOR_TERM / std::sqrt(entries)) * c->norm_x_sq;
+}
 
 // The launches behind a record whose kernel may have raised c->need_dev: sum (X - U V^T)^2 over this rank's rows (the
 // kernels return at once when the flag is clear), the sum over ranks, and the rewrite of the record.
@@ -736,7 +747,8 @@ int prmf_begin(prmf_ctx* c, float* dU, float* dV, double gamma, double delta, do
   // Objective deferred to prmf_end + reductions folded into the sweeps' prologues: whenever the tradeoff feedback is
   // off (with it on, gamma / delta of step t + 1 need the record of step t) -- one rank and both multi-rank modes.
   // Decided per rank; the exchanges do not depend on it.
-  c->lazy = !(tradeoff >= 0.0) && c->plan_xv.nw == 4 && c->plan_xtu.nw == 4 && c->vsup_ring &&
+  c->tradeoff_on = tradeoff >= 0.0;
+  c->lazy = !c->tradeoff_on && c->plan_xv.nw == 4 && c->plan_xtu.nw == 4 && c->vsup_ring &&
             !(c->flags & (PRMF_FLAG_EAGER_OBJECTIVE | PRMF_FLAG_DIRECT_RESIDUAL));
   c->batch_open = true;
   return PRMF_OK;

@@ -31,6 +31,9 @@ constexpr int REC_FLAG_DIRECT = 1, REC_FLAG_IMPRECISE = 2, REC_FLAG_CLAMPED = 4;
 // passes ~2.5e-5 and the direct residual takes over (recon / ||X|| < 1.4% resp. 4.5%).
 constexpr double RECON_DIRECT_THRESHOLD_LO = 2e-4;      // k <= 64
 constexpr double RECON_DIRECT_THRESHOLD = 2e-3;         // k > 64
+// + RECON_DIRECT_FACTOR_TERM / sqrt(min(m, n) k): the rounding of the sweeps' hi/lo-packed factors (16 mantissa bits,
+// 4e-6 per entry) enters <X^T U, V> through the min(m, n) k entries of the smaller factor and only averages over those
+constexpr double RECON_DIRECT_FACTOR_TERM = 0.13;
 constexpr int RESIDUAL_MAX_BLOCKS = 1024;
 
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

@@ -169,3 +169,43 @@ def test_embed_and_cv_helpers():
     V = rs.rand(30, 3)
     Xt = rs.rand(5, 3) @ V.T
     assert np.all(orc.measure_cv_performance(V, Xt) < 1e-6)
+
+
+def test_tradeoff_trace_conditioning(golden_dir, tmp_path, monkeypatch):
+    """How much of the GPU path's drift on `g6_api_tradeoff` (trace within 1.7e-3 of the reference's in the middle of the
+    run, tests/test_gpu_solver.py) is what ANY float32-state implementation shows?  The float64 oracle is run on that
+    input with the stopping rule off (tol = 0, all 1000 iterations, as the GPU test does): (a) as is, (b) with V_init
+    perturbed once by 1e-7 relative, (c) with U and V rounded to float32 after every update -- everything else, the
+    objective and gamma = delta = (1 - t) recon / (t manifold) (prmf_runner.py:542-548) included, still in float64.
+    Measured: (b) contracts (4e-8 -> 2e-9: the iteration is stable), (c) drifts by the amount printed below, which is
+    the yardstick for the GPU run."""
+    c = synth.cli_case(str(tmp_path), variant=1)
+    pws = _graphs_to_pathways(c)
+    m, n = c["X"].shape
+    exact_step = orc.update_step
+
+    def f32_state_step(X, U, V, active, gamma, delta):
+        U2, V2 = exact_step(X, U, V, active, gamma, delta)
+        return U2.astype(np.float32).astype(np.float64), V2.astype(np.float32).astype(np.float64)
+
+    runs = {}
+    for name, eps, step in (("exact", 0.0, exact_step), ("perturbed", 1e-7, exact_step), ("f32state", 0.0, f32_state_step)):
+        monkeypatch.setattr(orc, "update_step", step)
+        np.random.seed(1)
+        U0 = 3 * (1 - np.random.rand(m, 6))                      # the reference's own draws, in its order (:651-653)
+        V0 = 3 * (1 - np.random.rand(n, 6))
+        V0 = V0 * (1.0 + eps * np.random.RandomState(99).standard_normal(V0.shape))
+        trace = []
+        U, V, od = orc.nmf_pathway(c["X"], pws, gamma=1.0, tradeoff=0.5, k_latent=6, tol=0.0, U_init=U0, V_init=V0, trace=trace)
+        runs[name] = (np.array([t["obj"] for t in trace]), U, V)
+    t0, Ue, Ve = runs["exact"]
+    out = {}
+    for name in ("perturbed", "f32state"):
+        t1, U1, V1 = runs[name]
+        assert len(t0) == len(t1) == 1000
+        drift = np.abs(t1 - t0) / np.abs(t0)
+        out[name] = ([float(drift[a:a + 100].max()) for a in range(0, 1000, 100)], rel(U1, Ue), rel(V1, Ve))
+        print("[measured] tradeoff conditioning, %s: trace drift per 100 iterations %s final U %.1e V %.1e"
+              % (name, ["%.1e" % d for d in out[name][0]], out[name][1], out[name][2]))
+    assert max(out["perturbed"][0]) < 1e-6                       # a single perturbation dies out
+    assert out["f32state"][1] < 1e-4 and out["f32state"][2] < 1e-4

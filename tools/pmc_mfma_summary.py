@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""MFMA-pipe utilisation of the sweep launches from one rocprofv3 pass
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -- python3 bench.py ...
+Per dispatch: duration from the kernel trace, counters from the collection file (matched by dispatch id).
+  effective shader clock      = GRBM_GUI_ACTIVE / 8 / duration            (the counter is summed over the 8 XCDs; the guide's
+                                                                          DVFS note: reads high on dispatches < 0.3 ms)
+  MFMA pipe utilisation       = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)
+  algorithmic MFMA cycles     = 32 cycles x matrix instructions the arithmetic needs (stated per workload below)
+    python tools/pmc_mfma_summary.py DIR OUT.json WORKLOAD"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from prmf_amd.synthetic import CONFIGS  # noqa: E402
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", ""))
+    return re.sub(r"^void ", "", name).replace("prmf::", "")
+
+
+def main():
+    d, out, wl = sys.argv[1:4]
+    dur = {}
+    for fp in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(fp)):
+            dur[row["Dispatch_Id"]] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9
+    per = {}
+    for fp in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(fp)):
+            k = short(row["Kernel_Name"])
+            if not k.startswith("sweep_kernel"):
+                continue
+            e = per.setdefault(row["Dispatch_Id"], {"kernel": k})
+            e[row["Counter_Name"]] = e.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+    m, n, k, P, xd = CONFIGS[wl]
+    KP = (k + 31) // 32 * 32
+    per_frag = 2 if xd == "bf16" else 5                      # hi/lo factor pieces | three-piece split of f32 X
+    pad = lambda a, b: (a + b - 1) // b * b
+    n_mfma = (pad(m, 256) / 32) * (pad(n, 128) / 16) * (KP / 32) * per_frag
+    rows = [e for did, e in per.items() if did in dur and "GRBM_GUI_ACTIVE" in e]
+    rows = rows[len(rows) // 4:]                              # drop the warm-up launches
+    if not rows:
+        sys.exit("no sweep dispatches with counters found in %s" % d)
+    for did, e in per.items():
+        if did in dur:
+            e["duration_s"] = dur[did]
+    avg = lambda key: sum(e[key] for e in rows) / len(rows)
+    gui, mf, t = avg("GRBM_GUI_ACTIVE"), avg("SQ_VALU_MFMA_BUSY_CYCLES"), avg("duration_s")
+    res = {"workload": wl, "kernel": rows[0]["kernel"], "sweep_launches_averaged": len(rows),
+           "avg_duration_ms": t * 1e3, "GRBM_GUI_ACTIVE_per_launch": gui, "SQ_VALU_MFMA_BUSY_CYCLES_per_launch": mf,
+           "SQ_BUSY_CYCLES_per_launch": avg("SQ_BUSY_CYCLES") if "SQ_BUSY_CYCLES" in rows[0] else None,
+           "effective_clock_ghz": gui / 8.0 / t / 1e9,
+           "mfma_pipe_utilisation": mf / (1024.0 * gui / 8.0),
+           "algorithmic_mfma_instructions_per_launch": n_mfma, "algorithmic_mfma_cycles_per_launch": 32.0 * n_mfma,
+           "counter_over_algorithmic": mf / (32.0 * n_mfma),
+           "note": "under rocprofv3 --pmc the launches run slower than un-profiled ones (the guide's DVFS note (2)); utilisation = "
+                   "busy cycles / (1024 SIMDs x shader cycles of the launch)"}
+    json.dump(res, open(out, "w"), indent=1)
+    print("%-8s %s: %.3f ms/launch, clock %.2f GHz, MFMA pipe busy %.1f%% (counter / algorithmic = %.3f)" % (
+        wl, res["kernel"], t * 1e3, res["effective_clock_ghz"], 100 * res["mfma_pipe_utilisation"], res["counter_over_algorithmic"]))
+
+
+if __name__ == "__main__":
+    main()
