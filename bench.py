@@ -85,7 +85,10 @@ def cpu_baseline(torch, Xd, U0, V0, pathways, active, gamma, delta, m_full, budg
     m <= 25000 the full problem is timed and nothing is scaled."""
     from oracle import prmf_oracle as orc
     info = host_info()
-    threads = max([p.get("num_threads") or 1 for p in (info.get("blas") or [])] or [os.cpu_count() or 1])
+    # `cores` = the thread pool that ran the GEMMs (the BLAS pool; the OpenMP pool of the same process can be larger)
+    pools = info.get("blas") or []
+    blas_pools = [p.get("num_threads") or 1 for p in pools if p.get("user_api") == "blas"]
+    threads = max(blas_pools or [p.get("num_threads") or 1 for p in pools] or [os.cpu_count() or 1])
     n, k = V0.shape
     m2 = min(int(Xd.shape[0]), 25000)
     m1 = m2 // 2 if m2 < m_full else m2

@@ -6,23 +6,23 @@
 // workgroup, so the kernel is HBM-bound; MFMA does the arithmetic.
 //
 // Data layout
-//   A   row-major, zero padded to [round_up(M,256)] x [round_up(K,64)], so the
+//   A   row-major, zero padded to [round_up(M, 512)] x [round_up(K, 128)], so the
 //       kernel has no bounds checks on loads.  A reduction "chunk" is 128 B of
 //       each row (64 bf16 / 32 f32).
-//   B   packed on the device by pack_*_kernel into MFMA B-fragment order so one
-//       wave-wide 16 B/lane read is one fragment:
-//         bf16: block (kb, t, hl) of 1 KiB, kb = k/16, t = 32-column tile,
-//               hl = 0 hi / 1 lo;  lane (c = lane&31, h = lane>>5), element e:
-//               B[16 kb + 8 h + e][32 t + c]   split as hi = bf16(v), lo = bf16(v - hi)
-//         f32 : block (g, t) of 1 KiB, g = k/8; lane (c,h), element q (4 floats):
-//               B[8 g + 4 h + q][32 t + c]
-//       The packed chunk (all blocks of 64 resp. 32 reduction rows) is staged
+//   B   the factor, packed on the device (pack_bf16_kernel, or the epilogue that produced it) into MFMA B-fragment
+//       order so that one wave-wide 16 B/lane read is one fragment -- for bf16 X and f32 X alike:
+//         block (kb, t, hl) of 1 KiB, kb = k/16, t = 32-column tile, hl = 0 hi / 1 lo;
+//         lane (c = lane&31, h = lane>>5), element e:  B[16 kb + 8 h + e][32 t + c],
+//         split as hi = bf16(v), lo = bf16(v - hi)  (16 mantissa bits)
+//       The packed chunk (all blocks of the chunk's 64 resp. 32 reduction rows) is staged
 //       once per workgroup into LDS and shared by its 4 waves.
-//   C   per-split partial slabs [split][M][KP] f32, summed by the consumer kernel
-//       in a fixed order (deterministic; no atomics).
+//   C   per-segment partial slabs in MFMA fragment order, [slab][32-row tile][t][q4][lane][4 floats] (1 KiB per
+//       store / load instruction); which slabs hold a segment of a row panel is a per-panel bit mask, and the consumer
+//       kernel sums them in slab-index order (deterministic; no atomics).
 //
 // Wave tiling (wave64): a workgroup is 4 waves x 64 rows; each wave owns MT = 2 32-row tiles x NT 32-column tiles of
-// accumulators (v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32), so every B fragment read from LDS feeds two MFMAs.
+// accumulators (v_mfma_f32_32x32x16_bf16 throughout: f32 X is split exactly into three bf16 pieces in registers), so
+// every B fragment read from LDS feeds two MFMAs.
 // A is loaded line-complete (8 rows x 128 B per wave instruction, non-temporal), one chunk ahead of the MFMAs, and
 // bounced through a wave-private XOR-swizzled LDS tile from which the 16-B A fragments are read (see "A path" below:
 // fragment-shaped global loads were 22% slower).  B is staged once per workgroup per chunk through registers into LDS.

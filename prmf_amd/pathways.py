@@ -117,6 +117,30 @@ class PathwayLibrary(object):
             adjs.append(sub)
         return cls(n, supports, adjs, names)
 
+    # ---- cache (the built library as one .npz) -------------------------
+    def save(self, path, key=""):
+        """The flat arrays (what the GPU gets) + names + a caller-chosen `key` naming the inputs they were built from."""
+        np.savez_compressed(path, n=np.int64(self.n), names=np.array([str(x) for x in self.names]), key=np.array(str(key)),
+                            sup_ptr=self.sup_ptr, sup_idx=self.sup_idx, row_ptr=self.row_ptr, col_local=self.col_local, w=self.w)
+
+    @classmethod
+    def load(cls, path, key=None):
+        """Library saved by `save`; None if `key` is given and the file was built from something else (or is unreadable)."""
+        try:
+            z = np.load(path)
+            if key is not None and str(z["key"]) != str(key):
+                return None
+            sup_ptr, row_ptr = z["sup_ptr"], z["row_ptr"]
+            supports, adjs = [], []
+            for p in range(len(sup_ptr) - 1):
+                s0, s1 = int(sup_ptr[p]), int(sup_ptr[p + 1])
+                e0, e1 = int(row_ptr[s0]), int(row_ptr[s1])
+                supports.append(z["sup_idx"][s0:s1].astype(np.int64))
+                adjs.append(sp.csr_matrix((z["w"][e0:e1], z["col_local"][e0:e1], row_ptr[s0:s1 + 1] - e0), shape=(s1 - s0, s1 - s0)))
+            return cls(int(z["n"]), supports, adjs, [str(x) for x in z["names"]])
+        except (OSError, KeyError, ValueError):
+            return None
+
     # ---- host-side helpers used by the outer solver -------------------------
     def laplacian_quadratic(self, p, v):
         """v^T L_p v for a full-length vector v (force_distinct_lapls, :232)."""

@@ -295,6 +295,9 @@ Solve an optimization problem of the form
     parser.add_argument("--n-gpus", type=int, default=1,
                         help="shard the solve over N GPUs of this node: re-launches this command under torch.distributed.run "
                              "(one process per GPU); not needed when the command is already started by that launcher")
+    parser.add_argument("--library-cache", default=None,
+                        help="keep the built pathway library (support lists + support-local adjacency of every manifold over this "
+                             "nodelist) in this .npz file and reuse it when the same manifold files and nodelist come back")
     parser.add_argument("--dist-mode", default=None, choices=["colshard", "replicated"],
                         help="multi-GPU V update: sharded by latent columns (default) or replicated on every rank")
     args = parser.parse_args(argv)
@@ -362,10 +365,23 @@ def _run(args, rank, world):
         U_init, V_init = initial_factors(args, X, manifolds, nodelist, write=rank == 0)
 
     from .solver import measure_cv_performance, nmf_pathway
+    library = None
+    if args.library_cache:                                  # graphs -> W / D / L / supports once per (manifolds, nodelist)
+        import hashlib
+        from .pathways import PathwayLibrary
+        h = hashlib.sha256("\n".join(nodelist).encode())
+        for fp in manifolds.paths:
+            st = os.stat(fp)
+            h.update(("%s|%d|%d" % (os.path.abspath(fp), st.st_size, int(st.st_mtime))).encode())
+        library = PathwayLibrary.load(args.library_cache, key=h.hexdigest())
+        if library is None:
+            library = PathwayLibrary.from_graphs(manifolds.graphs, nodelist)       # exactly what nmf_pathway would build
+            if rank == 0:
+                library.save(args.library_cache, key=h.hexdigest())
     U, V, obj_data = nmf_pathway(X, manifolds.graphs, nodelist=nodelist, gamma=args.gamma,       # the GPU solve (:1067)
                                  tradeoff=None if args.tradeoff == -1 else args.tradeoff, k_latent=args.k_latent,
                                  U_init=U_init, V_init=V_init, verbose=args.verbose, x_dtype=args.x_dtype,
-                                 dist_mode=args.dist_mode)
+                                 dist_mode=args.dist_mode, library=library)
     if rank != 0:                                          # every rank holds the same U, V, obj_data; rank 0 writes them
         return
     if X_test is not None:                                 # :1073-1079: one sweep + batched NNLS (prmf/__init__.py:768-798)

@@ -396,3 +396,24 @@ def test_cv_error_vs_scipy_nnls(m, n, k, x_dtype):
         assert abs(got[5] - want[5]) < 1e-6 * want[5]
     else:                                                  # near-zero residual: sqrt of the float64 cancellation noise
         assert got[5] < 1e-6 and want[5] < 1e-6
+
+
+def test_cli_library_cache(golden_dir, tmp_path):
+    """--library-cache: the second run loads the pathway library from the .npz instead of rebuilding it from the graphs;
+    outputs are byte-identical to the first run's and match the reference golden."""
+    g = np.load(os.path.join(golden_dir, "g6_nonorm.npz"))
+    c = synth.cli_case(str(tmp_path), variant=1)
+    cache = str(tmp_path / "lib.npz")
+    outs = []
+    for run in range(2):
+        out = str(tmp_path / ("out%d" % run))
+        os.makedirs(out)
+        _cli(["--data", c["data"], "--manifolds"] + c["manifolds"] + ["--node-attribute", "name", "--nodelist", c["nodelist"],
+                                                                      "--outdir", out, "--delimiter", "\t", "--seed", "1", "--no-normalize",
+                                                                      "--library-cache", cache], str(tmp_path))
+        assert os.path.exists(cache)
+        outs.append([open(os.path.join(out, f)).read() for f in ("obj.txt", "U.csv", "V.csv")])
+    assert outs[0] == outs[1]
+    vals, mapping = _read_obj(str(tmp_path / "out1" / "obj.txt"))
+    assert mapping == json.loads(str(g["mapping"]))
+    assert max(obj_txt_errors(vals, json.loads(str(g["obj_txt"]))).values()) < TOL_OBJ

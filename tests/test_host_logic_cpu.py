@@ -135,3 +135,21 @@ def test_verbose_candidate_table_format(capsys):
     out = capsys.readouterr().out.splitlines()
     assert out == ["-----------------------------", "Latent to pathway match data:", "-----------------------------",
                    "Latent vector: 0", "  1\t1.5", "  3\t0.25", "Latent vector: 1", "  2\t2"]
+
+
+def test_pathway_library_cache_roundtrip(tmp_path):
+    """SURVEY 8f2: the built library as one .npz -- every array the GPU gets and the host-side helpers survive a save / load;
+    a cache built from other inputs (key mismatch) is refused."""
+    import synth
+    from prmf_amd import PathwayLibrary
+    case = synth.small_case(seed=4, n=300, P=5, order=30)
+    lib = PathwayLibrary.from_edge_lists(300, case["pathways"], names=["p%d" % i for i in range(5)])
+    fp = str(tmp_path / "lib.npz")
+    lib.save(fp, key="abc")
+    assert PathwayLibrary.load(fp, key="other") is None and PathwayLibrary.load(str(tmp_path / "missing.npz"), key="abc") is None
+    got = PathwayLibrary.load(fp, key="abc")
+    assert got.n == lib.n and got.P == lib.P and got.names == lib.names and got.max_support == lib.max_support
+    for a, b in zip(got.arrays(), lib.arrays()):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    v = np.random.RandomState(0).rand(300)
+    assert all(got.laplacian_quadratic(p, v) == lib.laplacian_quadratic(p, v) for p in range(5))
