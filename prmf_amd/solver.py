@@ -96,11 +96,21 @@ class PrmfEngine(object):
             pass
 
     def device_tensor(self, a, dtype=None):
-        """numpy / torch -> contiguous tensor on this engine's GPU."""
+        """numpy / torch -> contiguous tensor on this engine's GPU.  A large host matrix travels in row chunks in its own
+        dtype and is converted ON THE DEVICE: `from_numpy(X).to(device, dtype)` converts on one host thread first
+        (50000 x 20000 f32 -> bf16: 0.45 s, f64 -> f32: 0.91 s; chunked: 0.07 s = 54 GB/s, profiles/r03_outer_solver.txt)."""
         torch = self.torch
+        dev = "cuda:%d" % self.device
+        if isinstance(a, np.ndarray) and a.ndim == 2 and a.nbytes > (32 << 20) and a.dtype in (np.float32, np.float64):
+            a = np.ascontiguousarray(a)
+            out = torch.empty(a.shape, dtype=dtype or torch.from_numpy(a[:0]).dtype, device=dev)
+            rows = max(1, (160 << 20) // max(1, a.shape[1] * a.itemsize))
+            for r0 in range(0, a.shape[0], rows):
+                out[r0:r0 + rows] = torch.from_numpy(a[r0:r0 + rows]).to(device=dev)
+            return out
         if not isinstance(a, torch.Tensor):
             a = torch.from_numpy(np.ascontiguousarray(a))
-        return a.to(device="cuda:%d" % self.device, dtype=dtype or a.dtype).contiguous()
+        return a.to(device=dev, dtype=dtype or a.dtype).contiguous()
 
     # -- inputs ---------------------------------------------------------------
     def set_x(self, X, norm_x_sq=None):
@@ -442,23 +452,72 @@ def print_latent_to_pathway_data(latent_to_pathway_data, out=None):
     out.write("\n".join(lines) + "\n")
 
 
+def _max_weight_matching(per_latent):
+    """Maximum-weight matching between latent factors and candidate pathways: [(k, [(pathway, weight >= 0), ...]), ...]
+    -> [(k, pathway)], the matching networkx.max_weight_matching returns for the reference (prmf_runner.py:246).
+
+    networkx's blossom algorithm is pure Python (64 latents x 61 candidates each: 0.80 s, 700 000 calls of its `slack`;
+    cubic in the number of latents).  The graph is bipartite, so the same optimum is an assignment problem: solved by
+    scipy's linear_sum_assignment (C), and then PROVEN to be the only optimum -- another optimal matching would have to
+    leave out one of the matched edges, so the problem is re-solved once per matched edge with that edge removed and
+    every one of those optima must be strictly lighter.  A unique optimum is what any correct algorithm returns, networkx
+    included.  If the proof fails (exact ties, zero-weight edges) networkx itself is run: its tie-breaking stays the
+    contract."""
+    from scipy.optimize import linear_sum_assignment
+    lat = [k for k, _ws in per_latent]
+    paths = sorted({p for _k, ws in per_latent for p, _w in ws})
+    col = {p: j for j, p in enumerate(paths)}
+    W = np.zeros((len(lat), len(paths)))
+    generic = True
+    for i, (_k, ws) in enumerate(per_latent):
+        for p, w in ws:
+            W[i, col[p]] = w
+            generic = generic and w > 0
+    if generic and W.size:
+        def solve(M):
+            r, c = linear_sum_assignment(M, maximize=True)
+            keep = M[r, c] > 0
+            return r[keep], c[keep], math.fsum(M[r, c][keep])
+        r, c, best = solve(W)
+        unique = best > 0
+        for i, j in zip(r, c):
+            if not unique:
+                break
+            w = W[i, j]
+            W[i, j] = 0.0
+            unique = solve(W)[2] < best * (1.0 - 1e-9)
+            W[i, j] = w
+        if unique:
+            return [(lat[i], paths[j]) for i, j in zip(r, c)]
+    import networkx as nx
+    G = nx.Graph()
+    for k, ws in per_latent:
+        for p, w in ws:
+            G.add_edge("k{}".format(k), "l{}".format(p), weight=w)
+    out = []
+    for a, b in nx.max_weight_matching(G):
+        if a[0] != "k":
+            a, b = b, a
+        out.append((int(a[1:]), int(b[1:])))
+    return out
+
+
 def force_distinct_lapls(V, library, latent_to_pathway_data, k_to_lapl, gamma, delta):
     """prmf_runner.py:209-258: max-weight matching between latent factors and their
     remaining candidate pathways, weight 1/(gamma v^T L v + delta*ignore).  As in the
     reference the ignore term is overwritten (not summed) over the active supports
     (:233-235), so it is the last latent's value."""
-    import networkx as nx
-    G = nx.Graph()
     k_last = max(k_to_lapl.keys())
     ign = float(np.sum(1.0 / (V[library.supports[k_to_lapl[k_last]], k_last] + 1)))
+    per_latent = []
     for k, data in latent_to_pathway_data.items():
+        ws = []
         for lapl, _score in data:
             denom = gamma * library.laplacian_quadratic(lapl, V[:, k]) + delta * ign
-            G.add_edge("k{}".format(k), "l{}".format(lapl), weight=0 if denom == 0 else 1 / denom)
-    for a, b in nx.max_weight_matching(G):
-        if a[0] != "k":
-            a, b = b, a
-        latent_to_pathway_data[int(a[1:])] = [(int(b[1:]), 2)]
+            ws.append((lapl, 0 if denom == 0 else 1 / denom))
+        per_latent.append((k, ws))
+    for k, p in _max_weight_matching(per_latent):
+        latent_to_pathway_data[k] = [(p, 2)]
     return latent_to_pathway_data
 
 

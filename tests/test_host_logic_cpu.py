@@ -153,3 +153,29 @@ def test_pathway_library_cache_roundtrip(tmp_path):
         assert a.dtype == b.dtype and np.array_equal(a, b)
     v = np.random.RandomState(0).rand(300)
     assert all(got.laplacian_quadratic(p, v) == lib.laplacian_quadratic(p, v) for p in range(5))
+
+
+def test_fast_matching_equals_networkx():
+    """force_distinct_lapls solves the latent <-> pathway matching as an assignment problem and proves the optimum unique
+    before trusting it (solver._max_weight_matching); on random instances -- more latents than pathways, fewer, sparse
+    candidate lists, exact ties, zero weights -- the result must be networkx.max_weight_matching's."""
+    import networkx as nx
+    rs = np.random.RandomState(3)
+    for trial in range(60):
+        K, P = rs.randint(1, 10), rs.randint(1, 30)
+        per_latent = []
+        for k in range(K):
+            cand = sorted(rs.choice(P, size=rs.randint(1, P + 1), replace=False).tolist())
+            if trial % 6 == 4:
+                ws = [(p, float(rs.randint(1, 4))) for p in cand]              # ties
+            elif trial % 6 == 5:
+                ws = [(p, float(rs.rand() > 0.5) * rs.rand()) for p in cand]   # zero weights
+            else:
+                ws = [(p, float(rs.rand()) + 1e-3) for p in cand]
+            per_latent.append((k, ws))
+        G = nx.Graph()
+        for k, ws in per_latent:
+            for p, w in ws:
+                G.add_edge("k%d" % k, "l%d" % p, weight=w)
+        want = sorted((int(a[1:]), int(b[1:])) if a[0] == "k" else (int(b[1:]), int(a[1:])) for a, b in nx.max_weight_matching(G))
+        assert sorted(solver._max_weight_matching(per_latent)) == want, trial
