@@ -362,19 +362,21 @@ double direct_below(const prmf_ctx* c) {
 
 // The launches behind a record whose kernel may have raised c->need_dev: sum (X - U V^T)^2 over this rank's rows (the
 // kernels return at once when the flag is clear), the sum over ranks, and the rewrite of the record.
-int direct_residual(prmf_ctx* c, double* record, bool feedback, hipStream_t s) {
+// `on_device_flag`: the kernels look at c->need_dev themselves (per-iteration form: no host round trip between the
+// iterations); false: the host has already seen the flag raised (prmf_end) and the kernels run unconditionally.
+int direct_residual(prmf_ctx* c, double* record, bool feedback, bool on_device_flag, hipStream_t s) {
   int nparts = 0;
+  const int* need = on_device_flag ? c->need_dev : c->need_dev + 1;     // need_dev[1] is a constant 1
   if (c->m > 0) {
-    HIP_TRY(c, launch_residual(c->x_dtype, c->X, c->ldx, c->m, c->n, c->k, c->U, c->V, c->n_cus, c->resid_partial, &nparts,
-                               c->need_dev, s));
+    HIP_TRY(c, launch_residual(c->x_dtype, c->X, c->ldx, c->m, c->n, c->k, c->U, c->V, c->n_cus, c->resid_partial, &nparts, need, s));
   }
   if (c->nranks == 1) {
-    HIP_TRY(c, launch_residual_sum(c->resid_partial, nparts, c->need_dev, c->resid_sq, record, c->hyper, feedback, s));
+    HIP_TRY(c, launch_residual_sum(c->resid_partial, nparts, need, c->resid_sq, record, c->hyper, feedback, s));
     return PRMF_OK;
   }
-  HIP_TRY(c, launch_residual_sum(c->resid_partial, nparts, c->need_dev, c->resid_sq, nullptr, nullptr, false, s));
+  HIP_TRY(c, launch_residual_sum(c->resid_partial, nparts, need, c->resid_sq, nullptr, nullptr, false, s));
   NCCL_TRY(c, rccl().AllReduce(c->resid_sq, c->resid_sq, 1, ncclFloat64, ncclSum, c->comm, s));
-  HIP_TRY(c, launch_record_fix(c->need_dev, c->resid_sq, record, c->hyper, feedback, s));
+  HIP_TRY(c, launch_record_fix(need, c->resid_sq, record, c->hyper, feedback, s));
   return PRMF_OK;
 }
 
@@ -384,7 +386,7 @@ int finalize_record(prmf_ctx* c, const double* loc_partial, int loc_nblocks, con
   const bool direct = direct_available(c);
   HIP_TRY(c, launch_finalize(c->gram_buf, c->Gv, c->k, c->v_recv, c->lr, c->v_send_floats, c->extras_off, c->norm_x_sq, c->hyper,
                              record, loc_partial, loc_nblocks, loc_colres, direct ? c->need_dev : nullptr, direct_forced(c), direct_below(c), s));
-  if (direct) return direct_residual(c, record, true, s);
+  if (direct) return direct_residual(c, record, true, true, s);
   return PRMF_OK;
 }
 
@@ -487,6 +489,10 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, &c->records, (size_t)MAX_RECORDS * PRMF_OBJ_STRIDE))) return bail(rc);
   if ((rc = dev_alloc(c, &c->colnorm, (size_t)k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->need_dev, 2))) return bail(rc);
+  {
+    const int one = 1;                 // need_dev[0]: the request flag the record kernels raise; need_dev[1]: always 1
+    if (hipMemcpy(c->need_dev + 1, &one, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { fail(c, PRMF_ERR_HIP, "hipMemcpy failed"); return bail(PRMF_ERR_HIP); }
+  }
   if ((rc = dev_alloc(c, &c->resid_partial, (size_t)4 * RESIDUAL_MAX_BLOCKS))) return bail(rc);
   if ((rc = dev_alloc(c, &c->resid_sq, 2))) return bail(rc);
   if ((rc = dev_alloc(c, &c->Gu_keep, (size_t)(MAX_RECORDS + 1) * k * k, false))) return bail(rc);
@@ -920,6 +926,7 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
   int rc;
   if ((rc = set_device(c))) return rc;
   hipStream_t s = (hipStream_t)stream;
+  bool lazy_direct = false;
   if (c->lazy) {
     if (c->gv_pending) {               // no sweep follows the last iteration: its V side is closed by a launch of its own
       HIP_TRY(c, launch_prologue_alone(post_prologue(c, c->cursor - 1), s));
@@ -931,15 +938,26 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
     const bool direct = direct_available(c) && c->cursor > 0;
     HIP_TRY(c, launch_records_all(c->Gu_keep, c->Gv_keep, c->k, c->cursor, c->cross_ring, c->colres_ring, c->norm_x_sq, c->hyper,
                                   c->records, direct ? c->need_dev : nullptr, false, direct_below(c), s));
-    // the last record of the batch is the one the outer loop acts on: direct residual if its identity value is too small
-    if (direct && (rc = direct_residual(c, c->records + (size_t)(c->cursor - 1) * PRMF_OBJ_STRIDE, false, s))) return rc;
+    lazy_direct = direct;
   }
   c->batch_open = false;
   if (n_steps > 0)
     HIP_TRY(c, hipMemcpyAsync(c->records_host, c->records + (size_t)(c->cursor - n_steps) * PRMF_OBJ_STRIDE,
                               (size_t)n_steps * PRMF_OBJ_STRIDE * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipMemcpyAsync(c->hyper_host, c->hyper, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (lazy_direct) HIP_TRY(c, hipMemcpyAsync(c->hyper_host + 3, c->need_dev, sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
+  // The last record of the batch is the one the outer loop acts on: if its identity-based recon^2 was too small to trust
+  // (the record kernel raised the flag -- identically on every rank), the direct residual is evaluated now and that
+  // record is fetched again.  The common case costs nothing: no launch, no second synchronisation.
+  if (lazy_direct && *reinterpret_cast<const int*>(c->hyper_host + 3) != 0) {
+    double* last = c->records + (size_t)(c->cursor - 1) * PRMF_OBJ_STRIDE;
+    if ((rc = direct_residual(c, last, false, false, s))) return rc;
+    if (n_steps > 0)
+      HIP_TRY(c, hipMemcpyAsync(c->records_host + (size_t)(n_steps - 1) * PRMF_OBJ_STRIDE, last, PRMF_OBJ_STRIDE * sizeof(double),
+                                hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+  }
   if ((c->flags & PRMF_FLAG_TIMING) && c->m > 0) {
     c->ms_xv = c->ms_xtu = 0;
     c->timed_iters = 0;
