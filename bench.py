@@ -9,9 +9,10 @@ BASELINE.json's target is quoted on (c3: X 50000 x 20000 bf16, k = 64, 300 tree
 pathways).  X, U, V are resident in HBM before the timed
 region.  With N > 1 (launched by torch.distributed.run, one rank per GPU) the
 SAME global problem is row-sharded over the ranks (strong scaling); per iteration the
-k x k Gram U^T U is all-reduced and the n x k product X^T U is reduce-scattered by owner column block, the V update is
-sharded by latent column and V is all-gathered (--dist-mode colshard, the default), or X^T U is all-reduced and every
-rank updates all of V (--dist-mode replicated); RCCL issued inside the library.  Rank 0 prints one JSON line.
+k x k Gram U^T U is all-reduced together with the reduce-scatter of the n x k product X^T U by owner column block (one RCCL
+group), the V update is sharded by latent column and V is all-gathered (--dist-mode colshard, the default everywhere), or
+X^T U is all-reduced and every rank updates all of V (--dist-mode replicated); RCCL issued inside the library.  Rank 0
+prints one JSON line.
 """
 import argparse
 import json
@@ -281,9 +282,9 @@ def main():
             out["distributed"] = {
                 "mode": ci["mode"], "collectives": "in-library RCCL (prmf_step_dist)" if runner.native else "host-driven (torch.distributed)",
                 "rccl_comm_world_size": ci["comm_nranks"], "torch_world_size": world,
-                "exchanges_per_iteration": (["all_reduce U^T U (k*k f64, side stream)", "reduce_scatter X^T U (n*k/N f32 per rank)",
-                                             "all_gather V (n*k/N f32 per rank)"] if ci["mode"] == "colshard" else
-                                            ["all_reduce U^T U (k*k f64, side stream)", "all_reduce X^T U (n*k f32)"]),
+                "exchanges_per_iteration": (["one RCCL group: all_reduce U^T U (k*k f64) + reduce_scatter X^T U (n*k/N f32 per rank)",
+                                             "all_gather V (n*k/N f32 per rank + the own-column update's sums)"] if ci["mode"] == "colshard" else
+                                            ["one RCCL group: all_reduce U^T U (k*k f64) + all_reduce X^T U (n*k f32)"]),
                 "phase_ms_rank0": dict(zip(["phase_u", "phase_q+exchange", "phase_v+exchange", "phase_post"], ci["ms_phase"]))}
         if backend != "nccl":
             out["config"]["rehearsal"] = "ranks share one GPU, exchanges staged through the host (%s): not a measurement" % backend
