@@ -256,6 +256,9 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&ac
 // 50000x20000 about 1e-5 of the wave-steps saw an OLDER load still outstanding with only the N youngest
 // pending -> 2-4 wrong 32-row tiles per launch, different every run.  The design therefore never carries a
 // load across a chunk boundary: every chunk ends with all of its loads landed and stored.
+// (Round 3 re-tried two chunks in flight for the 32-row-tile sweeps with plain C++ loads into a second register set --
+// compiler-counted waits, correct -- and it is not faster either: 5000 x 10000 f32 k = 16 0.0447 -> 0.0459 ms,
+// profiles/r03_ab_two_chunks_in_flight.txt.)
 
 #ifndef PRMF_A_NT
 #define PRMF_A_NT 1
