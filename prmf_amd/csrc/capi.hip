@@ -117,6 +117,7 @@ struct prmf_ctx {
   double* hyper_host = nullptr;       // pinned
   double* records = nullptr;          // device [MAX_RECORDS][8]
   double* records_host = nullptr;     // pinned
+  int* need_host = nullptr;           // pinned: the direct-residual request of the batch's last record (prmf_end)
   int cursor = 0;
 
   // bound factors
@@ -500,7 +501,8 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   if ((rc = dev_alloc(c, &c->colnorm2_ring, (size_t)(MAX_RECORDS + 1) * k))) return bail(rc);
   if ((rc = dev_alloc(c, &c->cross_ring, (size_t)MAX_RECORDS + 1))) return bail(rc);
   if ((rc = dev_alloc(c, &c->colres_ring, (size_t)MAX_RECORDS * k * 2))) return bail(rc);
-  if (hipHostMalloc((void**)&c->hyper_host, 4 * sizeof(double)) != hipSuccess ||
+  if (hipHostMalloc((void**)&c->need_host, 2 * sizeof(int)) != hipSuccess ||
+      hipHostMalloc((void**)&c->hyper_host, 4 * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&c->records_host, (size_t)MAX_RECORDS * PRMF_OBJ_STRIDE * sizeof(double)) != hipSuccess) {
     fail(c, PRMF_ERR_HIP, "hipHostMalloc failed");
     return bail(PRMF_ERR_HIP);
@@ -557,6 +559,7 @@ int prmf_destroy(prmf_ctx* c) {
   dev_free(c->vsup_ring);
   dev_free(c->scores_dev);
   if (c->hyper_host) (void)hipHostFree(c->hyper_host);
+  if (c->need_host) (void)hipHostFree(c->need_host);
   if (c->records_host) (void)hipHostFree(c->records_host);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -945,12 +948,12 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
     HIP_TRY(c, hipMemcpyAsync(c->records_host, c->records + (size_t)(c->cursor - n_steps) * PRMF_OBJ_STRIDE,
                               (size_t)n_steps * PRMF_OBJ_STRIDE * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipMemcpyAsync(c->hyper_host, c->hyper, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (lazy_direct) HIP_TRY(c, hipMemcpyAsync(c->hyper_host + 3, c->need_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (lazy_direct) HIP_TRY(c, hipMemcpyAsync(c->need_host, c->need_dev, sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   // The last record of the batch is the one the outer loop acts on: if its identity-based recon^2 was too small to trust
   // (the record kernel raised the flag -- identically on every rank), the direct residual is evaluated now and that
   // record is fetched again.  The common case costs nothing: no launch, no second synchronisation.
-  if (lazy_direct && *reinterpret_cast<const int*>(c->hyper_host + 3) != 0) {
+  if (lazy_direct && c->need_host[0] != 0) {
     double* last = c->records + (size_t)(c->cursor - 1) * PRMF_OBJ_STRIDE;
     if ((rc = direct_residual(c, last, false, false, s))) return rc;
     if (n_steps > 0)
