@@ -249,7 +249,7 @@ int check_ready(prmf_ctx* c) {
   if (!c->have_x) return fail(c, PRMF_ERR_STATE, "prmf_set_x has not been called");
   if (!c->have_lib) return fail(c, PRMF_ERR_STATE, "prmf_set_pathway_library has not been called");
   if (!c->have_active) return fail(c, PRMF_ERR_STATE, "prmf_set_active has not been called");
-  if (!c->U || !c->V) return fail(c, PRMF_ERR_STATE, "factors are not bound (prmf_begin / prmf_step)");
+  if ((c->m > 0 && !c->U) || !c->V) return fail(c, PRMF_ERR_STATE, "factors are not bound (prmf_begin / prmf_step)");
   if (!c->gram_buf || !c->q_send || !c->q_recv || !c->v_send || !c->v_recv)
     return fail(c, PRMF_ERR_STATE, "communication buffers are not set (prmf_set_comm_buffers)");
   return PRMF_OK;

@@ -307,3 +307,66 @@ def test_in_library_step_two_ranks_at_real_share_shapes(workload, mode, tmp_path
     assert eu < 1e-5 and ev < 1e-5
     for key, v in eo.items():
         assert v < 1e-5, (key, v)
+
+
+def _empty_rank_worker(rank, world, port, mode, mock, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if mock:
+        os.environ["PRMF_RCCL_LIB"] = mock
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from prmf_amd import PathwayLibrary
+        from prmf_amd.distributed import DistributedPrmf
+        from prmf_amd.solver import PrmfEngine
+        from prmf_amd.synthetic import shard_rows
+        case = synth.small_case(seed=19, m=1, n=90, k=4, P=3, order=12, zero_genes=2, isolated=1)
+        X = case["X"]
+        lo, hi = shard_rows(X.shape[0], world, rank)           # rank 0: the one sample; rank 1: no rows at all
+        eng = PrmfEngine(hi - lo, X.shape[1], 4, x_dtype="f32", device=0, nranks=world, rank=rank, dist_mode=mode)
+        eng.set_x(X[lo:hi], norm_x_sq=float(np.sum(X * X)))
+        eng.set_library(PathwayLibrary.from_edge_lists(X.shape[1], case["pathways"]))
+        eng.set_active(np.arange(4) % 3)
+        U = eng.device_tensor(case["U0"][lo:hi], torch.float32)
+        V = eng.device_tensor(case["V0"], torch.float32)
+        objs, gd = DistributedPrmf(eng, native=True if mock else None).step(U, V, 5, case["gamma"], case["delta"])
+        q.put((rank, U.cpu().numpy(), V.cpu().numpy(), objs))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,native", [("colshard", True), ("replicated", True), ("colshard", False), ("replicated", False)])
+def test_rank_without_samples(mode, native, tmp_path):
+    """One sample on two ranks: rank 1 holds no rows of X (no sweeps, zero contributions to both exchanges) but still
+    updates its share of V and keeps the same records as rank 0."""
+    import subprocess
+    import torch.multiprocessing as mp
+    from oracle import prmf_oracle as orc
+    mock = None
+    if native:
+        mock = str(tmp_path / "libmock_rccl.so")
+        cc = subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                             os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "mock_rccl.cpp"), "-o", mock,
+                             "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"], capture_output=True, text=True)
+        assert cc.returncode == 0, cc.stderr[-2000:]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_empty_rank_worker, args=(r, 2, port, mode, mock, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = _collect(procs, q)
+    assert res[1][0].shape[0] == 0 and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+    case = synth.small_case(seed=19, m=1, n=90, k=4, P=3, order=12, zero_genes=2, isolated=1)
+    pws = [orc.pathway_from_edges(90, e, nodes, w) for (e, w, nodes) in case["pathways"]]
+    tr = []
+    Ur, Vr, od = orc.nmf_manifold_vec_update(case["X"], case["U0"], case["V0"], [pws[i % 3] for i in range(4)], n_steps=5,
+                                             gamma=case["gamma"], delta=case["delta"], trace=tr)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert rel(res[0][0], Ur) < 1e-4 and rel(res[0][1], Vr) < 1e-4
+    for a, b in zip(res[0][2], tr):
+        for key in ("recon", "manifold", "ignore", "fro", "obj"):
+            assert abs(a[key] - b[key]) <= 1e-4 * max(abs(b[key]), 1e-12), key
