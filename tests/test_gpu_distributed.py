@@ -370,3 +370,70 @@ def test_rank_without_samples(mode, native, tmp_path):
     for a, b in zip(res[0][2], tr):
         for key in ("recon", "manifold", "ignore", "fro", "obj"):
             assert abs(a[key] - b[key]) <= 1e-4 * max(abs(b[key]), 1e-12), key
+
+
+def _tradeoff_worker(rank, world, port, mode, mock, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if mock:
+        os.environ["PRMF_RCCL_LIB"] = mock
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from prmf_amd import PathwayLibrary
+        from prmf_amd.distributed import DistributedPrmf
+        from prmf_amd.solver import PrmfEngine
+        from prmf_amd.synthetic import shard_rows
+        case = synth.small_case(seed=23, m=301, n=800, k=8, P=4, order=60)
+        X = case["X"]
+        lo, hi = shard_rows(X.shape[0], world, rank)
+        eng = PrmfEngine(hi - lo, X.shape[1], 8, x_dtype="f32", device=0, nranks=world, rank=rank, dist_mode=mode)
+        eng.set_x(X[lo:hi], norm_x_sq=float(np.sum(X * X)))
+        eng.set_library(PathwayLibrary.from_edge_lists(X.shape[1], case["pathways"]))
+        eng.set_active(np.arange(8) % 4)
+        U = eng.device_tensor(case["U0"][lo:hi], torch.float32)
+        V = eng.device_tensor(case["V0"], torch.float32)
+        objs, gd = DistributedPrmf(eng, native=True if mock else None).step(U, V, 6, case["gamma"], case["delta"], tradeoff=0.4)
+        q.put((rank, U.cpu().numpy(), V.cpu().numpy(), objs, gd, list(eng.last_flags)))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,native", [("colshard", True), ("replicated", True), ("colshard", False)])
+def test_two_ranks_tradeoff_feedback(mode, native, tmp_path):
+    """gamma = delta = (1 - t) recon / (t manifold) (prmf_runner.py:542-548) on two ranks: the per-iteration objective,
+    with the in-library step every record from the direct residual (the ranks' sums all-reduced each iteration), host-driven
+    from the Gram identity -- against the oracle's tradeoff loop."""
+    import subprocess
+    import torch.multiprocessing as mp
+    from oracle import prmf_oracle as orc
+    mock = None
+    if native:
+        mock = str(tmp_path / "libmock_rccl.so")
+        cc = subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                             os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "mock_rccl.cpp"), "-o", mock,
+                             "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"], capture_output=True, text=True)
+        assert cc.returncode == 0, cc.stderr[-2000:]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tradeoff_worker, args=(r, 2, port, mode, mock, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = _collect(procs, q)
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2] and res[0][3] == res[1][3]
+    assert all(bool(f & 1) == native for f in res[0][4]), res[0][4]       # direct residual exactly when the library can sum the ranks
+    case = synth.small_case(seed=23, m=301, n=800, k=8, P=4, order=60)
+    pws = [orc.pathway_from_edges(800, e, nodes, w) for (e, w, nodes) in case["pathways"]]
+    tr = []
+    Ur, Vr, od, g_ref, d_ref = orc.nmf_manifold_vec_update_tradeoff(case["X"], case["U0"], case["V0"], [pws[i % 4] for i in range(8)],
+                                                                   n_steps=6, tradeoff=0.4, gamma=case["gamma"], delta=case["delta"], trace=tr)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    U = np.concatenate([res[0][0], res[1][0]])
+    assert rel(U, Ur) < 1e-4 and rel(res[0][1], Vr) < 1e-4
+    for a, b in zip(res[0][2], tr):
+        for key in ("recon", "manifold", "ignore", "fro", "gamma", "delta", "obj"):
+            assert abs(a[key] - b[key]) <= 1e-4 * max(abs(b[key]), 1e-12), key
+    assert abs(res[0][3][0] - g_ref) <= 1e-4 * abs(g_ref)
