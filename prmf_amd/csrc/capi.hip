@@ -757,7 +757,7 @@ int prmf_begin(prmf_ctx* c, float* dU, float* dV, double gamma, double delta, do
   // off (with it on, gamma / delta of step t + 1 need the record of step t) -- one rank and both multi-rank modes.
   // Decided per rank; the exchanges do not depend on it.
   c->tradeoff_on = tradeoff >= 0.0;
-  c->lazy = !c->tradeoff_on && c->plan_xv.nw == 4 && c->plan_xtu.nw == 4 && c->vsup_ring &&
+  c->lazy = !c->tradeoff_on && c->vsup_ring &&
             !(c->flags & (PRMF_FLAG_EAGER_OBJECTIVE | PRMF_FLAG_DIRECT_RESIDUAL));
   c->batch_open = true;
   return PRMF_OK;

@@ -316,7 +316,7 @@ __device__ __forceinline__ void store_b_chunk(u32x4* sb, const u32x4 (&src)[NB],
 //              workgroup -> more resident workgroups (bytes in flight) per CU
 // The chunk loop is unrolled x2 with compile-time LDS buffer offsets; a segment may have any number of chunks.
 template <int MODE, int MT, int NT, int NW, bool BDB>
-__global__ void __launch_bounds__(64 * NW, PRMF_SWEEP_MINW)   // two workgroups per CU: at most 256 registers (arch + accumulator) per wave
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : PRMF_SWEEP_MINW)   // two workgroups of 4 waves per CU, or one of 8: at most 256 registers (arch + accumulator) per wave
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
              const uint4* __restrict__ Bp, int npanels, int g_begin, int ngroups /* work units (UNIT chunks each) [g_begin, g_begin+ngroups) of every row */,
              int nx, int pmax, int seg_base, float* __restrict__ slabs, int64_t slab_stride, int slab_nt,
@@ -325,14 +325,21 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   constexpr int NTHR = 64 * NW;
   constexpr int BCH = MODE == 1 ? 512 * NT : 256 * NT;   // uint4 per packed chunk (64 bf16 or 32 f32 elements of the reduction)
   constexpr int BPT = (BCH + NTHR - 1) / NTHR;      // uint4 staged per thread per chunk (last one may be partial)
-  __shared__ u32x4 sB[BDB ? 2 : 1][BCH];
-  __shared__ u32x4 sA[NW][MT * 256];                // per wave: MT tiles of 32 rows x 128 B
+  // LDS: the factor chunk (double-buffered if BDB) and one A tile per wave (MT tiles of 32 rows x 128 B).  The 8-wave shape
+  // with a double-buffered k = 128 chunk needs 128 KiB: dynamic shared memory there, static arrays everywhere else.
+  constexpr bool DYN_LDS = NW == 8;
+  constexpr int LDS_B = (BDB ? 2 : 1) * BCH, LDS_A = NW * MT * 256;
+  extern __shared__ u32x4 sweep_dyn_lds[];
+  __shared__ u32x4 sweep_stat_lds[DYN_LDS ? 1 : LDS_B + LDS_A];
+  u32x4* const lds_base = DYN_LDS ? sweep_dyn_lds : sweep_stat_lds;
+  u32x4 (*const sB)[BCH] = reinterpret_cast<u32x4 (*)[BCH]>(lds_base);
+  u32x4 (*const sA)[MT * 256] = reinterpret_cast<u32x4 (*)[MT * 256]>(lds_base + LDS_B);
 
   // the small reductions between the epilogue before this sweep and the one after it (prologue.h); the LDS
   // scratch is the A tile area (>= 16 KiB with 4 waves x 64 rows), untouched until the main loop's own prologue
-  if constexpr (NW == 4) {
+  if constexpr (NW == 4 || NW == 8) {
     if (pro.kind != PROLOGUE_NONE) {
-      run_sweep_prologue(pro, reinterpret_cast<char*>(&sA[0][0]), (int)sizeof(sA));
+      run_sweep_prologue(pro, reinterpret_cast<char*>(&sA[0][0]), LDS_A * 16);
       __syncthreads();
     }
   }
@@ -523,7 +530,13 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 //   4 waves x 64 rows (MT = 2), two workgroups per CU;
 //   k <= 64: factor chunk double-buffered in LDS (32 KiB of A tiles + 2 x 8 NT KiB), one barrier per chunk;
 //   k  > 64: factor chunk single-buffered (k = 128: 32 + 32 KiB, 116 VGPRs + 128 accumulator registers), two barriers.
-constexpr int SWEEP_NW = 4, SWEEP_MT = 2, SWEEP_WGS_PER_CU = 2;
+//   bf16 X, k > 64, packed factor >= 32 MB (round 3): ONE workgroup of 8 waves x 64 rows per CU with the factor chunk
+//   double-buffered (64 KiB of A tiles + 2 x 32 KiB at k = 128, dynamic LDS), one barrier per chunk.  Same-session A/B
+//   (profiles/r03_ab_k128_8wave_double_buffer.txt): X^T U of 200000 x 25000 (102 MB factor, re-read from the Infinity
+//   Cache by every segment) 2.62 -> 2.21 ms; with a 12.8 MB factor -2% at 25000 rows and +7% at 200000 rows -- hence the
+//   threshold.
+constexpr int SWEEP_NW = 4, SWEEP_MT = 2, SWEEP_WGS_PER_CU = 2, SWEEP_NW_WIDE = 8;
+constexpr double SWEEP_WIDE_FACTOR_BYTES = 32.0 * 1024 * 1024;
 
 // 32-row tiles per wave.  bf16 X: 2 at every k.  f32 X (three-piece split, two accumulator sets): 2 at k = 33..64; 1 at
 // k > 64, where two do not fit 256 registers, and at k <= 32, where the 128-row panels measure 4% faster on the
@@ -536,12 +549,18 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
   p.nw = SWEEP_NW;
   p.bdb = NT <= 2;
   p.mt = f32_wave_tiles(x_dtype, NT);
-  p.panel_rows = SWEEP_NW * 32 * p.mt;
+  // bf16 X, k > 64, a factor far beyond the caches (the X^T U sweep of 200000 samples: 102 MB): one 8-wave workgroup per
+  // CU on 512-row panels -- every 32 KiB factor chunk then serves twice the rows -- with the chunk double-buffered
+  if (x_dtype == 1 && NT > 2 && (double)Kpad * 32.0 * NT * 4.0 >= SWEEP_WIDE_FACTOR_BYTES) {
+    p.nw = SWEEP_NW_WIDE;
+    p.bdb = true;
+  }
+  p.panel_rows = p.nw * 32 * p.mt;
   p.panels = (int)(round_up(M, p.panel_rows) / p.panel_rows);
   p.nchunks = (int)(Kpad / chunk_elems(x_dtype));          // even (K_PAD)
   p.ngroups = p.nchunks / UNIT;                            // work units per row panel
   // one workgroup per resident slot (a multiple of 8: one share per XCD), but at least 8 chunks each
-  int64_t G = (int64_t)n_cus * SWEEP_WGS_PER_CU;
+  int64_t G = (int64_t)n_cus * (p.nw == SWEEP_NW_WIDE ? 1 : SWEEP_WGS_PER_CU);
   const int64_t total_units = (int64_t)p.panels * p.ngroups;
   if (G > total_units * UNIT / 8) G = total_units * UNIT / 8;
   G = G / 8 * 8;
@@ -621,11 +640,24 @@ unsigned long long* g_sweep_stamps = nullptr;   // debug: per-workgroup start/en
 template <int MODE, int NW, bool BDB, int MTV>
 static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda16, int64_t M_store, const void* Bp,
                                   int NT, float* slabs, int64_t slab_stride, hipStream_t s, const SweepPrologue& pro) {
+  // dynamic LDS only for the 8-wave shape (see the kernel)
+  const size_t dyn = NW == 8 ? (size_t)((BDB ? 2 : 1) * (MODE == 1 ? 512 : 256) * NT + NW * MTV * 256) * 16 : 0;
 #define PRMF_LAUNCH(NTV)                                                                                       \
-  sweep_kernel<MODE, MTV, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), 0, s>>>(                                  \
+  if (dyn > 64 * 1024) {                                                                                       \
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<MODE, MTV, NTV, NW, BDB>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);           \
+    if (ea != hipSuccess) return ea;                                                                           \
+  }                                                                                                            \
+  sweep_kernel<MODE, MTV, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), dyn, s>>>(                                \
       (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, 0, p.ngroups, p.nx, p.pmax, 0, slabs, slab_stride, \
       p.slab_nt ? 1 : 0, g_sweep_stamps, pro)
-  if constexpr (BDB) {
+  if constexpr (NW == 8) {
+    switch (NT) {
+      case 3: PRMF_LAUNCH(3); break;
+      case 4: PRMF_LAUNCH(4); break;
+      default: return hipErrorInvalidValue;
+    }
+  } else if constexpr (BDB) {
     switch (NT) {
       case 1: PRMF_LAUNCH(1); break;
       case 2: PRMF_LAUNCH(2); break;
@@ -647,13 +679,14 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
                        const SweepPrologue* prologue) {
   const int64_t lda16 = lda * elem_bytes(x_dtype) / 16;
   SweepPrologue pro = prologue ? *prologue : SweepPrologue{};
-  if (pro.kind != PROLOGUE_NONE && (p.nw != 4 || pro.nparts > GRAM_MAX_PARTS)) return hipErrorInvalidValue;
+  if (pro.kind != PROLOGUE_NONE && pro.nparts > GRAM_MAX_PARTS) return hipErrorInvalidValue;
   if (pro.kind != PROLOGUE_NONE) {
     // The prologue's jobs (k^2 / 8 Gram entries + k + 1 column sums) are dealt over the sweep's workgroups.  A small
     // matrix launches few of them (one for 100 x 2000): at k = 64 its 512 jobs then ran one after the other -- 0.79 ms
     // in front of a 10 us sweep (tools/shape_scan.py).  More than 4 jobs per workgroup: a launch of their own.
-    const int jobs = gram_reduce_jobs(pro.k * pro.k) + (pro.kind == PROLOGUE_POST ? pro.k + 1 : pro.ncols);
-    if (jobs > 4 * p.grid) {
+    if (pro.ncols != 0) return hipErrorInvalidValue;      // the pathway terms ride in the U epilogue launch (GraphJob)
+    const int jobs = gram_reduce_jobs(pro.k) + (pro.kind == PROLOGUE_POST ? pro.k + 1 : 0);
+    if (jobs > 4 * p.grid * (p.nw / 4)) {          // a 512-thread workgroup runs two jobs side by side
       const hipError_t e = launch_prologue_alone(pro, s);
       if (e != hipSuccess) return e;
       pro = SweepPrologue{};
@@ -662,6 +695,10 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
   // arithmetic: 1 = bf16 X x hi/lo bf16 factor; 2 = f32 X split into three bf16 pieces (every k)
   const int mode = x_dtype == 1 ? 1 : 2;
   if (x_dtype != 1 && !split) return hipErrorInvalidValue;
+  if (p.nw == SWEEP_NW_WIDE) {
+    if (mode != 1 || NT <= 2 || !p.bdb || p.mt != SWEEP_MT) return hipErrorInvalidValue;
+    return launch_sweep_nt<1, SWEEP_NW_WIDE, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
+  }
   if (p.nw != SWEEP_NW || p.mt != f32_wave_tiles(x_dtype, NT) || p.bdb != (NT <= 2)) return hipErrorInvalidValue;
   if (NT <= 2) {
     if (mode == 1) return launch_sweep_nt<1, SWEEP_NW, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
@@ -681,8 +718,9 @@ __global__ void __launch_bounds__(256) prologue_alone_kernel(const SweepPrologue
 hipError_t launch_prologue_alone(const SweepPrologue& p, hipStream_t s) {
   if (p.kind == PROLOGUE_NONE) return hipSuccess;
   if (p.nparts > GRAM_MAX_PARTS) return hipErrorInvalidValue;
-  int jobs = gram_reduce_jobs(p.k * p.k);
-  const int extra = p.kind == PROLOGUE_POST ? p.k + 1 : p.ncols;
+  if (p.ncols != 0) return hipErrorInvalidValue;
+  int jobs = gram_reduce_jobs(p.k);
+  const int extra = p.kind == PROLOGUE_POST ? p.k + 1 : 0;
   if (jobs < extra) jobs = extra;
   prologue_alone_kernel<<<jobs, 256, 0, s>>>(p);
   return hipGetLastError();

@@ -133,7 +133,7 @@ extern unsigned long long* g_epi_stamps;     // debug only (column-split epilogu
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
                        const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s,
                        bool split = false /* f32 X as three bf16 pieces, packedB in the bf16 hi/lo layout */,
-                       const SweepPrologue* prologue = nullptr /* only with 4-wave workgroups (plan.nw == 4) */);
+                       const SweepPrologue* prologue = nullptr /* runs inside the sweep when its jobs fit the grid, else as a launch of its own */);
 // Pathway terms of the V update as extra workgroups of the U epilogue launch (they depend on the OLD V and gamma / delta
 // only; the epilogue leaves a quarter of the chip's slots idle and runs longer than the terms' dependent-load chain, so
 // they cost nothing there -- as a prologue of the X^T U sweep they delayed k of its workgroups by 6-9 us).  ncols = 0: none.

@@ -18,9 +18,10 @@
 
 namespace prmf {
 
-// deterministic block-wide sum of one double per thread (256 threads)
-__device__ __forceinline__ double block_sum_256(double v, double* red /* [256] shared */) {
-  const int tid = threadIdx.x;
+// deterministic sum of one double per thread over a group of 256 threads (`tid` = index in the group, `red` = the
+// group's 256 doubles of LDS).  Every thread of the WORKGROUP has to call it: the barriers are workgroup barriers (a
+// 512-thread sweep workgroup runs two groups side by side, prologue below).
+__device__ __forceinline__ double block_sum_256(double v, double* red /* [256] shared */, int tid = (int)threadIdx.x) {
   red[tid] = v;
   __syncthreads();
 #pragma unroll
@@ -35,39 +36,54 @@ __device__ __forceinline__ double block_sum_256(double v, double* red /* [256] s
 
 // ---------------------------------------------------------------------------
 // G[e] = sum over the per-workgroup float partials, in float64.
-// Job j (256 threads) finishes entries [8 j, 8 j + 8): thread (sub = tid >> 3, el = tid & 7) loads
-// partials sub, sub + 32, ... of entry 8 j + el -- all of them in flight at once (nparts <= 1024:
-// at most 32 independent loads, one memory round trip) -- and sums them in index order; the 32
-// sub-sums are then added in index order.  The order depends on (nparts, entry) only.
+// Job j (256 threads) finishes entries [E j, E j + E): thread (sub = tid / E, el = tid % E) loads partials sub,
+// sub + 256 / E, ... of entry E j + el -- 32 of them in flight at once -- and sums them in index order; the 256 / E
+// sub-sums are then added in index order.  The order depends on (nparts, entry, E) only.
+// E = 8 at k <= 64 (512 short jobs at k = 64: one memory round trip each).  E = 32 at k > 64: with 8 entries a wave's load
+// touches 8 x 32 B of eight 64-KB-apart partials -- a quarter of every 128-B line; the 2048 jobs of k = 128 took 28 us as
+// a launch of their own (profiles/r03_c5_kernel_stats.csv), most of it over-fetch.
 // ---------------------------------------------------------------------------
-constexpr int GRAM_JOB_ENTRIES = 8;
 constexpr int GRAM_MAX_PARTS = 1024;
-__host__ __device__ inline int gram_reduce_jobs(int kk2) { return (kk2 + GRAM_JOB_ENTRIES - 1) / GRAM_JOB_ENTRIES; }
+__host__ __device__ inline int gram_job_entries(int k) { return k > 64 ? 32 : 8; }
+__host__ __device__ inline int gram_reduce_jobs(int k) { return (k * k + gram_job_entries(k) - 1) / gram_job_entries(k); }
 
-__device__ __forceinline__ void gram_reduce_job(const float* __restrict__ partial, int nparts, int kk2,
-                                                double* __restrict__ G, double* __restrict__ G_keep, int job,
-                                                double* red /* [256] shared */) {
-  const int tid = threadIdx.x, el = tid & 7, sub = tid >> 3;
-  const int e = job * GRAM_JOB_ENTRIES + el;
-  float v[GRAM_MAX_PARTS / 32];
-#pragma unroll
-  for (int j = 0; j < GRAM_MAX_PARTS / 32; ++j) {
-    const int b = sub + 32 * j;
-    v[j] = (e < kk2 && b < nparts) ? partial[(int64_t)b * kk2 + e] : 0.f;
-  }
+// `job` past the last one: the same barriers, no loads, no store (the idle half of a 512-thread workgroup)
+template <int E>
+__device__ __forceinline__ void gram_reduce_job_e(const float* __restrict__ partial, int nparts, int kk2,
+                                                  double* __restrict__ G, double* __restrict__ G_keep, int job,
+                                                  double* red /* [256] shared */, int tid) {
+  constexpr int NSUB = 256 / E;
+  const int el = tid % E, sub = tid / E;
+  const int e = job * E + el;
   double s = 0.0;
+#pragma unroll 1
+  for (int j0 = 0; j0 * NSUB < nparts; j0 += 32) {
+    float v[32];
 #pragma unroll
-  for (int j = 0; j < GRAM_MAX_PARTS / 32; ++j) s += (double)v[j];
-  red[sub * 8 + el] = s;
+    for (int j = 0; j < 32; ++j) {
+      const int b = sub + NSUB * (j0 + j);
+      v[j] = (e < kk2 && b < nparts) ? partial[(int64_t)b * kk2 + e] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) s += (double)v[j];
+  }
+  red[sub * E + el] = s;
   __syncthreads();
   if (sub == 0 && e < kk2) {
     double t = red[el];
 #pragma unroll
-    for (int j = 1; j < 32; ++j) t += red[j * 8 + el];
+    for (int j = 1; j < NSUB; ++j) t += red[j * E + el];
     G[e] = t;
     if (G_keep) G_keep[e] = t;
   }
   __syncthreads();
+}
+
+__device__ __forceinline__ void gram_reduce_job(const float* __restrict__ partial, int nparts, int k,
+                                                double* __restrict__ G, double* __restrict__ G_keep, int job,
+                                                double* red /* [256] shared */, int tid = (int)threadIdx.x) {
+  if (k > 64) gram_reduce_job_e<32>(partial, nparts, k * k, G, G_keep, job, red, tid);
+  else gram_reduce_job_e<8>(partial, nparts, k * k, G, G_keep, job, red, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -110,62 +126,65 @@ __device__ __forceinline__ void graph_terms_body(const PathwayLibDev& lib, const
 }
 
 // column c < k: sum of squares of column c of V_new;  c == k: <Q, V_new> -- from the V epilogue's
-// per-wave float64 partials [nwaves][k + 1], thread-strided then a fixed tree
+// per-wave float64 partials [nwaves][k + 1], thread-strided then a fixed tree.  c > k: barriers only.
 __device__ __forceinline__ void colcross_job(const double* __restrict__ vpartial, int nwaves, int k, int c,
-                                             double* __restrict__ colnorm2, double* __restrict__ cross, double* red) {
+                                             double* __restrict__ colnorm2, double* __restrict__ cross, double* red, int tid) {
   double s = 0.0;
-  for (int b = threadIdx.x; b < nwaves; b += 256) s += vpartial[(int64_t)b * (k + 1) + c];
-  s = block_sum_256(s, red);
-  if (threadIdx.x == 0) {
+  if (c <= k)
+    for (int b = tid; b < nwaves; b += 256) s += vpartial[(int64_t)b * (k + 1) + c];
+  s = block_sum_256(s, red, tid);
+  if (tid == 0 && c <= k) {
     if (c < k) colnorm2[c] = s;
     else *cross = s;
   }
 }
 
 // The same two sums in the column-sharded multi-rank mode, from the partials every rank's own-column V update appended
-// to its block of the all-gather: column c belongs to rank c / kc; <Q, V_new> is summed rank-major.
-__device__ __forceinline__ void colcross_gathered_job(const SweepPrologue& p, int c, double* red) {
-  if (c < p.k) {
-    const double* part = reinterpret_cast<const double*>(p.gath + (int64_t)(c / p.gath_kc) * p.gath_stride + p.gath_off);
+// to its block of the all-gather: column c belongs to rank c / kc; <Q, V_new> is summed per rank first, then the ranks
+// in order (the order of the per-iteration form).
+__device__ __forceinline__ void colcross_gathered_job(const SweepPrologue& p, int c, double* red, int tid) {
+  if (c != p.k) {
     double s = 0.0;
-    for (int b = threadIdx.x; b < p.gath_nblk; b += 256) s += part[(int64_t)b * (p.gath_kc + 1) + (c % p.gath_kc)];
-    s = block_sum_256(s, red);
-    if (threadIdx.x == 0) p.colnorm2[c] = s;
+    if (c < p.k) {
+      const double* part = reinterpret_cast<const double*>(p.gath + (int64_t)(c / p.gath_kc) * p.gath_stride + p.gath_off);
+      for (int b = tid; b < p.gath_nblk; b += 256) s += part[(int64_t)b * (p.gath_kc + 1) + (c % p.gath_kc)];
+    }
+    s = block_sum_256(s, red, tid);
+    if (tid == 0 && c < p.k) p.colnorm2[c] = s;
+    // the other group of a 512-thread workgroup may be summing <Q, V_new>: keep the barrier counts equal
+    for (int r = 1; r < p.gath_nranks; ++r) (void)block_sum_256(0.0, red, tid);
     return;
   }
-  double tot = 0.0;                    // per rank first, then the ranks in order: the order of the per-iteration form
+  double tot = 0.0;
   for (int r = 0; r < p.gath_nranks; ++r) {
     const double* part = reinterpret_cast<const double*>(p.gath + (int64_t)r * p.gath_stride + p.gath_off);
     double s = 0.0;
-    for (int b = threadIdx.x; b < p.gath_nblk; b += 256) s += part[(int64_t)b * (p.gath_kc + 1) + p.gath_kc];
-    tot += block_sum_256(s, red);
+    for (int b = tid; b < p.gath_nblk; b += 256) s += part[(int64_t)b * (p.gath_kc + 1) + p.gath_kc];
+    tot += block_sum_256(s, red, tid);
   }
-  if (threadIdx.x == 0) *p.cross = tot;
+  if (tid == 0) *p.cross = tot;
 }
 
-// The prologue a sweep launch runs before its main loop (see the header comment).  `lds` is scratch
-// of at least 2 KiB + 4 * max_support bytes for the LDS form of the pathway terms (else global gathers).
+// The side work a sweep launch runs before its main loop (see the header comment), or a launch of its own.  The workgroup
+// is one or two groups of 256 threads (the 8-wave sweep shape); a group does one job at a time, both groups in step.
+// `lds`: 2 KiB of scratch per group.
 __device__ __forceinline__ void run_sweep_prologue(const SweepPrologue& p, char* lds, int lds_bytes) {
-  double* red = reinterpret_cast<double*>(lds);
-  const int kk2 = p.k * p.k;
-  const int nj = gram_reduce_jobs(kk2);
-  for (int j = blockIdx.x; j < nj; j += gridDim.x) gram_reduce_job(p.gram_partial, p.nparts, kk2, p.G, p.G_keep, j, red);
+  (void)lds_bytes;
+  const int groups = (int)(blockDim.x >> 8), grp = (int)(threadIdx.x >> 8), tid = (int)(threadIdx.x & 255);
+  double* red = reinterpret_cast<double*>(lds) + 256 * grp;
+  const int nj = gram_reduce_jobs(p.k);
+  for (int j0 = (int)blockIdx.x * groups; j0 < nj; j0 += (int)gridDim.x * groups)
+    gram_reduce_job(p.gram_partial, p.nparts, p.k, p.G, p.G_keep, j0 + grp < nj ? j0 + grp : 0x3fffffff / 32, red, tid);
   if (p.kind == PROLOGUE_POST) {
     // workgroups from the far end of the grid first: at small k they are the ones without a Gram job
-    if (p.vpartial)
-      for (int c = (int)(gridDim.x - 1 - blockIdx.x); c <= p.k; c += gridDim.x)
-        colcross_job(p.vpartial, p.nwaves, p.k, c, p.colnorm2, p.cross, red);
-    else if (p.gath)                 // column-sharded multi-rank mode: the sums arrived with the all-gather
-      for (int c = (int)(gridDim.x - 1 - blockIdx.x); c <= p.k; c += gridDim.x) colcross_gathered_job(p, c, red);
+    if (p.vpartial || p.gath)
+      for (int c0 = (int)(gridDim.x - 1 - blockIdx.x) * groups; c0 <= p.k; c0 += (int)gridDim.x * groups) {
+        const int c = c0 + grp <= p.k ? c0 + grp : p.k + 1;
+        if (p.vpartial) colcross_job(p.vpartial, p.nwaves, p.k, c, p.colnorm2, p.cross, red, tid);
+        else colcross_gathered_job(p, c, red, tid);
+      }
     if (p.gu_keep)
-      for (int e = (int)(blockIdx.x * 256 + threadIdx.x); e < kk2; e += (int)(gridDim.x * 256)) p.gu_keep[e] = p.gu_src[e];
-  } else if (p.kind == PROLOGUE_MID) {
-    float* vs = reinterpret_cast<float*>(lds + 2048);
-    const bool fits = lds_bytes >= 2048 + (int)sizeof(float) * p.lib.max_support;
-    for (int c = (int)(gridDim.x - 1 - blockIdx.x); c < p.ncols; c += gridDim.x) {
-      if (fits) graph_terms_body<true>(p.lib, p.active, p.col0, c, p.V, p.k, p.hyper, p.gnum, p.gden, vs);
-      else graph_terms_body<false>(p.lib, p.active, p.col0, c, p.V, p.k, p.hyper, p.gnum, p.gden, vs);
-    }
+      for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < p.k * p.k; e += (int)(gridDim.x * blockDim.x)) p.gu_keep[e] = p.gu_src[e];
   }
 }
 

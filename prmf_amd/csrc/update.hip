@@ -106,10 +106,10 @@ __global__ void __launch_bounds__(256) gram_mfma_kernel(FactorView f, float* __r
 }
 
 // reduce per-workgroup Gram partials into G (float64, fixed order: prologue.h)
-__global__ void __launch_bounds__(256) gram_reduce_kernel(const float* __restrict__ partial, int nparts, int kk2,
+__global__ void __launch_bounds__(256) gram_reduce_kernel(const float* __restrict__ partial, int nparts, int k,
                                                           double* __restrict__ G) {
   __shared__ double red[256];
-  gram_reduce_job(partial, nparts, kk2, G, nullptr, blockIdx.x, red);
+  gram_reduce_job(partial, nparts, k, G, nullptr, blockIdx.x, red);
 }
 
 hipError_t launch_gram_partials(const FactorView& f, float* pf, hipStream_t s) {
@@ -130,8 +130,7 @@ hipError_t launch_gram(const FactorView& f, double* partial, double* G, hipStrea
   float* pf = reinterpret_cast<float*>(partial);
   hipError_t e = launch_gram_partials(f, pf, s);
   if (e != hipSuccess) return e;
-  const int kk2 = f.cols * f.cols;
-  gram_reduce_kernel<<<gram_reduce_jobs(kk2), 256, 0, s>>>(pf, nparts, kk2, G);
+  gram_reduce_kernel<<<gram_reduce_jobs(f.cols), 256, 0, s>>>(pf, nparts, f.cols, G);
   return hipGetLastError();
 }
 
@@ -1184,8 +1183,7 @@ hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_
 hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G, hipStream_t s);
 
 hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G, hipStream_t s) {
-  const int kk2 = k * k;
-  gram_reduce_kernel<<<gram_reduce_jobs(kk2), 256, 0, s>>>(partial, nparts, kk2, G);
+  gram_reduce_kernel<<<gram_reduce_jobs(k), 256, 0, s>>>(partial, nparts, k, G);
   return hipGetLastError();
 }
 
@@ -1315,7 +1313,7 @@ mid_kernel(const float* __restrict__ gram_partial, int nparts, int k, double* __
            float* __restrict__ gnum, float* __restrict__ gden) {
   extern __shared__ __attribute__((aligned(16))) float vs[];
   __shared__ double red[256];
-  if ((int)blockIdx.x < nred) gram_reduce_job(gram_partial, nparts, k * k, Gu, nullptr, blockIdx.x, red);
+  if ((int)blockIdx.x < nred) gram_reduce_job(gram_partial, nparts, k, Gu, nullptr, blockIdx.x, red);
   else graph_terms_body<USE_LDS>(lib, active, col0, blockIdx.x - nred, V, k, hyper, gnum, gden, vs);
 }
 
@@ -1323,7 +1321,7 @@ mid_kernel(const float* __restrict__ gram_partial, int nparts, int k, double* __
 hipError_t launch_mid(const float* gram_partial, int nparts, int k, double* Gu, const PathwayLibDev& lib,
                       const int32_t* active_dev, int col0, int ncols, const float* V, const double* hyper, float* gnum,
                       float* gden, hipStream_t s) {
-  const int nred = gram_reduce_jobs(k * k);
+  const int nred = gram_reduce_jobs(k);
   const size_t lds = (size_t)lib.max_support * sizeof(float);
   if (lds <= 64 * 1024) mid_kernel<true><<<nred + ncols, 256, lds, s>>>(gram_partial, nparts, k, Gu, nred, lib, active_dev, col0, V, hyper, gnum, gden);
   else mid_kernel<false><<<nred + ncols, 256, 0, s>>>(gram_partial, nparts, k, Gu, nred, lib, active_dev, col0, V, hyper, gnum, gden);
@@ -1533,14 +1531,14 @@ post_kernel(const float* __restrict__ gram_partial, int nparts, int k, double* _
             const int32_t* __restrict__ active, const float* __restrict__ V, const double* __restrict__ partial, int nblocks,
             double* __restrict__ colres, double* __restrict__ scratch) {
   __shared__ double red[256];
-  if ((int)blockIdx.x < nred) gram_reduce_job(gram_partial, nparts, k * k, Gv, nullptr, blockIdx.x, red);
+  if ((int)blockIdx.x < nred) gram_reduce_job(gram_partial, nparts, k, Gv, nullptr, blockIdx.x, red);
   else objective_col_body(lib, active, 0, k, blockIdx.x - nred, V, partial, nblocks, colres, scratch, red);
 }
 
 hipError_t launch_post(const float* gram_partial, int nparts, int k, double* Gv, const PathwayLibDev& lib,
                        const int32_t* active_dev, const float* V, const double* partial, int nblocks, double* colres,
                        double* scratch, hipStream_t s) {
-  const int nred = gram_reduce_jobs(k * k);
+  const int nred = gram_reduce_jobs(k);
   post_kernel<<<nred + k, 256, 0, s>>>(gram_partial, nparts, k, Gv, nred, lib, active_dev, V, partial, nblocks, colres, scratch);
   return hipGetLastError();
 }
