@@ -42,27 +42,33 @@ def main():
     per_frag = 2 if xd == "bf16" else 5                      # hi/lo factor pieces | three-piece split of f32 X
     pad = lambda a, b: (a + b - 1) // b * b
     n_mfma = (pad(m, 256) / 32) * (pad(n, 128) / 16) * (KP / 32) * per_frag
-    rows = [e for did, e in per.items() if did in dur and "GRBM_GUI_ACTIVE" in e]
-    rows = rows[len(rows) // 4:]                              # drop the warm-up launches
-    if not rows:
-        sys.exit("no sweep dispatches with counters found in %s" % d)
     for did, e in per.items():
         if did in dur:
             e["duration_s"] = dur[did]
-    avg = lambda key: sum(e[key] for e in rows) / len(rows)
-    gui, mf, t = avg("GRBM_GUI_ACTIVE"), avg("SQ_VALU_MFMA_BUSY_CYCLES"), avg("duration_s")
-    res = {"workload": wl, "kernel": rows[0]["kernel"], "sweep_launches_averaged": len(rows),
-           "avg_duration_ms": t * 1e3, "GRBM_GUI_ACTIVE_per_launch": gui, "SQ_VALU_MFMA_BUSY_CYCLES_per_launch": mf,
-           "SQ_BUSY_CYCLES_per_launch": avg("SQ_BUSY_CYCLES") if "SQ_BUSY_CYCLES" in rows[0] else None,
-           "effective_clock_ghz": gui / 8.0 / t / 1e9,
-           "mfma_pipe_utilisation": mf / (1024.0 * gui / 8.0),
-           "algorithmic_mfma_instructions_per_launch": n_mfma, "algorithmic_mfma_cycles_per_launch": 32.0 * n_mfma,
-           "counter_over_algorithmic": mf / (32.0 * n_mfma),
-           "note": "under rocprofv3 --pmc the launches run slower than un-profiled ones (the guide's DVFS note (2)); utilisation = "
-                   "busy cycles / (1024 SIMDs x shader cycles of the launch)"}
-    json.dump(res, open(out, "w"), indent=1)
-    print("%-8s %s: %.3f ms/launch, clock %.2f GHz, MFMA pipe busy %.1f%% (counter / algorithmic = %.3f)" % (
-        wl, res["kernel"], t * 1e3, res["effective_clock_ghz"], 100 * res["mfma_pipe_utilisation"], res["counter_over_algorithmic"]))
+    out_rows = []
+    for kname in sorted({e["kernel"] for e in per.values()}):
+        rows = [e for e in per.values() if e["kernel"] == kname and "duration_s" in e and "GRBM_GUI_ACTIVE" in e]
+        rows = rows[len(rows) // 4:]                          # drop the warm-up launches
+        if not rows:
+            continue
+        avg = lambda key: sum(e[key] for e in rows) / len(rows)
+        gui, mf, t = avg("GRBM_GUI_ACTIVE"), avg("SQ_VALU_MFMA_BUSY_CYCLES"), avg("duration_s")
+        # a workload whose two sweeps run different kernels (C5: 4-wave X V, 8-wave X^T U) has half the launches each
+        res = {"workload": wl, "kernel": kname, "sweep_launches_averaged": len(rows),
+               "avg_duration_ms": t * 1e3, "GRBM_GUI_ACTIVE_per_launch": gui, "SQ_VALU_MFMA_BUSY_CYCLES_per_launch": mf,
+               "SQ_BUSY_CYCLES_per_launch": avg("SQ_BUSY_CYCLES") if "SQ_BUSY_CYCLES" in rows[0] else None,
+               "effective_clock_ghz": gui / 8.0 / t / 1e9,
+               "mfma_pipe_utilisation": mf / (1024.0 * gui / 8.0),
+               "algorithmic_mfma_instructions_per_launch": n_mfma, "algorithmic_mfma_cycles_per_launch": 32.0 * n_mfma,
+               "counter_over_algorithmic": mf / (32.0 * n_mfma),
+               "note": "under rocprofv3 --pmc the launches run slower than un-profiled ones (the guide's DVFS note (2)); utilisation = "
+                       "busy cycles / (1024 SIMDs x shader cycles of the launch)"}
+        out_rows.append(res)
+        print("%-8s %s: %.3f ms/launch, clock %.2f GHz, MFMA pipe busy %.1f%% (counter / algorithmic = %.3f)" % (
+            wl, kname, t * 1e3, res["effective_clock_ghz"], 100 * res["mfma_pipe_utilisation"], res["counter_over_algorithmic"]))
+    if not out_rows:
+        sys.exit("no sweep dispatches with counters found in %s" % d)
+    json.dump(out_rows[0] if len(out_rows) == 1 else {"workload": wl, "kernels": out_rows}, open(out, "w"), indent=1)
 
 
 if __name__ == "__main__":
