@@ -33,6 +33,7 @@ struct prmf_ctx {
   int x_dtype = 0;
   int pack_dtype = 0;                 // fragment layout of the packed factors (= x_dtype unless split_f32)
   bool split_f32 = false;             // f32 X multiplied as three bf16 pieces on the bf16 MFMA (see prmf_create)
+  bool w16 = false;                   // packed factors in the fragment order of the 16x16x32 MFMA (bf16 X, k > 64: gemm.hip)
   int nranks = 1, rank = 0;
   // Layout ranks: how many column blocks the V update is split into.  Column-sharded mode (default for nranks > 1):
   // lr = nranks (each rank updates kc = ceil(k / nranks) columns; reduce-scatter of Q, all-gather of V).  Replicated mode
@@ -237,7 +238,7 @@ int set_device(prmf_ctx* c) {
 // pack V and build V^T V from the bound V (first step, or after the caller changed V)
 int prepare(prmf_ctx* c, hipStream_t s) {
   FactorView fv{c->V, (int)c->n, c->k, c->k, 0};
-  HIP_TRY(c, launch_pack_factor(fv, c->pack_dtype, c->NT, c->Kpad_x, c->Vp, s));
+  HIP_TRY(c, launch_pack_factor(fv, c->pack_dtype, c->NT, c->Kpad_x, c->Vp, s, c->w16));
   HIP_TRY(c, launch_gram(fv, c->gram_partial, c->Gv, s));
   c->prepared = true;
   c->gv_pending = false;
@@ -458,6 +459,7 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   // the registers): 0.80 vs 1.17 ms per sweep at 25000 x 25000, k = 128.
   c->split_f32 = x_dtype == PRMF_X_F32;
   c->pack_dtype = c->split_f32 ? PRMF_X_BF16 : x_dtype;
+  c->w16 = x_dtype == PRMF_X_BF16 && c->NT > 2;
   // slabs are written as whole 32-row tiles of whole panels (fragment order, no row masking)
   c->slab_stride_p = (int64_t)c->plan_xv.panels * c->plan_xv.panel_rows * c->KP;
   c->slab_stride_q = (int64_t)c->plan_xtu.panels * c->plan_xtu.panel_rows * c->KP;
@@ -807,7 +809,7 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
   bool gram_done = false;
   const GraphJob gj = graph_job(c);
   HIP_TRY(c, launch_u_epilogue(c->U, c->m, c->k, c->slabs, c->nseg_xv, c->plan_xv.panel_rows, c->slab_stride_p, c->KP,
-                               c->Gv, c->pack_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, c->wpt_u, s, &gj));
+                               c->Gv, c->pack_dtype, c->Up, c->Kpad_xt, (float*)c->gram_partial, &gram_done, c->wpt_u, s, &gj, c->w16));
   c->graph_done = true;
   c->nparts_u = epilogue_blocks(c->Kpad_xt, c->wpt_u);
   if (!gram_done) {
@@ -861,7 +863,7 @@ int prmf_phase_v(prmf_ctx* c, void* stream) {
     HIP_TRY(c, launch_v_epilogue(c->V, c->n, c->k, c->slabs, c->nseg_xtu, c->plan_xtu.panel_rows, c->slab_stride_q, c->KP,
                                  c->gram_buf, c->pos, c->gnum, c->gden, c->lib.max_support, c->pack_dtype, c->Vp, c->Kpad_x,
                                  c->vpartial, (float*)c->gram_partial, &c->gram_v_done, c->replicated ? c->q_recv : nullptr,
-                                 c->lazy ? c->vsup_ring + (size_t)c->cursor * c->k * c->lib.max_support : nullptr, c->wpt_v, s));
+                                 c->lazy ? c->vsup_ring + (size_t)c->cursor * c->k * c->lib.max_support : nullptr, c->wpt_v, s, c->w16));
     c->nparts_v = epilogue_blocks(c->Kpad_x, c->wpt_v);
     if (!c->gram_v_done) {
       FactorView fv{c->V, (int)c->n, c->k, c->k, 0};
@@ -898,7 +900,8 @@ int prmf_phase_post(prmf_ctx* c, void* stream) {
     bool gram_done = false;
     HIP_TRY(c, launch_v_post(c->V, c->n, c->k, c->v_recv, c->v_send_floats, c->kc, c->KP, c->pack_dtype, c->Vp, c->Kpad_x,
                              (float*)c->gram_partial, &gram_done, c->lazy ? c->pos_all : nullptr,
-                             c->lazy ? c->vsup_ring + (size_t)c->cursor * c->k * c->lib.max_support : nullptr, c->lib.max_support, s));
+                             c->lazy ? c->vsup_ring + (size_t)c->cursor * c->k * c->lib.max_support : nullptr, c->lib.max_support, s,
+                             c->w16));
     c->nparts_v = epilogue_blocks(c->Kpad_x);
     if (!gram_done) {
       HIP_TRY(c, launch_gram_partials(fv, (float*)c->gram_partial, s));

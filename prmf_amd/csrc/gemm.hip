@@ -14,6 +14,10 @@
 //         block (kb, t, hl) of 1 KiB, kb = k/16, t = 32-column tile, hl = 0 hi / 1 lo;
 //         lane (c = lane&31, h = lane>>5), element e:  B[16 kb + 8 h + e][32 t + c],
 //         split as hi = bf16(v), lo = bf16(v - hi)  (16 mantissa bits)
+//       bf16 X at k > 64 ("W16", round 3) multiplies with v_mfma_f32_16x16x32_bf16 and packs accordingly:
+//         block (g, t16, hl) of 1 KiB, g = k/32, t16 = 16-column tile; lane (c16 = lane&15, kg = lane>>4), element e:
+//         B[32 g + 8 kg + e][16 t16 + c16]
+//       (same bytes per chunk, so the staging is the same).
 //       The packed chunk (all blocks of the chunk's 64 resp. 32 reduction rows) is staged
 //       once per workgroup into LDS and shared by its 4 waves.
 //   C   per-segment partial slabs in MFMA fragment order, [slab][32-row tile][t][q4][lane][4 floats] (1 KiB per
@@ -63,7 +67,7 @@ __device__ __forceinline__ float factor_at(const FactorView& f, int64_t row, int
 // ---------------------------------------------------------------------------
 // packing
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) pack_bf16_kernel(FactorView f, int NT, int64_t nkb, uint4* __restrict__ out) {
+__global__ void __launch_bounds__(256) pack_bf16_kernel(FactorView f, int NT, int64_t nkb, uint4* __restrict__ out, int w16) {
   int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int lane = (int)(gid & 63);
   int64_t rest = gid >> 6;
@@ -73,6 +77,11 @@ __global__ void __launch_bounds__(256) pack_bf16_kernel(FactorView f, int NT, in
   int c = lane & 31, h = lane >> 5;
   int col = 32 * t + c;
   int64_t row0 = kb * 16 + 8 * h;
+  if (w16) {        // the same thread count, dealt as (g = kb / 2, t16 = 2 t + (kb & 1), lane (c16, kg))
+    const int t16 = 2 * t + (int)(kb & 1);
+    col = 16 * t16 + (lane & 15);
+    row0 = (kb >> 1) * 32 + 8 * (lane >> 4);
+  }
   unsigned hi[4], lo[4];
 #pragma unroll
   for (int e = 0; e < 8; e += 2) {
@@ -83,15 +92,16 @@ __global__ void __launch_bounds__(256) pack_bf16_kernel(FactorView f, int NT, in
     lo[e >> 1] = (unsigned)l0 | ((unsigned)l1 << 16);
   }
   int64_t blk = (kb * NT + t) * 2;
+  if (w16) blk = ((kb >> 1) * (2 * NT) + 2 * t + (kb & 1)) * 2;
   out[blk * 64 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
   out[(blk + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
-hipError_t launch_pack_factor(const FactorView& f, int x_dtype, int NT, int64_t Kpad, void* packed, hipStream_t s) {
+hipError_t launch_pack_factor(const FactorView& f, int x_dtype, int NT, int64_t Kpad, void* packed, hipStream_t s, bool w16) {
   if (x_dtype != 1) return hipErrorInvalidValue;   // every sweep multiplies with the hi/lo bf16 fragment layout
-  int64_t nkb = Kpad / 16;
+  int64_t nkb = Kpad / 16;                         // Kpad is a multiple of 128: whole 32-row groups
   int64_t threads = nkb * NT * 64;
-  pack_bf16_kernel<<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(f, NT, nkb, (uint4*)packed);
+  pack_bf16_kernel<<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(f, NT, nkb, (uint4*)packed, w16 ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -189,33 +199,48 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&ac
     return;
   }
   static_assert(MODE == 1 || MODE == 2, "MODE 1: bf16 X, MODE 2: f32 X");
-  if constexpr (NT > 2) {
-    // k > 64: the fragment reads of step j + 1 (a B hi/lo pair; the A fragments when a new 16-element slice starts) are
-    // issued before the MFMAs of step j (the scheduling barriers keep the compiler from sinking them back): 2% at
-    // k = 128; at k = 64 it changes nothing (profiles/r02_ab_priority_and_pipelined_reads.txt)
-    u32x4 av[2][MT], bb[2][2];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) av[0][mt] = sa[mt * 256 + r * 8 + ((0 + h) ^ swz)];
+  if constexpr (MODE == 1 && NT > 2) {
+    // k > 64 ("W16"): v_mfma_f32_16x16x32_bf16 -- under load the chip holds a higher clock with this shape than with
+    // 32x32x16 at the same cycles per flop (the guide's DVFS note; same-session ablation with realistic operands:
+    // X V of 25000 x 25000, k = 128 0.307 -> 0.290 ms, of 200000 x 25000 2.37 -> 2.23 ms; nothing at k = 64:
+    // profiles/r03_ab_mfma_16x16x32.txt).  A wave's 64 rows are four 16-row groups (A operand: lane (r16, kg) holds
+    // row r16, 8 consecutive reduction elements 8 kg ..), the chunk is two 32-element steps, a column tile is 16 wide.
+    // The accumulators keep their [MT][NT] x 16 storage: 16-row group rg16 = 2 mt + a and 16-column tile t16 = 2 t + b
+    // own floats 4 (2 a + b) .. + 4 of acc[mt][t]  (C layout: lane (c16, rg) holds rows 4 rg + i, i = 0..3).
+    // The fragment reads of step j + 1 are issued before the MFMAs of step j (scheduling barriers keep them there).
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    static_assert(MT == 2, "four 16-row groups per wave");
+    const int r16 = lane & 15, kg = lane >> 4;
+    u32x4 av[4], bb[2][2];     // (A fragments double-buffered too: 16 more registers, 45 spilled instead of 26 at k = 128)
+    auto a_frag = [&](int step, int rg16) -> u32x4 {
+      const int rr = 16 * (rg16 & 1) + r16;
+      return sa[(rg16 >> 1) * 256 + rr * 8 + ((4 * step + kg) ^ ((rr >> 1) & 7))];
+    };
     bb[0][0] = sb[0 * 64 + lane];
     bb[0][1] = sb[1 * 64 + lane];
+    constexpr int T16 = 2 * NT;
 #pragma unroll
-    for (int j = 0; j < 4 * NT; ++j) {
-      const int s4 = j / NT, t = j % NT, jn = j + 1;
-      if (jn < 4 * NT) {
-        if (jn % NT == 0) {
+    for (int j = 0; j < 2 * T16; ++j) {
+      const int step = j / T16, t16 = j % T16, jn = j + 1;
+      if (t16 == 0) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) av[(jn / NT) & 1][mt] = sa[mt * 256 + r * 8 + ((2 * (jn / NT) + h) ^ swz)];
-        }
+        for (int g = 0; g < 4; ++g) av[g] = a_frag(step, g);
+      }
+      if (jn < 2 * T16) {
         bb[jn & 1][0] = sb[(jn * 2 + 0) * 64 + lane];
         bb[jn & 1][1] = sb[(jn * 2 + 1) * 64 + lane];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            __builtin_bit_cast(bf16x8, av[s4 & 1][mt]), __builtin_bit_cast(bf16x8, bb[j & 1][0]), acc[mt][t], 0, 0, 0);
-        acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            __builtin_bit_cast(bf16x8, av[s4 & 1][mt]), __builtin_bit_cast(bf16x8, bb[j & 1][1]), acc[mt][t], 0, 0, 0);
+      for (int g = 0; g < 4; ++g) {
+        const int mt = g >> 1, t = t16 >> 1, o = 4 * (2 * (g & 1) + (t16 & 1));
+        f32x4_ c4 = {acc[mt][t][o], acc[mt][t][o + 1], acc[mt][t][o + 2], acc[mt][t][o + 3]};
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[g]), __builtin_bit_cast(bf16x8, bb[j & 1][0]), c4, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[g]), __builtin_bit_cast(bf16x8, bb[j & 1][1]), c4, 0, 0, 0);
+        acc[mt][t][o] = c4[0];
+        acc[mt][t][o + 1] = c4[1];
+        acc[mt][t][o + 2] = c4[2];
+        acc[mt][t][o + 3] = c4[3];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -339,7 +364,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   // scratch is the A tile area (>= 16 KiB with 4 waves x 64 rows), untouched until the main loop's own prologue
   if constexpr (NW == 4 || NW == 8) {
     if (pro.kind != PROLOGUE_NONE) {
-      run_sweep_prologue(pro, reinterpret_cast<char*>(&sA[0][0]), LDS_A * 16);
+      run_sweep_prologue<(NT > 2) ? 1 : 0>(pro, reinterpret_cast<char*>(&sA[0][0]), LDS_A * 16);
       __syncthreads();
     }
   }
@@ -495,6 +520,28 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   // tools/stream_ladder2.hip).  Element (row, col) of a slab:
   //   tile = row/32, rr = row%32, lane = col%32 + 32*((rr>>2)&1), q4 = rr>>3, j = rr&3, t = col/32
   f32x4* out = reinterpret_cast<f32x4*>(slabs + (int64_t)seg * slab_stride);
+  if constexpr (MODE == 1 && NT > 2) {
+    // W16 accumulators (see sweep_compute) into the SAME slab order: floats 4 (2 a + b) .. + 4 of acc[mt][t] are rows
+    // 16 a + 4 rg + i, column 16 b + c16 of the 32 x 32 tile (mt, t) -> q4 = 2 a + (rg >> 1), lane' = 16 b + c16 + 32 (rg & 1):
+    // every store instruction writes four 256-B runs
+    const int c16 = lane & 15, rg = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int64_t tile = row0 / 32 + mt;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+          for (int b2 = 0; b2 < 2; ++b2) {
+            const int o = 4 * (2 * a2 + b2);
+            const f32x4 v = {acc[mt][t][o], acc[mt][t][o + 1], acc[mt][t][o + 2], acc[mt][t][o + 3]};
+            f32x4* dst = out + ((tile * NT + t) * 4 + (2 * a2 + (rg >> 1))) * 64 + (16 * b2 + c16 + 32 * (rg & 1));
+            if (slab_nt) __builtin_nontemporal_store(v, dst);     // (uniform)
+            else *dst = v;
+          }
+    }
+  } else {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int64_t tile = row0 / 32 + mt;
@@ -511,6 +558,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
         if (slab_nt) __builtin_nontemporal_store(v, dst);     // (uniform)
         else *dst = v;
       }
+  }
   }
   }   // segments
 #if PRMF_PHASE_PROF

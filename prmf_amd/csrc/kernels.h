@@ -103,7 +103,8 @@ struct SweepPrologue {
 // ---------------------------------------------------------------------------
 // gemm.hip
 // ---------------------------------------------------------------------------
-hipError_t launch_pack_factor(const FactorView& f, int x_dtype, int NT, int64_t Kpad, void* packed, hipStream_t s);
+// w16: the fragment order of the 16x16x32 MFMA (bf16 X at k > 64), see gemm.hip; the epilogues that pack take the same flag
+hipError_t launch_pack_factor(const FactorView& f, int x_dtype, int NT, int64_t Kpad, void* packed, hipStream_t s, bool w16 = false);
 // which slabs hold a segment of a row panel: one bit per slab, at most 64 slabs per panel (wide, short matrices -- the
 // reference's typical samples << genes shape -- have 2-3 panels and would otherwise run the X V sweep on 32 workgroups per panel)
 typedef uint64_t segmask_t;
@@ -168,7 +169,8 @@ int epilogue_wpt(int64_t rows, int max_seg, int NT);   // waves sharing a tile's
 int epilogue_blocks(int64_t rows, int wpt = 1);
 hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const segmask_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
-                             float* gram_partial, bool* gram_done, int wpt, hipStream_t s, const GraphJob* graph = nullptr);
+                             float* gram_partial, bool* gram_done, int wpt, hipStream_t s, const GraphJob* graph = nullptr,
+                             bool w16 = false);
 hipError_t launch_gram_reduce(const float* partial, int nparts, int k, double* G, hipStream_t s);
 // fused single-rank V epilogue (k % 4 == 0): in place, + packing + per-wave partials [waves][k+1]
 int v_epilogue_waves(int64_t n, int wpt = 1);
@@ -178,7 +180,7 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
                              double* partial, float* gram_partial, bool* gram_done,
                              const float* qdense /* null: sum the slabs; else Q [n][k], already summed */,
                              float* vsup /* null, or [k][max_support]: V_new on the active supports (deferred objective) */,
-                             int wpt, hipStream_t s);
+                             int wpt, hipStream_t s, bool w16 = false);
 // Deferred objective (single rank, tradeoff off): all iterations of a batch in two launches at prmf_end.
 //   colnorm2 [iters][k], vsup [iters][k][max_support] -> colres [iters][k][2] (manifold, ignore of the normalised column)
 hipError_t launch_objective_all(const PathwayLibDev& lib, const int32_t* active_dev, int k, int iters, const double* colnorm2,
@@ -232,7 +234,7 @@ hipError_t launch_mid(const float* gram_partial, int nparts, int k, double* Gu, 
 //   pos_all / vsup (nullable): V_new on the active supports of ALL k columns for the deferred objective (pos_all: [n][k])
 hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_t blk_stride, int kc, int KP, int x_dtype,
                          void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, const int32_t* pos_all, float* vsup,
-                         int max_support, hipStream_t s);
+                         int max_support, hipStream_t s, bool w16 = false);
 hipError_t launch_post(const float* gram_partial, int nparts, int k, double* Gv, const PathwayLibDev& lib,
                        const int32_t* active_dev, const float* V, const double* partial, int nblocks, double* colres,
                        double* scratch, hipStream_t s);

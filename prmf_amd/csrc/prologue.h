@@ -79,10 +79,16 @@ __device__ __forceinline__ void gram_reduce_job_e(const float* __restrict__ part
   __syncthreads();
 }
 
+// WIDE_K: -1 = decide at run time (the stand-alone kernels); 0 / 1 = the caller knows k <= 64 / k > 64 at compile time
+// (the sweep kernels: only one of the two forms is then compiled into them -- both together cost every sweep kernel its
+// register headroom: 256 VGPRs and 12 spilled where the k = 64 sweep had 250 and none)
+template <int WIDE_K = -1>
 __device__ __forceinline__ void gram_reduce_job(const float* __restrict__ partial, int nparts, int k,
                                                 double* __restrict__ G, double* __restrict__ G_keep, int job,
                                                 double* red /* [256] shared */, int tid = (int)threadIdx.x) {
-  if (k > 64) gram_reduce_job_e<32>(partial, nparts, k * k, G, G_keep, job, red, tid);
+  if constexpr (WIDE_K == 1) gram_reduce_job_e<32>(partial, nparts, k * k, G, G_keep, job, red, tid);
+  else if constexpr (WIDE_K == 0) gram_reduce_job_e<8>(partial, nparts, k * k, G, G_keep, job, red, tid);
+  else if (k > 64) gram_reduce_job_e<32>(partial, nparts, k * k, G, G_keep, job, red, tid);
   else gram_reduce_job_e<8>(partial, nparts, k * k, G, G_keep, job, red, tid);
 }
 
@@ -168,13 +174,14 @@ __device__ __forceinline__ void colcross_gathered_job(const SweepPrologue& p, in
 // The side work a sweep launch runs before its main loop (see the header comment), or a launch of its own.  The workgroup
 // is one or two groups of 256 threads (the 8-wave sweep shape); a group does one job at a time, both groups in step.
 // `lds`: 2 KiB of scratch per group.
+template <int WIDE_K = -1>
 __device__ __forceinline__ void run_sweep_prologue(const SweepPrologue& p, char* lds, int lds_bytes) {
   (void)lds_bytes;
   const int groups = (int)(blockDim.x >> 8), grp = (int)(threadIdx.x >> 8), tid = (int)(threadIdx.x & 255);
   double* red = reinterpret_cast<double*>(lds) + 256 * grp;
   const int nj = gram_reduce_jobs(p.k);
   for (int j0 = (int)blockIdx.x * groups; j0 < nj; j0 += (int)gridDim.x * groups)
-    gram_reduce_job(p.gram_partial, p.nparts, p.k, p.G, p.G_keep, j0 + grp < nj ? j0 + grp : 0x3fffffff / 32, red, tid);
+    gram_reduce_job<WIDE_K>(p.gram_partial, p.nparts, p.k, p.G, p.G_keep, j0 + grp < nj ? j0 + grp : 0x3fffffff / 32, red, tid);
   if (p.kind == PROLOGUE_POST) {
     // workgroups from the far end of the grid first: at small k they are the ones without a Gram job
     if (p.vpartial || p.gath)

@@ -181,6 +181,46 @@ __device__ __forceinline__ void pack_tile_from_cd(const float (&un)[NT][16], int
   }
 }
 
+// The same for the fragment order of the 16x16x32 MFMA (bf16 X at k > 64, gemm.hip "W16"): block (g = row0 / 32, t16, hl),
+// lane (c16, kg) holds rows 32 g + 8 kg .. + 8 of column 16 t16 + c16.  After the permlane32 swap lane (c, h) of the
+// C/D layout holds the 8-row groups kg = 2 kb + h (kb = 0, 1) of its column c of the 32-column tile t; lane (c16, kg) of
+// block t16 = 2 t + b takes them from lane (16 b + c16, h = kg & 1), register set kb = kg >> 1: 32 ds_bpermute per tile.
+__device__ __forceinline__ void pack_cd_w16(const float (&v)[16], int64_t row0, int t, int NT, int lane, void* packed) {
+  uint4* out = reinterpret_cast<uint4*>(packed);
+  unsigned P[2][2][4];                 // [kb][hl][word]
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    float e[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 * kb + i]), __float_as_uint(v[8 * kb + 4 + i]), false, false);
+      e[i] = __uint_as_float(sw[0]);
+      e[4 + i] = __uint_as_float(sw[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      P[kb][0][j] = pack_bf16_pair(e[2 * j], e[2 * j + 1]);
+      P[kb][1][j] = pack_bf16_pair(e[2 * j] - bf16_trunc_back(e[2 * j]), e[2 * j + 1] - bf16_trunc_back(e[2 * j + 1]));
+    }
+  }
+  const int c16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int src = 16 * b + c16 + 32 * (kg & 1);
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl) {
+      unsigned w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned v0 = (unsigned)__shfl((int)P[0][hl][j], src, 64), v1 = (unsigned)__shfl((int)P[1][hl][j], src, 64);
+        w[j] = (kg >> 1) ? v1 : v0;
+      }
+      const int64_t blk = ((row0 / 32) * (2 * NT) + 2 * t + b) * 2 + hl;
+      out[blk * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
 // A-layout load of one 32-row tile of F (lane (r,h): F[row0+r][(KP/2)h .. +KP/2), zero outside).
 // VEC4: k % 4 == 0, the rows of F are 16-B aligned -> one float4 per 4 columns; else (any k -- the CLI's default is 6)
 // element loads with clamped addresses.  A template parameter, not a branch: both forms in one kernel cost the
@@ -587,7 +627,7 @@ struct EpiArgs {
   unsigned long long* stamps;   // debug (tools/epi_phases.py): 8 wall-clock stamps per workgroup, first round of wave 0
 };
 
-template <int NT, bool IS_V, bool VEC4, bool DENSE>
+template <int NT, bool IS_V, bool VEC4, bool DENSE, bool W16>
 __global__ void __launch_bounds__(256, 2)
 epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
   constexpr int KP = 32 * NT, HALF = KP / 2, NP = NT * (NT + 1) / 2;
@@ -741,7 +781,9 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
     }
     if (a.stamps) { float t_ = 0.f; for (int i = 0; i < 16; ++i) t_ += vn[i]; if (t_ == 1.2345e-33f) vn[2] = t_; EPI_STAMP(5); }
     // (4) this column tile's fragments of the packed factor (tiles past the end are packed as zeros)
-    if (in_range) {
+    if constexpr (W16) {
+      if (in_range) pack_cd_w16(vn, row0, t, NT, lane, a.packed);
+    } else if (in_range) {
       {
         uint4* out = reinterpret_cast<uint4*>(a.packed);
 #pragma unroll
@@ -835,18 +877,21 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
 
 
 template <bool IS_V>
-static hipError_t launch_epilogue_cs(const EpiArgs& a_in, const GraphJob& gj, int NT, bool bf16, bool dense, int grid, hipStream_t s) {
+static hipError_t launch_epilogue_cs(const EpiArgs& a_in, const GraphJob& gj, int NT, bool bf16, bool dense, int grid, hipStream_t s, bool w16) {
   if (!bf16) return hipErrorInvalidValue;      // the factors are always packed as hi/lo bf16 fragments
   const bool vec4 = (a_in.k & 3) == 0;         // rows of F 16-B aligned
   EpiArgs a = a_in;
   a.stamps = g_epi_stamps;
+#define PRMF_CS2(NTV, V4, DN)                                                                              \
+  do {                                                                                                   \
+    if (w16) epilogue_cs_kernel<NTV, IS_V, V4, DN, true><<<grid, 256, 0, s>>>(a, gj);                       \
+    else epilogue_cs_kernel<NTV, IS_V, V4, DN, false><<<grid, 256, 0, s>>>(a, gj);                          \
+  } while (0)
 #define PRMF_CS(NTV)                                                                                     \
   if (vec4) {                                                                                            \
-    if (dense) epilogue_cs_kernel<NTV, IS_V, true, IS_V><<<grid, 256, 0, s>>>(a, gj);                       \
-    else epilogue_cs_kernel<NTV, IS_V, true, false><<<grid, 256, 0, s>>>(a, gj);                            \
+    if (dense) PRMF_CS2(NTV, true, IS_V); else PRMF_CS2(NTV, true, false);                                 \
   } else {                                                                                               \
-    if (dense) epilogue_cs_kernel<NTV, IS_V, false, IS_V><<<grid, 256, 0, s>>>(a, gj);                      \
-    else epilogue_cs_kernel<NTV, IS_V, false, false><<<grid, 256, 0, s>>>(a, gj);                           \
+    if (dense) PRMF_CS2(NTV, false, IS_V); else PRMF_CS2(NTV, false, false);                               \
   }
   switch (NT) {
 #if PRMF_EPI_CS_MIN_NT <= 1
@@ -860,13 +905,15 @@ static hipError_t launch_epilogue_cs(const EpiArgs& a_in, const GraphJob& gj, in
     default: return hipErrorInvalidValue;
   }
 #undef PRMF_CS
+#undef PRMF_CS2
   return hipGetLastError();
 }
 
 hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, const segmask_t* segmask, int panel_rows,
                              int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
-                             float* gram_partial, bool* gram_done, int wpt, hipStream_t s, const GraphJob* graph) {
+                             float* gram_partial, bool* gram_done, int wpt, hipStream_t s, const GraphJob* graph, bool w16) {
   const int NT = KP / 32;
+  if (w16 && NT < PRMF_EPI_CS_MIN_NT) return hipErrorInvalidValue;      // the 16x16x32 fragment order exists for k > 64 only
   const int64_t ntiles = Kpad / 32;          // every tile of the packed buffer is (re)written, zero beyond m
   const GraphJob gj = graph ? *graph : GraphJob{};
   if (x_dtype != 1) return hipErrorInvalidValue;   // fragment layout of the packed factor: hi/lo bf16 only
@@ -876,7 +923,7 @@ hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, con
     a.G = Gv; a.packed = packed; a.ntiles_pack = ntiles; a.gram_partial = gram_partial;
     a.nblocks_main = epilogue_blocks(Kpad, NT);
     *gram_done = true;
-    return launch_epilogue_cs<false>(a, gj, NT, x_dtype == 1, false, a.nblocks_main + (gj.ncols > 0 ? gj.ncols * gj.nsplit : 0), s);
+    return launch_epilogue_cs<false>(a, gj, NT, x_dtype == 1, false, a.nblocks_main + (gj.ncols > 0 ? gj.ncols * gj.nsplit : 0), s, w16);
   }
   if (NT > 2) wpt = 1;
   const int nmain = epilogue_blocks(Kpad, wpt);
@@ -1043,8 +1090,9 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
                              int64_t slab_stride, int KP, const double* Gu, const int32_t* pos, const float* gnum,
                              const float* gden, int max_support, int x_dtype, void* packed, int64_t Kpad,
                              double* partial, float* gram_partial, bool* gram_done, const float* qdense, float* vsup, int wpt,
-                             hipStream_t s) {
+                             hipStream_t s, bool w16) {
   const int NT = KP / 32;
+  if (w16 && NT < PRMF_EPI_CS_MIN_NT) return hipErrorInvalidValue;
   const int64_t ntiles = Kpad / 32;
   if (x_dtype != 1) return hipErrorInvalidValue;
   if (NT >= PRMF_EPI_CS_MIN_NT) {
@@ -1054,7 +1102,7 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
     a.nblocks_main = epilogue_blocks(Kpad, NT);
     a.pos = pos; a.gnum = gnum; a.gden = gden; a.max_support = max_support; a.partial = partial; a.vsup = vsup;
     *gram_done = true;
-    return launch_epilogue_cs<true>(a, GraphJob{}, NT, x_dtype == 1, qdense != nullptr, a.nblocks_main, s);
+    return launch_epilogue_cs<true>(a, GraphJob{}, NT, x_dtype == 1, qdense != nullptr, a.nblocks_main, s, w16);
   }
   // `wpt` must be the value the caller sized `partial` with (v_epilogue_waves): every partial row is written by
   // exactly one wave; the dense-Q form has no slabs to share and runs one wave per tile on the same grid
@@ -1088,7 +1136,7 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
 // runs with 16-B loads into a private LDS tile and reads its C/D-layout values from there.  Read straight from the
 // blocks in the C/D layout, one load instruction touched 2 rows x 32 / kc blocks with kc * 4 bytes each (32 B at eight
 // ranks of k = 64): 25.5 us per iteration at 20000 genes against 18 us for the whole fused V epilogue.
-template <int NT, bool GRAM, bool STAGED>
+template <int NT, bool GRAM, bool STAGED, bool W16>
 __global__ void __launch_bounds__(256)
 v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ v_recv, int64_t blk_stride, int kc,
               void* __restrict__ packed, int64_t ntiles_pack, float* __restrict__ gram_partial,
@@ -1149,15 +1197,20 @@ v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__
     if constexpr (GRAM) {
       if (row0 < n) gram_accumulate<NT>(vn, g);
     }
-    pack_tile_from_cd<NT>(vn, row0, lane, packed);
+    if constexpr (W16) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) pack_cd_w16(vn[t], row0, t, NT, lane, packed);
+    } else {
+      pack_tile_from_cd<NT>(vn, row0, lane, packed);
+    }
   }
   if constexpr (GRAM) gram_block_store<NT>(g, k, gram_partial + (int64_t)blockIdx.x * k * k, red);
 }
 
 hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_t blk_stride, int kc, int KP, int x_dtype,
                          void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, const int32_t* pos_all, float* vsup,
-                         int max_support, hipStream_t s) {
-  if (x_dtype != 1 || (pos_all && !vsup)) return hipErrorInvalidValue;
+                         int max_support, hipStream_t s, bool w16) {
+  if (x_dtype != 1 || (pos_all && !vsup) || (w16 && KP <= 64)) return hipErrorInvalidValue;
   const int NT = KP / 32;
   const int64_t ntiles = Kpad / 32;
   const int grid = epilogue_blocks(Kpad);
@@ -1165,16 +1218,23 @@ hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_
   const bool staged = (kc & 3) == 0 && (blk_stride & 3) == 0;
 #define PRMF_VPOST(NTV, GR)                                                                                      \
   do {                                                                                                           \
-    if (staged) v_post_kernel<NTV, GR, true><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, pos_all, vsup, max_support); \
-    else v_post_kernel<NTV, GR, false><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, pos_all, vsup, max_support); \
+    if (staged) v_post_kernel<NTV, GR, true, false><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, pos_all, vsup, max_support); \
+    else v_post_kernel<NTV, GR, false, false><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, pos_all, vsup, max_support); \
+  } while (0)
+#define PRMF_VPOST_W(NTV)                                                                                        \
+  do {                                                                                                           \
+    if (!w16) { PRMF_VPOST(NTV, false); }                                                                        \
+    else if (staged) v_post_kernel<NTV, false, true, true><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, pos_all, vsup, max_support); \
+    else v_post_kernel<NTV, false, false, true><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, pos_all, vsup, max_support); \
   } while (0)
   switch (NT) {
     case 1: PRMF_VPOST(1, true); break;
     case 2: PRMF_VPOST(2, true); break;
-    case 3: PRMF_VPOST(3, false); break;
-    case 4: PRMF_VPOST(4, false); break;
+    case 3: PRMF_VPOST_W(3); break;
+    case 4: PRMF_VPOST_W(4); break;
     default: return hipErrorInvalidValue;
   }
+#undef PRMF_VPOST_W
 #undef PRMF_VPOST
   return hipGetLastError();
 }
