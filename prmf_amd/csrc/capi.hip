@@ -459,7 +459,7 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   // the registers): 0.80 vs 1.17 ms per sweep at 25000 x 25000, k = 128.
   c->split_f32 = x_dtype == PRMF_X_F32;
   c->pack_dtype = c->split_f32 ? PRMF_X_BF16 : x_dtype;
-  c->w16 = x_dtype == PRMF_X_BF16 && c->NT > 2;
+  c->w16 = c->NT > 2 || (x_dtype == PRMF_X_F32 && c->NT == 2);    // gemm.hip SweepW16
   // slabs are written as whole 32-row tiles of whole panels (fragment order, no row masking)
   c->slab_stride_p = (int64_t)c->plan_xv.panels * c->plan_xv.panel_rows * c->KP;
   c->slab_stride_q = (int64_t)c->plan_xtu.panels * c->plan_xtu.panel_rows * c->KP;

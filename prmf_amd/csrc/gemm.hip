@@ -156,12 +156,56 @@ __device__ __forceinline__ void split_fragment(const u32x4& f0, const u32x4& f1,
 // running sum 10^4 times their size.
 template <int MODE, int NT>
 struct SweepLo { static constexpr bool value = MODE == 2 || (PRMF_BF16_ACC_LO != 0 && NT <= 2); };
+// Which sweeps multiply with v_mfma_f32_16x16x32_bf16 and the W16 fragment order: bf16 X at k > 64, f32 X at k > 32 (the
+// shapes whose matrix-instruction load makes the chip lower its clock: -5..10% per sweep, nothing at bf16 k <= 64 or f32
+// k <= 32 -- profiles/r03_ab_mfma_16x16x32.txt).  capi.hip's `w16` flag and the packing kernels follow the same rule.
+template <int MODE, int NT>
+struct SweepW16 { static constexpr bool value = (MODE == 1 && NT > 2) || (MODE == 2 && NT >= 2); };
 
 template <int MODE, int MT, int NT>
 __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&acc_lo)[(SweepLo<MODE, NT>::value ? MT : 1)][(SweepLo<MODE, NT>::value ? NT : 1)],
                                               const u32x4* __restrict__ sa, const u32x4* __restrict__ sb, int lane) {
   const int r = lane & 31, h = lane >> 5;
   const int swz = (r >> 1) & 7;
+  if constexpr (MODE == 2 && SweepW16<MODE, NT>::value) {
+    // f32 X, W16: the chunk (32 columns) is ONE 32-element step of the 16x16x32 MFMA.  The three exact pieces of every
+    // 16-row group's A fragment (lane (r16, kg): 8 consecutive floats = 16-B pieces 2 kg, 2 kg + 1 of its row) are split
+    // once and kept; the factor fragments stream by, one 16-column tile at a time.  Accumulator storage as for bf16 X.
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    constexpr int NG = 2 * MT, T16 = 2 * NT;
+    const int r16 = lane & 15, kg = lane >> 4;
+    u32x4 ah[NG], am[NG], al[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int rr = 16 * (g & 1) + r16, sw = (rr >> 1) & 7;
+      split_fragment(sa[(g >> 1) * 256 + rr * 8 + ((2 * kg) ^ sw)], sa[(g >> 1) * 256 + rr * 8 + ((2 * kg + 1) ^ sw)], ah[g], am[g], al[g]);
+    }
+    auto mm16 = [&](f32x4_& d, const u32x4& a, const u32x4& b) {
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), d, 0, 0, 0);
+    };
+#pragma unroll
+    for (int t16 = 0; t16 < T16; ++t16) {
+      const u32x4 bh = sb[(t16 * 2 + 0) * 64 + lane];
+      const u32x4 bl = sb[(t16 * 2 + 1) * 64 + lane];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int mt = g >> 1, t = t16 >> 1, o = 4 * (2 * (g & 1) + (t16 & 1));
+        f32x4_ lo4 = {acc_lo[mt][t][o], acc_lo[mt][t][o + 1], acc_lo[mt][t][o + 2], acc_lo[mt][t][o + 3]};
+        f32x4_ hi4 = {acc[mt][t][o], acc[mt][t][o + 1], acc[mt][t][o + 2], acc[mt][t][o + 3]};
+        mm16(lo4, al[g], bh);      // smallest terms first
+        mm16(lo4, am[g], bl);
+        mm16(lo4, ah[g], bl);
+        mm16(lo4, am[g], bh);
+        mm16(hi4, ah[g], bh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc_lo[mt][t][o + i] = lo4[i];
+          acc[mt][t][o + i] = hi4[i];
+        }
+      }
+    }
+    return;
+  }
   if constexpr (MODE == 2) {
     // 64-row wave tiles (k <= 64): not unrolled over the two k-blocks -- the three-piece split is register-hungry (222
     // registers at k = 64 next to the 2 x 64 accumulator registers; two waves per SIMD allow 256) and unrolled it is no
@@ -209,7 +253,7 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&ac
     // own floats 4 (2 a + b) .. + 4 of acc[mt][t]  (C layout: lane (c16, rg) holds rows 4 rg + i, i = 0..3).
     // The fragment reads of step j + 1 are issued before the MFMAs of step j (scheduling barriers keep them there).
     typedef float f32x4_ __attribute__((ext_vector_type(4)));
-    static_assert(MT == 2, "four 16-row groups per wave");
+    static_assert(MT == 2 && SweepW16<MODE, NT>::value, "four 16-row groups per wave");
     const int r16 = lane & 15, kg = lane >> 4;
     u32x4 av[4], bb[2][2];     // (A fragments double-buffered too: 16 more registers, 45 spilled instead of 26 at k = 128)
     auto a_frag = [&](int step, int rg16) -> u32x4 {
@@ -520,7 +564,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   // tools/stream_ladder2.hip).  Element (row, col) of a slab:
   //   tile = row/32, rr = row%32, lane = col%32 + 32*((rr>>2)&1), q4 = rr>>3, j = rr&3, t = col/32
   f32x4* out = reinterpret_cast<f32x4*>(slabs + (int64_t)seg * slab_stride);
-  if constexpr (MODE == 1 && NT > 2) {
+  if constexpr (SweepW16<MODE, NT>::value) {
     // W16 accumulators (see sweep_compute) into the SAME slab order: floats 4 (2 a + b) .. + 4 of acc[mt][t] are rows
     // 16 a + 4 rg + i, column 16 b + c16 of the 32 x 32 tile (mt, t) -> q4 = 2 a + (rg >> 1), lane' = 16 b + c16 + 32 (rg & 1):
     // every store instruction writes four 256-B runs
@@ -535,7 +579,11 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 #pragma unroll
           for (int b2 = 0; b2 < 2; ++b2) {
             const int o = 4 * (2 * a2 + b2);
-            const f32x4 v = {acc[mt][t][o], acc[mt][t][o + 1], acc[mt][t][o + 2], acc[mt][t][o + 3]};
+            f32x4 v = {acc[mt][t][o], acc[mt][t][o + 1], acc[mt][t][o + 2], acc[mt][t][o + 3]};
+            if constexpr (HAS_LO) {
+              const f32x4 w = {acc_lo[mt][t][o], acc_lo[mt][t][o + 1], acc_lo[mt][t][o + 2], acc_lo[mt][t][o + 3]};
+              v += w;
+            }
             f32x4* dst = out + ((tile * NT + t) * 4 + (2 * a2 + (rg >> 1))) * 64 + (16 * b2 + c16 + 32 * (rg & 1));
             if (slab_nt) __builtin_nontemporal_store(v, dst);     // (uniform)
             else *dst = v;

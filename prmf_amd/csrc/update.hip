@@ -221,6 +221,16 @@ __device__ __forceinline__ void pack_cd_w16(const float (&v)[16], int64_t row0, 
   }
 }
 
+template <int NT, bool W16>
+__device__ __forceinline__ void pack_tile(const float (&un)[NT][16], int64_t row0, int lane, void* packed) {
+  if constexpr (W16) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) pack_cd_w16(un[t], row0, t, NT, lane, packed);
+  } else {
+    pack_tile_from_cd<NT>(un, row0, lane, packed);
+  }
+}
+
 // A-layout load of one 32-row tile of F (lane (r,h): F[row0+r][(KP/2)h .. +KP/2), zero outside).
 // VEC4: k % 4 == 0, the rows of F are 16-B aligned -> one float4 per 4 columns; else (any k -- the CLI's default is 6)
 // element loads with clamped addresses.  A template parameter, not a branch: both forms in one kernel cost the
@@ -456,7 +466,7 @@ __device__ __forceinline__ void gram_total_store(const float (&gtot)[NT * (NT + 
 }
 
 // GRAM: also accumulate F_new^T F_new (per-workgroup partial [k*k] floats at gram_partial[blockIdx])
-template <int NT, bool VEC4, bool GRAM>
+template <int NT, bool VEC4, bool GRAM, bool W16>
 __global__ void __launch_bounds__(256, NT <= 2 ? 2 : 1)
 u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restrict__ slabs, const segmask_t* __restrict__ segmask,
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gv, void* __restrict__ packed,
@@ -548,7 +558,7 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
     }
     EPI_DEP(un);
     EPI_STAMP(4);
-    if (lead) pack_tile_from_cd<NT>(un, row0, lane, packed);   // tiles past m are packed as zeros
+    if (lead) pack_tile<NT, W16>(un, row0, lane, packed);   // tiles past m are packed as zeros
     EPI_STAMP(5);
     if constexpr (GRAM) {
       f32x16 gt[NP];
@@ -913,7 +923,7 @@ hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, con
                              int64_t slab_stride, int KP, const double* Gv, int x_dtype, void* packed, int64_t Kpad,
                              float* gram_partial, bool* gram_done, int wpt, hipStream_t s, const GraphJob* graph, bool w16) {
   const int NT = KP / 32;
-  if (w16 && NT < PRMF_EPI_CS_MIN_NT) return hipErrorInvalidValue;      // the 16x16x32 fragment order exists for k > 64 only
+  if (w16 && NT < 2) return hipErrorInvalidValue;      // the 16x16x32 fragment order exists for k > 32 only
   const int64_t ntiles = Kpad / 32;          // every tile of the packed buffer is (re)written, zero beyond m
   const GraphJob gj = graph ? *graph : GraphJob{};
   if (x_dtype != 1) return hipErrorInvalidValue;   // fragment layout of the packed factor: hi/lo bf16 only
@@ -929,12 +939,13 @@ hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, con
   const int nmain = epilogue_blocks(Kpad, wpt);
   const int grid = nmain + (gj.ncols > 0 ? gj.ncols * gj.nsplit : 0);
   *gram_done = NT <= 2;
-#define PRMF_UEP(NTV, GR)                                                                                          \
-  if ((k & 3) == 0) u_epilogue_kernel<NTV, true, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial, wpt, nmain, gj, g_epi_stamps); \
-  else u_epilogue_kernel<NTV, false, GR><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial, wpt, nmain, gj, g_epi_stamps)
+#define PRMF_UEP2(NTV, GR, WV)                                                                                     \
+  if ((k & 3) == 0) u_epilogue_kernel<NTV, true, GR, WV><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial, wpt, nmain, gj, g_epi_stamps); \
+  else u_epilogue_kernel<NTV, false, GR, WV><<<grid, 256, 0, s>>>(U, m, k, slabs, segmask, panel_rows, slab_stride, Gv, packed, ntiles, gram_partial, wpt, nmain, gj, g_epi_stamps)
+#define PRMF_UEP(NTV, GR) PRMF_UEP2(NTV, GR, false)
   switch (NT) {
     case 1: PRMF_UEP(1, true); break;
-    case 2: PRMF_UEP(2, true); break;
+    case 2: if (w16) { PRMF_UEP2(2, true, true); } else { PRMF_UEP(2, true); } break;
 #if PRMF_EPI_CS_MIN_NT > 3      // k > 64 takes the column-split kernel above
     case 3: PRMF_UEP(3, false); break;
     case 4: PRMF_UEP(4, false); break;
@@ -942,13 +953,14 @@ hipError_t launch_u_epilogue(float* U, int64_t m, int k, const float* slabs, con
     default: return hipErrorInvalidValue;
   }
 #undef PRMF_UEP
+#undef PRMF_UEP2
   return hipGetLastError();
 }
 
 // Single-rank V epilogue: V <- V * (Q + g_num) / max(V (U^T U) + g_den, eps), clamp
 // (prmf_runner.py:424-444), in place, + packing + per-wave partial column sums of
 // squares and <Q, V_new> (float64) + (GRAM) V_new^T V_new partials.
-template <int NT, bool VEC4, bool GRAM, bool DENSE>
+template <int NT, bool VEC4, bool GRAM, bool DENSE, bool W16>
 __global__ void __launch_bounds__(256, NT <= 2 ? 2 : 1)
 v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__ slabs /* DENSE: Q [n][k] */, const segmask_t* __restrict__ segmask,
                   int panel_rows, int64_t slab_stride, const double* __restrict__ Gu, const int32_t* __restrict__ pos,
@@ -1060,7 +1072,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
         }
       }
     }
-    if (lead) pack_tile_from_cd<NT>(vn, row0, lane, packed);   // tiles past n are packed as zeros
+    if (lead) pack_tile<NT, W16>(vn, row0, lane, packed);   // tiles past n are packed as zeros
     if constexpr (GRAM) {
       f32x16 gt[NP];
 #pragma unroll
@@ -1092,7 +1104,7 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
                              double* partial, float* gram_partial, bool* gram_done, const float* qdense, float* vsup, int wpt,
                              hipStream_t s, bool w16) {
   const int NT = KP / 32;
-  if (w16 && NT < PRMF_EPI_CS_MIN_NT) return hipErrorInvalidValue;
+  if (w16 && NT < 2) return hipErrorInvalidValue;
   const int64_t ntiles = Kpad / 32;
   if (x_dtype != 1) return hipErrorInvalidValue;
   if (NT >= PRMF_EPI_CS_MIN_NT) {
@@ -1111,8 +1123,10 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
   const int kwpt = qdense ? 1 : wpt;
   *gram_done = NT <= 2;
   const float* qsrc = qdense ? qdense : slabs;
+#define PRMF_VEP3(NTV, GR, V4, DN, WV)                                                                              \
+  v_epilogue_kernel<NTV, V4, GR, DN, WV><<<grid, 256, 0, s>>>(V, n, k, qsrc, segmask, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial, vsup, kwpt)
 #define PRMF_VEP2(NTV, GR, V4, DN)                                                                                  \
-  v_epilogue_kernel<NTV, V4, GR, DN><<<grid, 256, 0, s>>>(V, n, k, qsrc, segmask, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial, vsup, kwpt)
+  do { if (NTV == 2 && w16) { PRMF_VEP3(2, GR, V4, DN, true); } else { PRMF_VEP3(NTV, GR, V4, DN, false); } } while (0)
 #define PRMF_VEP(NTV, GR)                                                                                           \
   if ((k & 3) == 0) { if (qdense) PRMF_VEP2(NTV, GR, true, true); else PRMF_VEP2(NTV, GR, true, false); }           \
   else { if (qdense) PRMF_VEP2(NTV, GR, false, true); else PRMF_VEP2(NTV, GR, false, false); }
@@ -1127,6 +1141,7 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
   }
 #undef PRMF_VEP
 #undef PRMF_VEP2
+#undef PRMF_VEP3
   return hipGetLastError();
 }
 
@@ -1210,7 +1225,7 @@ v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__
 hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_t blk_stride, int kc, int KP, int x_dtype,
                          void* packed, int64_t Kpad, float* gram_partial, bool* gram_done, const int32_t* pos_all, float* vsup,
                          int max_support, hipStream_t s, bool w16) {
-  if (x_dtype != 1 || (pos_all && !vsup) || (w16 && KP <= 64)) return hipErrorInvalidValue;
+  if (x_dtype != 1 || (pos_all && !vsup) || (w16 && KP < 64)) return hipErrorInvalidValue;
   const int NT = KP / 32;
   const int64_t ntiles = Kpad / 32;
   const int grid = epilogue_blocks(Kpad);
@@ -1229,7 +1244,11 @@ hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_
   } while (0)
   switch (NT) {
     case 1: PRMF_VPOST(1, true); break;
-    case 2: PRMF_VPOST(2, true); break;
+    case 2:
+      if (!w16) { PRMF_VPOST(2, true); }
+      else if (staged) v_post_kernel<2, true, true, true><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, pos_all, vsup, max_support);
+      else v_post_kernel<2, true, false, true><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, pos_all, vsup, max_support);
+      break;
     case 3: PRMF_VPOST_W(3); break;
     case 4: PRMF_VPOST_W(4); break;
     default: return hipErrorInvalidValue;

@@ -43,6 +43,8 @@ def run_gpu(case, x_dtype, steps, repeats=1):
     (600, 800, 80, "bf16"),        # three 32-column tiles: the column-split epilogue with an idle fourth wave
     (450, 700, 96, "f32"),
     (777, 1111, 128, "f32"),       # f32 X at k > 64: three-piece split with 32-row wave tiles (128-row panels)
+    (640, 1500, 48, "f32"),        # f32 X at 32 < k <= 64: the 16x16x32 MFMA with 64-row wave tiles, W16 packing in the fused epilogues
+    (530, 1200, 50, "f32"),        # the same with k % 4 != 0 (element-wise factor loads)
     (500, 20000, 6, "f32"),        # the reference's typical shape: samples << genes, default k (2 row panels: up to 64 slabs each)
     (300, 12000, 8, "bf16"),
 ])
