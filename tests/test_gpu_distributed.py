@@ -77,7 +77,7 @@ def _worker(rank, world, port, k, x_dtype, mode, q, eager=False):
 
 
 @pytest.mark.parametrize("k,x_dtype,mode", [(16, "f32", "replicated"), (13, "bf16", "replicated"), (64, "bf16", "replicated"),
-                                             (128, "bf16", "replicated"), (100, "f32", "colshard"), (64, "f32", "colshard"),
+                                             (128, "bf16", "replicated"), (100, "f32", "colshard"), (64, "f32", "colshard"), (48, "f32", "replicated"),
                                              (16, "f32", "colshard"), (13, "bf16", "colshard")])
 def test_two_ranks_match_single_rank(k, x_dtype, mode):
     import torch
