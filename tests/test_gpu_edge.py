@@ -46,6 +46,10 @@ def check(case, x_dtype, steps=5):
     (33, 31, 3, 3, 8, "bf16"),        # fewer genes than one tile
     (257, 129, 8, 2, 20, "bf16"),     # one row past a 256-row panel, one chunk past 128 genes
     (64, 2049, 32, 4, 30, "f32"),
+    (5, 70, 40, 2, 10, "f32"),        # the 16x16x32 MFMA forms on tiny ragged shapes: f32 X at 32 < k <= 64 ...
+    (40, 33, 64, 3, 8, "f32"),
+    (33, 257, 100, 3, 20, "bf16"),    # ... and bf16 X at k > 64 (column-split epilogues)
+    (2, 65, 128, 2, 12, "f32"),
 ])
 def test_tiny_and_ragged_shapes(m, n, k, P, order, x_dtype):
     case = synth.small_case(seed=21, m=m, n=n, k=k, P=P, order=order, zero_genes=min(3, n // 8), isolated=1,
@@ -61,7 +65,7 @@ def test_deferred_objective_equals_per_iteration_form():
     import torch
     from prmf_amd import PathwayLibrary
     from prmf_amd.solver import PrmfEngine
-    for (m, n, k, xd) in [(777, 1900, 16, "f32"), (1500, 2600, 64, "bf16"), (300, 1000, 13, "f32"), (640, 900, 128, "bf16")]:
+    for (m, n, k, xd) in [(777, 1900, 16, "f32"), (1500, 2600, 64, "bf16"), (300, 1000, 13, "f32"), (640, 900, 128, "bf16"), (500, 800, 48, "f32")]:
         case = synth.small_case(seed=5, m=m, n=n, k=k, P=6, order=90, bf16_x=(xd == "bf16"))
         outs = []
         for lazy in (True, False):
