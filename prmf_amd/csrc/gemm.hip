@@ -162,9 +162,13 @@ struct SweepLo { static constexpr bool value = MODE == 2 || (PRMF_BF16_ACC_LO !=
 template <int MODE, int NT>
 struct SweepW16 { static constexpr bool value = (MODE == 1 && NT > 2) || (MODE == 2 && NT >= 2); };
 
-template <int MODE, int MT, int NT>
+struct NoStepHook { __device__ __forceinline__ void operator()(int) const {} };
+// number of hook calls sweep_compute makes per chunk (0: the form has no step structure)
+template <int MODE, int NT> struct SweepSteps { static constexpr int value = (MODE == 1 && NT > 2) ? 4 * NT : 0; };
+
+template <int MODE, int MT, int NT, typename Hook = NoStepHook>
 __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&acc_lo)[(SweepLo<MODE, NT>::value ? MT : 1)][(SweepLo<MODE, NT>::value ? NT : 1)],
-                                              const u32x4* __restrict__ sa, const u32x4* __restrict__ sb, int lane) {
+                                              const u32x4* __restrict__ sa, const u32x4* __restrict__ sb, int lane, const Hook& hook = Hook()) {
   const int r = lane & 31, h = lane >> 5;
   const int swz = (r >> 1) & 7;
   if constexpr (MODE == 2 && SweepW16<MODE, NT>::value) {
@@ -274,6 +278,7 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&ac
         bb[jn & 1][0] = sb[(jn * 2 + 0) * 64 + lane];
         bb[jn & 1][1] = sb[(jn * 2 + 1) * 64 + lane];
       }
+      hook(j);      // the caller's share of this step (the next chunk's global loads, one or two per step)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -338,6 +343,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PRMF_LOADS_FIRST 1
 #endif
 constexpr bool LOADS_FIRST = PRMF_LOADS_FIRST != 0;
+#ifndef PRMF_SPRINKLE
+#define PRMF_SPRINKLE 8     // workgroup size (in waves) whose k > 64 sweeps issue the next chunk's loads one per MFMA step; 0: none
+#endif
+// Sprinkled loads (see the chunk loop).  Measured in one session at 200000 x 25000, k = 128 (profiles/r03_ab_sprinkled_loads.txt):
+// the 8-wave form (one workgroup per CU: its two waves per SIMD run the same phase at the same time, so nothing else
+// overlaps a wave's load burst with MFMAs) 2.214 -> 2.059 ms; the 4-wave form (two workgroups per CU that alternate
+// phases by themselves) 2.132 -> 2.319 ms, 25000 x 25000 equal -- hence the 8-wave form only.
+template <int NW> struct Sprinkle { static constexpr bool value = PRMF_SPRINKLE != 0 && (PRMF_SPRINKLE == NW || PRMF_SPRINKLE == 1); };
 #ifndef PRMF_UNIT_CHUNKS
 #define PRMF_UNIT_CHUNKS 2
 #endif
@@ -509,7 +522,8 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
       if (have) {
         const int cn = c + u + 1;
         PH_MARK(0);
-        if constexpr (LOADS_FIRST && LF_MODE_OK) {
+        constexpr int STEPS = Sprinkle<NW>::value ? SweepSteps<MODE, NT>::value : 0;
+        if constexpr (LOADS_FIRST && LF_MODE_OK && STEPS == 0) {
           // the next chunk's loads are in flight while this chunk is computed from LDS
           if (next) {
             load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
@@ -528,12 +542,36 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 #if PRMF_SWEEP_PRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
-        sweep_compute<MODE, MT, NT>(acc, acc_lo, myA, sB[BDB ? u : 0], lane);
+        if constexpr (STEPS > 0) {
+          // k > 64: the next chunk's BPT + 4 MT loads go out one (or two) per MFMA step instead of as a burst in front of
+          // the chunk -- a wave that sits in a full memory queue issues no MFMAs
+          constexpr int NLD = BPT + 4 * MT, LPS = (NLD + STEPS - 1) / STEPS;
+          // no branch around the loads (behind one the compiler waits vmcnt(0) before every load): the last chunk of a
+          // segment re-loads itself, one wasted chunk per segment
+          const int cl = next ? cn : c + u;
+          const u32x4* const bnext = reinterpret_cast<const u32x4*>(bbase + (int64_t)cl * BCH);
+          const char* const anext = reinterpret_cast<const char*>(abase + (int64_t)cl * 8);
+          auto hook = [&](int j) {
+#pragma unroll
+            for (int q = 0; q < LPS; ++q) {
+              const int li = j * LPS + q;
+              if (li < BPT) {
+                if ((li + 1) * NTHR <= BCH || tid + NTHR * li < BCH) bs[li] = bnext[tid + NTHR * li];
+              } else if (li < NLD) {
+                const u32x4* src = reinterpret_cast<const u32x4*>(anext + avoff[(li - BPT) / 4][(li - BPT) % 4]);
+                a[(li - BPT) / 4][(li - BPT) % 4] = NT_LOADS ? __builtin_nontemporal_load(src) : *src;
+              }
+            }
+          };
+          sweep_compute<MODE, MT, NT>(acc, acc_lo, myA, sB[BDB ? u : 0], lane, hook);
+        } else {
+          sweep_compute<MODE, MT, NT>(acc, acc_lo, myA, sB[BDB ? u : 0], lane);
+        }
 #if PRMF_SWEEP_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
         PH_MARK(2);
-        if constexpr (!(LOADS_FIRST && LF_MODE_OK)) {
+        if constexpr (!(LOADS_FIRST && LF_MODE_OK) && STEPS == 0) {
           if (next) {
             load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
             load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
@@ -543,7 +581,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
         }
         if constexpr (!BDB) __syncthreads();          // everyone has finished reading B(c)
         PH_MARK(3);
-        if (next) {
+        if (next || STEPS > 0) {      // STEPS > 0: unconditional like the loads (or the compiler sinks the loads into this block)
           store_b_chunk<BPT, NTHR, BCH>(sB[BDB ? (u ^ 1) : 0], bs, tid);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
@@ -632,7 +670,12 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 //   Cache by every segment) 2.62 -> 2.21 ms; with a 12.8 MB factor -2% at 25000 rows and +7% at 200000 rows -- hence the
 //   threshold.
 constexpr int SWEEP_NW = 4, SWEEP_MT = 2, SWEEP_WGS_PER_CU = 2, SWEEP_NW_WIDE = 8;
-constexpr double SWEEP_WIDE_FACTOR_BYTES = 32.0 * 1024 * 1024;
+#ifndef PRMF_WIDE_MB
+#define PRMF_WIDE_MB 32.0
+#endif
+constexpr double SWEEP_WIDE_FACTOR_BYTES = PRMF_WIDE_MB * 1024 * 1024;
+constexpr double SWEEP_WIDE_SMALL_FACTOR_BYTES = 8.0 * 1024 * 1024;      // ... or >= 8 MB on a matrix of at most
+constexpr int64_t SWEEP_WIDE_SMALL_MAX_ROWS = 131072;                     //     this many rows
 
 // 32-row tiles per wave.  bf16 X: 2 at every k.  f32 X (three-piece split, two accumulator sets): 2 at k = 33..64; 1 at
 // k > 64, where two do not fit 256 registers, and at k <= 32, where the 128-row panels measure 4% faster on the
@@ -647,7 +690,12 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
   p.mt = f32_wave_tiles(x_dtype, NT);
   // bf16 X, k > 64, a factor far beyond the caches (the X^T U sweep of 200000 samples: 102 MB): one 8-wave workgroup per
   // CU on 512-row panels -- every 32 KiB factor chunk then serves twice the rows -- with the chunk double-buffered
-  if (x_dtype == 1 && NT > 2 && (double)Kpad * 32.0 * NT * 4.0 >= SWEEP_WIDE_FACTOR_BYTES) {
+  // Since its loads are sprinkled through the MFMA steps (chunk loop) the shape also wins at smaller factors as long as
+  // the matrix is not too tall: 12.8 MB factor (X V at k = 128), same session: 25000 rows 0.332 -> 0.322 ms, 50000 rows
+  // 0.606 -> 0.589, 100000 rows 1.167 -> 1.148, but 200000 rows 2.130 -> 2.232 (profiles/r03_ab_sprinkled_loads.txt).
+  const double factor_bytes = (double)Kpad * 32.0 * NT * 4.0;
+  if (x_dtype == 1 && NT > 2 &&
+      (factor_bytes >= SWEEP_WIDE_FACTOR_BYTES || (factor_bytes >= SWEEP_WIDE_SMALL_FACTOR_BYTES && M <= SWEEP_WIDE_SMALL_MAX_ROWS))) {
     p.nw = SWEEP_NW_WIDE;
     p.bdb = true;
   }
