@@ -343,6 +343,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PRMF_LOADS_FIRST 1
 #endif
 constexpr bool LOADS_FIRST = PRMF_LOADS_FIRST != 0;
+#ifndef PRMF_SPRINKLE_LPS
+#define PRMF_SPRINKLE_LPS 2     // loads per MFMA step (0: as few as cover the chunk).  2: the 12 loads of a k = 128 chunk leave in the first 6 of
+                                // its 16 steps, so the rest of the chunk covers their latency: 1-2 % ahead of 1 and of 3 per step
+#endif
 #ifndef PRMF_SPRINKLE
 #define PRMF_SPRINKLE 8     // workgroup size (in waves) whose k > 64 sweeps issue the next chunk's loads one per MFMA step; 0: none
 #endif
@@ -545,7 +549,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
         if constexpr (STEPS > 0) {
           // k > 64: the next chunk's BPT + 4 MT loads go out one (or two) per MFMA step instead of as a burst in front of
           // the chunk -- a wave that sits in a full memory queue issues no MFMAs
-          constexpr int NLD = BPT + 4 * MT, LPS = (NLD + STEPS - 1) / STEPS;
+          constexpr int NLD = BPT + 4 * MT, LPS = PRMF_SPRINKLE_LPS * STEPS >= NLD ? PRMF_SPRINKLE_LPS : (NLD + STEPS - 1) / STEPS;
           // no branch around the loads (behind one the compiler waits vmcnt(0) before every load): the last chunk of a
           // segment re-loads itself, one wasted chunk per segment
           const int cl = next ? cn : c + u;
