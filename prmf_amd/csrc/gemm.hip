@@ -678,8 +678,7 @@ constexpr int SWEEP_NW = 4, SWEEP_MT = 2, SWEEP_WGS_PER_CU = 2, SWEEP_NW_WIDE = 
 #define PRMF_WIDE_MB 32.0
 #endif
 constexpr double SWEEP_WIDE_FACTOR_BYTES = PRMF_WIDE_MB * 1024 * 1024;
-constexpr double SWEEP_WIDE_SMALL_FACTOR_BYTES = 8.0 * 1024 * 1024;      // ... or >= 8 MB on a matrix of at most
-constexpr int64_t SWEEP_WIDE_SMALL_MAX_ROWS = 131072;                     //     this many rows
+constexpr double SWEEP_WIDE_SMALL_FACTOR_BYTES = 8.0 * 1024 * 1024;      // the 8-wave form from this factor size up (unsliced below the 32 MB)
 
 // 32-row tiles per wave.  bf16 X: 2 at every k.  f32 X (three-piece split, two accumulator sets): 2 at k = 33..64; 1 at
 // k > 64, where two do not fit 256 registers, and at k <= 32, where the 128-row panels measure 4% faster on the
@@ -694,12 +693,10 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
   p.mt = f32_wave_tiles(x_dtype, NT);
   // bf16 X, k > 64, a factor far beyond the caches (the X^T U sweep of 200000 samples: 102 MB): one 8-wave workgroup per
   // CU on 512-row panels -- every 32 KiB factor chunk then serves twice the rows -- with the chunk double-buffered
-  // Since its loads are sprinkled through the MFMA steps (chunk loop) the shape also wins at smaller factors as long as
-  // the matrix is not too tall: 12.8 MB factor (X V at k = 128), same session: 25000 rows 0.332 -> 0.322 ms, 50000 rows
-  // 0.606 -> 0.589, 100000 rows 1.167 -> 1.148, but 200000 rows 2.130 -> 2.232 (profiles/r03_ab_sprinkled_loads.txt).
+  // Since its loads are sprinkled through the MFMA steps (chunk loop) the shape also wins at smaller factors -- unsliced
+  // (see below): from 8 MB up at every row count (profiles/r03_ab_sprinkled_loads.txt).
   const double factor_bytes = (double)Kpad * 32.0 * NT * 4.0;
-  if (x_dtype == 1 && NT > 2 &&
-      (factor_bytes >= SWEEP_WIDE_FACTOR_BYTES || (factor_bytes >= SWEEP_WIDE_SMALL_FACTOR_BYTES && M <= SWEEP_WIDE_SMALL_MAX_ROWS))) {
+  if (x_dtype == 1 && NT > 2 && factor_bytes >= SWEEP_WIDE_SMALL_FACTOR_BYTES) {
     p.nw = SWEEP_NW_WIDE;
     p.bdb = true;
   }
@@ -735,6 +732,12 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
       // straddle slice boundaries and two slices are 0-6% slower (profiles/r02_slices_small_shares.txt).
       p.nx = 2;
     }
+    // The 8-wave form reads half the factor bytes per byte of X, and unsliced it writes a third of the slab segments:
+    // below the 32 MB that its big-factor rule starts at it is fastest with no slices at all -- X V of 25000 / 50000 /
+    // 100000 / 200000 rows x 25000 genes, k = 128 (12.8 MB factor): 0.3215 -> 0.3162, 0.5798 -> 0.5701, 1.127 -> 1.050,
+    // 2.166 -> 2.083 ms (and 2.108 in the 4-wave form with 4 slices); from 51 MB up the slices stay (X^T U of 100000
+    // samples 1.066 against 1.085 ms unsliced; 200000 samples equal).  profiles/r03_ab_sprinkled_loads.txt.
+    if (p.nw == SWEEP_NW_WIDE && factor_bytes < SWEEP_WIDE_FACTOR_BYTES) p.nx = 1;
     if (tune.force_slices == 1 || tune.force_slices == 2 || tune.force_slices == 4 || tune.force_slices == 8) p.nx = tune.force_slices;
   }
   if (G < 1) G = 1;
