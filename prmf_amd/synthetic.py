@@ -12,6 +12,8 @@ CONFIGS = {
     "c5shard": (25000, 25000, 128, 1000, "bf16"),     # one rank's share of c5 on 8 GPUs
     "c5shardf32": (25000, 25000, 128, 1000, "f32"),   # the same with the CLI's default storage of X
     "c4share8": (6250, 20000, 64, 300, "bf16"),      # one rank's share of c3 on 8 GPUs (c4)
+    "c4share4": (12500, 20000, 64, 300, "bf16"),     # ... on 4 GPUs
+    "c4share2": (25000, 20000, 64, 300, "bf16"),     # ... on 2 GPUs
     "c5share4": (50000, 25000, 128, 1000, "bf16"),    # one rank's share of c5 on 4 GPUs
     "c5share2": (100000, 25000, 128, 1000, "bf16"),   # ... on 2 GPUs
     "cli": (500, 20000, 6, 50, "f32"),                # the reference's typical use: samples << genes, default k = 6
