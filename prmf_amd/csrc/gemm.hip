@@ -31,6 +31,7 @@
 // bounced through a wave-private XOR-swizzled LDS tile from which the 16-B A fragments are read (see "A path" below:
 // fragment-shaped global loads were 22% slower).  B is staged once per workgroup per chunk through registers into LDS.
 #include "kernels.h"
+#include <type_traits>
 #include "prologue.h"
 
 
@@ -164,7 +165,7 @@ struct SweepW16 { static constexpr bool value = (MODE == 1 && NT > 2) || (MODE =
 
 struct NoStepHook { __device__ __forceinline__ void operator()(int) const {} };
 // number of hook calls sweep_compute makes per chunk (0: the form has no step structure)
-template <int MODE, int NT> struct SweepSteps { static constexpr int value = (MODE == 1 && NT > 2) ? 4 * NT : 0; };
+template <int MODE, int NT> struct SweepSteps { static constexpr int value = MODE == 1 ? 4 * NT : 0; };
 
 template <int MODE, int MT, int NT, typename Hook = NoStepHook>
 __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&acc_lo)[(SweepLo<MODE, NT>::value ? MT : 1)][(SweepLo<MODE, NT>::value ? NT : 1)],
@@ -304,6 +305,10 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&ac
     for (int t = 0; t < NT; ++t) {
       const u32x4 bh = sb[((s4 * NT + t) * 2 + 0) * 64 + lane];
       const u32x4 bl = sb[((s4 * NT + t) * 2 + 1) * 64 + lane];
+      if constexpr (!std::is_same<Hook, NoStepHook>::value) {
+        hook(s4 * NT + t);      // the caller's share of this step (the next chunk's global loads), kept in place
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
@@ -696,7 +701,10 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
   // Since its loads are sprinkled through the MFMA steps (chunk loop) the shape also wins at smaller factors -- unsliced
   // (see below): from 8 MB up at every row count (profiles/r03_ab_sprinkled_loads.txt).
   const double factor_bytes = (double)Kpad * 32.0 * NT * 4.0;
-  if (x_dtype == 1 && NT > 2 && factor_bytes >= SWEEP_WIDE_SMALL_FACTOR_BYTES) {
+  // k = 33..64 as well (8 steps of 4 MFMAs per chunk, low-piece accumulators, 32x32x16): X^T U of 50000 samples
+  // (12.8 MB factor, 4 slices in the 4-wave form) 0.3845 -> 0.3795 ms unsliced in the 8-wave form, iteration 0.8420 ->
+  // 0.8325 ms, 7 of 7 interleaved rounds; with 2 slices it is slower than the 4-wave form.
+  if (x_dtype == 1 && NT >= 2 && factor_bytes >= SWEEP_WIDE_SMALL_FACTOR_BYTES) {
     p.nw = SWEEP_NW_WIDE;
     p.bdb = true;
   }
@@ -804,6 +812,7 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
       p.slab_nt ? 1 : 0, g_sweep_stamps, pro)
   if constexpr (NW == 8) {
     switch (NT) {
+      case 2: PRMF_LAUNCH(2); break;
       case 3: PRMF_LAUNCH(3); break;
       case 4: PRMF_LAUNCH(4); break;
       default: return hipErrorInvalidValue;
@@ -847,7 +856,7 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
   const int mode = x_dtype == 1 ? 1 : 2;
   if (x_dtype != 1 && !split) return hipErrorInvalidValue;
   if (p.nw == SWEEP_NW_WIDE) {
-    if (mode != 1 || NT <= 2 || !p.bdb || p.mt != SWEEP_MT) return hipErrorInvalidValue;
+    if (mode != 1 || NT < 2 || !p.bdb || p.mt != SWEEP_MT) return hipErrorInvalidValue;
     return launch_sweep_nt<1, SWEEP_NW_WIDE, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
   }
   if (p.nw != SWEEP_NW || p.mt != f32_wave_tiles(x_dtype, NT) || p.bdb != (NT <= 2)) return hipErrorInvalidValue;
