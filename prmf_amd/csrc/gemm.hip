@@ -165,7 +165,7 @@ struct SweepW16 { static constexpr bool value = (MODE == 1 && NT > 2) || (MODE =
 
 struct NoStepHook { __device__ __forceinline__ void operator()(int) const {} };
 // number of hook calls sweep_compute makes per chunk (0: the form has no step structure)
-template <int MODE, int NT> struct SweepSteps { static constexpr int value = MODE == 1 ? 4 * NT : 0; };
+template <int MODE, int NT> struct SweepSteps { static constexpr int value = MODE == 1 ? 4 * NT : ((MODE == 2 && NT >= 2) ? 2 * NT : 0); };
 
 template <int MODE, int MT, int NT, typename Hook = NoStepHook>
 __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&acc_lo)[(SweepLo<MODE, NT>::value ? MT : 1)][(SweepLo<MODE, NT>::value ? NT : 1)],
@@ -192,6 +192,10 @@ __device__ __forceinline__ void sweep_compute(f32x16 (&acc)[MT][NT], f32x16 (&ac
     for (int t16 = 0; t16 < T16; ++t16) {
       const u32x4 bh = sb[(t16 * 2 + 0) * 64 + lane];
       const u32x4 bl = sb[(t16 * 2 + 1) * 64 + lane];
+      if constexpr (!std::is_same<Hook, NoStepHook>::value) {
+        hook(t16);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int mt = g >> 1, t = t16 >> 1, o = 4 * (2 * (g & 1) + (t16 & 1));
@@ -704,7 +708,9 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
   // k = 33..64 as well (8 steps of 4 MFMAs per chunk, low-piece accumulators, 32x32x16): X^T U of 50000 samples
   // (12.8 MB factor, 4 slices in the 4-wave form) 0.3845 -> 0.3795 ms unsliced in the 8-wave form, iteration 0.8420 ->
   // 0.8325 ms, 7 of 7 interleaved rounds; with 2 slices it is slower than the 4-wave form.
-  if (x_dtype == 1 && NT >= 2 && factor_bytes >= SWEEP_WIDE_SMALL_FACTOR_BYTES) {
+  // f32 X too (three-piece split; hook per 16-column tile): X^T U at the C3 shape 0.777 -> 0.745 ms, the N = 8 share of C5
+  // 0.725 / 0.715 -> 0.711 / 0.705 ms -- unsliced; with the 4 slices of the 4-wave form it had measured equal.
+  if (NT >= 2 && factor_bytes >= SWEEP_WIDE_SMALL_FACTOR_BYTES) {
     p.nw = SWEEP_NW_WIDE;
     p.bdb = true;
   }
@@ -811,11 +817,16 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
       (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, 0, p.ngroups, p.nx, p.pmax, 0, slabs, slab_stride, \
       p.slab_nt ? 1 : 0, g_sweep_stamps, pro)
   if constexpr (NW == 8) {
-    switch (NT) {
-      case 2: PRMF_LAUNCH(2); break;
-      case 3: PRMF_LAUNCH(3); break;
-      case 4: PRMF_LAUNCH(4); break;
-      default: return hipErrorInvalidValue;
+    // bf16 X: k > 32; f32 X: k = 33..64 with 64-row wave tiles, k > 64 with 32-row ones (f32_wave_tiles)
+    constexpr bool K64 = MODE == 1 || MTV == SWEEP_MT, KWIDE = MODE == 1 || MTV == 1;
+    if (NT == 2) {
+      if constexpr (K64) { PRMF_LAUNCH(2); } else return hipErrorInvalidValue;
+    } else if (NT == 3) {
+      if constexpr (KWIDE) { PRMF_LAUNCH(3); } else return hipErrorInvalidValue;
+    } else if (NT == 4) {
+      if constexpr (KWIDE) { PRMF_LAUNCH(4); } else return hipErrorInvalidValue;
+    } else {
+      return hipErrorInvalidValue;
     }
   } else if constexpr (BDB) {
     switch (NT) {
@@ -856,7 +867,12 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
   const int mode = x_dtype == 1 ? 1 : 2;
   if (x_dtype != 1 && !split) return hipErrorInvalidValue;
   if (p.nw == SWEEP_NW_WIDE) {
-    if (mode != 1 || NT < 2 || !p.bdb || p.mt != SWEEP_MT) return hipErrorInvalidValue;
+    if (NT < 2 || !p.bdb) return hipErrorInvalidValue;
+    if (mode == 2) {
+      if (p.mt == 1) return launch_sweep_nt<2, SWEEP_NW_WIDE, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
+      return launch_sweep_nt<2, SWEEP_NW_WIDE, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
+    }
+    if (p.mt != SWEEP_MT) return hipErrorInvalidValue;
     return launch_sweep_nt<1, SWEEP_NW_WIDE, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
   }
   if (p.nw != SWEEP_NW || p.mt != f32_wave_tiles(x_dtype, NT) || p.bdb != (NT <= 2)) return hipErrorInvalidValue;
