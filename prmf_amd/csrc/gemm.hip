@@ -808,10 +808,16 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
   // dynamic LDS only for the 8-wave shape (see the kernel)
   const size_t dyn = NW == 8 ? (size_t)((BDB ? 2 : 1) * (MODE == 1 ? 512 : 256) * NT + NW * MTV * 256) * 16 : 0;
 #define PRMF_LAUNCH(NTV)                                                                                       \
-  if (dyn > 64 * 1024) {                                                                                       \
-    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<MODE, MTV, NTV, NW, BDB>), \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);           \
-    if (ea != hipSuccess) return ea;                                                                           \
+  if (dyn > 64 * 1024) {   /* once per (kernel, device): remembered per column-tile count of this instantiation */ \
+    static int attr_dev[5] = {-1, -1, -1, -1, -1};                                                             \
+    int dev_now = -1;                                                                                          \
+    if (hipGetDevice(&dev_now) != hipSuccess) return hipErrorInvalidDevice;                                    \
+    if (attr_dev[NTV] != dev_now) {                                                                            \
+      const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<MODE, MTV, NTV, NW, BDB>), \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);         \
+      if (ea != hipSuccess) return ea;                                                                         \
+      attr_dev[NTV] = dev_now;                                                                                 \
+    }                                                                                                          \
   }                                                                                                            \
   sweep_kernel<MODE, MTV, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), dyn, s>>>(                                \
       (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, 0, p.ngroups, p.nx, p.pmax, 0, slabs, slab_stride, \
