@@ -352,6 +352,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PRMF_LOADS_FIRST 1
 #endif
 constexpr bool LOADS_FIRST = PRMF_LOADS_FIRST != 0;
+#ifndef PRMF_SKIP_PAD_TILES
+#define PRMF_SKIP_PAD_TILES 1
+#endif
 #ifndef PRMF_SPRINKLE_LPS
 #define PRMF_SPRINKLE_LPS 2     // loads per MFMA step (0: as few as cover the chunk).  2: the 12 loads of a k = 128 chunk leave in the first 6 of
                                 // its 16 steps, so the rest of the chunk covers their latency: 1-2 % ahead of 1 and of 3 per step
@@ -423,6 +426,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   // LDS: the factor chunk (double-buffered if BDB) and one A tile per wave (MT tiles of 32 rows x 128 B).  The 8-wave shape
   // with a double-buffered k = 128 chunk needs 128 KiB: dynamic shared memory there, static arrays everywhere else.
   constexpr bool DYN_LDS = NW == 8;
+  constexpr bool SKIP_PAD_TILES = MODE == 1 && NW == 8 && PRMF_SKIP_PAD_TILES;   // where the registers allow it (232 / 244 at k = 64 / 128)
   constexpr int LDS_B = (BDB ? 2 : 1) * BCH, LDS_A = NW * MT * 256;
   extern __shared__ u32x4 sweep_dyn_lds[];
   __shared__ u32x4 sweep_stat_lds[DYN_LDS ? 1 : LDS_B + LDS_A];
@@ -468,14 +472,14 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   int64_t unit = T * wj / Gx;
   const int64_t unit_end = L > 0 ? T * (wj + 1) / Gx : 0;
 
-  unsigned avoff[MT][4];
+  unsigned avoff0[MT][4];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int lr = 8 * i + (lane >> 3);                           // row within the 32-row tile
       const int piece = (lane & 7) ^ ((lr >> 1) & 7);               // source-side swizzle
-      avoff[mt][i] = (unsigned)(((int64_t)(wave * (32 * MT) + 32 * mt + lr) * lda16 + piece) * 16);
+      avoff0[mt][i] = (unsigned)(((int64_t)(wave * (32 * MT) + 32 * mt + lr) * lda16 + piece) * 16);
     }
   u32x4* const myA = sA[wave];
 
@@ -490,6 +494,19 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   const int nch = UNIT * (g1 - g0);
   const int64_t prow0 = (int64_t)panel * (32 * MT * NW);            // first row of this panel
   const int64_t row0 = prow0 + wave * (32 * MT);                    // first row of this wave
+  // 512-row panels (bf16 X): a 32-row tile that lies entirely in the zero padding behind the matrix (20000 genes are
+  // 39 panels + 32 rows: 15 of the last panel's 16 tiles) does not stream its rows from memory -- all of its lanes read
+  // the panel's last row instead, which is padding too: 128 B per chunk out of the cache.  Same zeros, same arithmetic.
+  unsigned avoff[MT][4];
+  {
+    const unsigned zoff = (unsigned)(((int64_t)(32 * MT * NW - 1) * lda16 + (lane & 7)) * 16);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bool dead = SKIP_PAD_TILES && row0 + 32 * mt >= M_store;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) avoff[mt][i] = dead ? zoff : avoff0[mt][i];
+    }
+  }
 
   // uniform bases (SGPR) + per-lane byte offsets (VGPR, < panel rows * row bytes)
   const uint4* abase = A + prow0 * lda16 + (int64_t)c0 * 8;         // chunk = 8 x 16 B of each row
