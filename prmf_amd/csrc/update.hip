@@ -426,23 +426,25 @@ __device__ __forceinline__ void gram_block_store(const f32x16 (&g)[NT * (NT + 1)
 // 300 registers and one workgroup per CU (or spill).  Here the tile's Gram is formed in fresh accumulators (live only
 // after the update), summed over the 4 waves through LDS in wave order, and added to a running total of 4 floats per
 // 32x32 block per thread (thread (wave, lane) keeps registers i = 4 wave .. 4 wave + 3 of every block).
-// Every wave of the workgroup calls this once per loop round (2 barriers per block).
+// Every wave of the workgroup calls this once per loop round (2 barriers).
 template <int NT>
 __device__ __forceinline__ void gram_round(const f32x16 (&gt)[NT * (NT + 1) / 2], float (&gtot)[NT * (NT + 1) / 2][4],
-                                           float (*red)[16][64], int wave, int lane) {
+                                           float (*red)[16][64] /* [NP][4 waves] blocks of [16][64] */, int wave, int lane) {
+  // one exchange for all NP blocks of the tile (2 barriers per round; it was 2 per block)
   constexpr int NP = NT * (NT + 1) / 2;
 #pragma unroll
-  for (int p = 0; p < NP; ++p) {
+  for (int p = 0; p < NP; ++p)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) red[wave][i][lane] = gt[p][i];
-    __syncthreads();
+    for (int i = 0; i < 16; ++i) red[4 * p + wave][i][lane] = gt[p][i];
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
       const int i = 4 * wave + ii;
-      gtot[p][ii] += ((red[0][i][lane] + red[1][i][lane]) + red[2][i][lane]) + red[3][i][lane];
+      gtot[p][ii] += ((red[4 * p][i][lane] + red[4 * p + 1][i][lane]) + red[4 * p + 2][i][lane]) + red[4 * p + 3][i][lane];
     }
-    __syncthreads();
-  }
+  __syncthreads();
 }
 
 template <int NT>
@@ -475,7 +477,7 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
   constexpr int KP = 32 * NT, NP = NT * (NT + 1) / 2;
   constexpr int COMB = NT <= 2 ? 4 * NT * 16 * 64 : 1;              // cooperative slab sums exist for k <= 64
   __shared__ float Gs[KP * KP];
-  __shared__ float red_store[(GRAM ? 4 * 16 * 64 : 1) > COMB ? (GRAM ? 4 * 16 * 64 : 1) : COMB];   // Gram reduction | slab-sum exchange
+  __shared__ float red_store[(GRAM ? NP * 4 * 16 * 64 : 1) > COMB ? (GRAM ? NP * 4 * 16 * 64 : 1) : COMB];   // Gram exchange (all NP blocks of a tile at once) | slab-sum exchange
   float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(red_store);
   bool first_round = true;
 #define EPI_STAMP(j) do { if (stamps && threadIdx.x == 0 && first_round) stamps[8 * blockIdx.x + (j)] = wall_clock64(); } while (0)
@@ -971,7 +973,7 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
   constexpr int KP = 32 * NT, NP = NT * (NT + 1) / 2;
   constexpr int COMB = (NT <= 2 && !DENSE) ? 4 * NT * 16 * 64 : 1;
   __shared__ float Gs[KP * KP];
-  __shared__ float red_store[(GRAM ? 4 * 16 * 64 : 1) > COMB ? (GRAM ? 4 * 16 * 64 : 1) : COMB];   // Gram reduction | slab-sum exchange
+  __shared__ float red_store[(GRAM ? NP * 4 * 16 * 64 : 1) > COMB ? (GRAM ? NP * 4 * 16 * 64 : 1) : COMB];   // Gram exchange (all NP blocks of a tile at once) | slab-sum exchange
   float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(red_store);
   stage_gram<NT>(Gu, k, 0, k, Gs);
   __syncthreads();
