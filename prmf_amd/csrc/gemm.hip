@@ -14,7 +14,7 @@
 //         block (kb, t, hl) of 1 KiB, kb = k/16, t = 32-column tile, hl = 0 hi / 1 lo;
 //         lane (c = lane&31, h = lane>>5), element e:  B[16 kb + 8 h + e][32 t + c],
 //         split as hi = bf16(v), lo = bf16(v - hi)  (16 mantissa bits)
-//       bf16 X at k > 64 ("W16", round 3) multiplies with v_mfma_f32_16x16x32_bf16 and packs accordingly:
+//       bf16 X at k > 64 and f32 X at k > 32 ("W16", round 3) multiply with v_mfma_f32_16x16x32_bf16 and pack accordingly:
 //         block (g, t16, hl) of 1 KiB, g = k/32, t16 = 16-column tile; lane (c16 = lane&15, kg = lane>>4), element e:
 //         B[32 g + 8 kg + e][16 t16 + c16]
 //       (same bytes per chunk, so the staging is the same).
@@ -24,9 +24,12 @@
 //       store / load instruction); which slabs hold a segment of a row panel is a per-panel bit mask, and the consumer
 //       kernel sums them in slab-index order (deterministic; no atomics).
 //
-// Wave tiling (wave64): a workgroup is 4 waves x 64 rows; each wave owns MT = 2 32-row tiles x NT 32-column tiles of
-// accumulators (v_mfma_f32_32x32x16_bf16 throughout: f32 X is split exactly into three bf16 pieces in registers), so
-// every B fragment read from LDS feeds two MFMAs.
+// Wave tiling (wave64): a workgroup is 4 waves x 64 rows, two per CU -- or ONE workgroup of 8 waves x 64 rows per CU
+// (512-row panels, factor chunk double-buffered, the next chunk's loads issued between the MFMA steps, no reduction
+// slices below 32 MB) when the packed factor is >= 8 MB and k > 32: see plan_gemm.  Each wave owns MT = 2 32-row tiles
+// (1 for f32 X at k <= 32 and k > 64) x NT 32-column tiles of accumulators (v_mfma_f32_32x32x16_bf16 for bf16 X at
+// k <= 64 and f32 X at k <= 32, the 16x16x32 shape otherwise; f32 X is split exactly into three bf16 pieces in
+// registers), so every B fragment read from LDS feeds two MFMAs.
 // A is loaded line-complete (8 rows x 128 B per wave instruction, non-temporal), one chunk ahead of the MFMAs, and
 // bounced through a wave-private XOR-swizzled LDS tile from which the 16-B A fragments are read (see "A path" below:
 // fragment-shaped global loads were 22% slower).  B is staged once per workgroup per chunk through registers into LDS.
