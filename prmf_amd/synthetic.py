@@ -16,6 +16,10 @@ CONFIGS = {
     "c4share2": (25000, 20000, 64, 300, "bf16"),     # ... on 2 GPUs
     "c5share4": (50000, 25000, 128, 1000, "bf16"),    # one rank's share of c5 on 4 GPUs
     "c5share2": (100000, 25000, 128, 1000, "bf16"),   # ... on 2 GPUs
+    # planner corner cases: an 8-wave (512-row panel) sweep over a matrix with very few rows -- X^T of a tall thin X, X of a wide one
+    "tallthin": (40000, 700, 64, 20, "bf16"),       # X^T U: 10 MB factor over 700 rows (2 panels)
+    "tallthin128": (40000, 600, 128, 20, "bf16"),   # the same at k = 128 (20 MB factor)
+    "wideshort": (300, 70000, 64, 50, "bf16"),      # X V: 18 MB factor over 300 rows (1 panel)
     "cli": (500, 20000, 6, 50, "f32"),                # the reference's typical use: samples << genes, default k = 6
 }
 

@@ -118,7 +118,10 @@ def _tile_check(torch, name, got, want, tol_tile):
 
 
 @pytest.mark.parametrize("workload,x_dtype", [("c3", "bf16"), ("c3", "f32"), ("c5shard", "bf16"), ("c5shard", "f32"),
-                                              ("c5", "bf16")])
+                                              ("c5", "bf16"),
+                                              # 8-wave sweeps (factor >= 8 MB) over matrices of one or two 512-row panels
+                                              ("tallthin", "bf16"), ("tallthin", "f32"), ("tallthin128", "bf16"),
+                                              ("wideshort", "bf16"), ("wideshort", "f32")])
 def test_one_iteration_vs_fp64_at_full_size(workload, x_dtype):
     import torch
     eng, Xd, U, V, pathways, active, gamma, delta = _engine(torch, workload, x_dtype, 11)
