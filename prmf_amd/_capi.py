@@ -85,6 +85,7 @@ DEBUG_SIGNATURES = {
     "prmf_debug_set_epi_stamps": (_i, [_vp]),
     "prmf_debug_bump_cursor": (_i, [_vp]),
     "prmf_debug_swap": (_i, [_vp, _vp, _i]),
+    "prmf_debug_plan_sweep": (_i, [_i, C.c_longlong, C.c_longlong, _i, _i, C.POINTER(_i)]),
 }
 
 _lib = None

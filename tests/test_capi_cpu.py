@@ -63,3 +63,46 @@ def test_missing_library_is_an_error(tmp_path):
     from prmf_amd import _capi
     with pytest.raises(_capi.PrmfLibraryError):
         _capi.load(str(tmp_path / "libprmf_hip.so"))
+
+
+def test_sweep_plans_of_the_benchmark_shapes():
+    """The sweep planner is pure host arithmetic (prmf_debug_plan_sweep touches no GPU): pin what it decides for the
+    shapes DESIGN.md section 7 quotes, so that a threshold edit that changes one of them is a deliberate edit.
+    X V is the sweep over X (m rows, depth n), X^T U the one over X^T (n rows, depth m)."""
+    from prmf_amd import _capi
+    lib = _capi.load()
+    BF16, F32 = _capi.PRMF_X_BF16, _capi.PRMF_X_F32
+
+    def plan(xd, rows, depth, k):
+        out = (C.c_int * 8)()
+        assert lib.prmf_debug_plan_sweep(xd, rows, depth, k, 256, out) == _capi.PRMF_OK
+        keys = ("waves", "tiles_per_wave", "panel_rows", "grid", "slices", "max_slabs", "double_buffered", "panels")
+        return dict(zip(keys, list(out)))
+
+    # C3 50000 x 20000, k = 64, bf16: X V (5.1 MB factor) in the 4-wave form, unsliced; X^T U (12.8 MB) in the 8-wave form, unsliced
+    xv, xtu = plan(BF16, 50000, 20000, 64), plan(BF16, 20000, 50000, 64)
+    assert (xv["waves"], xv["panel_rows"], xv["grid"], xv["slices"], xv["panels"]) == (4, 256, 512, 1, 196)
+    assert (xtu["waves"], xtu["panel_rows"], xtu["grid"], xtu["slices"], xtu["panels"]) == (8, 512, 256, 1, 40)
+    # the same shape with f32 X: the same forms (64-row wave tiles at k = 33..64)
+    xv, xtu = plan(F32, 50000, 20000, 64), plan(F32, 20000, 50000, 64)
+    assert (xv["waves"], xv["tiles_per_wave"], xv["slices"]) == (4, 2, 1) and (xtu["waves"], xtu["tiles_per_wave"], xtu["slices"]) == (8, 2, 1)
+    # C5 200000 x 25000, k = 128, bf16: both sweeps 8-wave; X V (12.8 MB) unsliced, X^T U (102 MB) sliced
+    xv, xtu = plan(BF16, 200000, 25000, 128), plan(BF16, 25000, 200000, 128)
+    assert (xv["waves"], xv["slices"], xv["double_buffered"], xv["panels"]) == (8, 1, 1, 391)
+    assert xtu["waves"] == 8 and xtu["slices"] > 1 and xtu["double_buffered"] == 1 and xtu["panels"] == 49
+    # its N = 8 share (25000 x 25000): both 8-wave, unsliced; with f32 X: 32-row wave tiles
+    for p in (plan(BF16, 25000, 25000, 128), plan(F32, 25000, 25000, 128)):
+        assert (p["waves"], p["slices"]) == (8, 1)
+    assert plan(F32, 25000, 25000, 128)["tiles_per_wave"] == 1 and plan(F32, 25000, 25000, 128)["panel_rows"] == 256
+    # C2 5000 x 10000, k = 16, f32: small factors, 4 waves x one 32-row tile, unsliced, double-buffered
+    for p in (plan(F32, 5000, 10000, 16), plan(F32, 10000, 5000, 16)):
+        assert (p["waves"], p["tiles_per_wave"], p["panel_rows"], p["slices"], p["double_buffered"]) == (4, 1, 128, 1, 1)
+    # the N = 8 share of C3 (6250 x 20000): X V's 5.1 MB factor takes two slices there, X^T U (1.6 MB) none
+    assert plan(BF16, 6250, 20000, 64)["slices"] == 2 and plan(BF16, 20000, 6250, 64)["slices"] == 1
+    # a tiny matrix launches few workgroups (at least 8 chunks each) and never more slabs than the 64-bit mask holds
+    tiny = plan(F32, 100, 2000, 6)
+    assert tiny["grid"] <= 16 and tiny["max_slabs"] <= 64
+    # bad arguments
+    out = (C.c_int * 8)()
+    assert lib.prmf_debug_plan_sweep(BF16, 10, 0, 4, 256, out) == _capi.PRMF_ERR_ARG
+    assert lib.prmf_debug_plan_sweep(7, 10, 10, 4, 256, out) == _capi.PRMF_ERR_ARG
