@@ -59,13 +59,17 @@ __device__ __forceinline__ void gram_reduce_job_e(const float* __restrict__ part
 #pragma unroll 1
   for (int j0 = 0; j0 * NSUB < nparts; j0 += 32) {
     float v[32];
+    // BRANCH-FREE: indices are clamped and the values masked afterwards.  Written as `cond ? partial[..] : 0` every load
+    // became its own exec-masked block with a wait for it behind it -- the "32 loads in flight" were 13 dependent memory
+    // round trips per job at C3 (391 parts), 8-10 us in front of every sweep (profiles/r03_gram_partial_layout.txt).
+    const int ec = e < kk2 ? e : kk2 - 1;
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
       const int b = sub + NSUB * (j0 + j);
-      v[j] = (e < kk2 && b < nparts) ? partial[(int64_t)b * kk2 + e] : 0.f;
+      v[j] = partial[(int64_t)(b < nparts ? b : nparts - 1) * kk2 + ec];
     }
 #pragma unroll
-    for (int j = 0; j < 32; ++j) s += (double)v[j];
+    for (int j = 0; j < 32; ++j) s += (e < kk2 && sub + NSUB * (j0 + j) < nparts) ? (double)v[j] : 0.0;
   }
   red[sub * E + el] = s;
   __syncthreads();
@@ -136,8 +140,19 @@ __device__ __forceinline__ void graph_terms_body(const PathwayLibDev& lib, const
 __device__ __forceinline__ void colcross_job(const double* __restrict__ vpartial, int nwaves, int k, int c,
                                              double* __restrict__ colnorm2, double* __restrict__ cross, double* red, int tid) {
   double s = 0.0;
-  if (c <= k)
-    for (int b = tid; b < nwaves; b += 256) s += vpartial[(int64_t)b * (k + 1) + c];
+  if (c <= k) {
+    // 8 rows per thread in flight (clamped, masked; same order of additions as one row at a time)
+    for (int b0 = tid; b0 < nwaves; b0 += 8 * 256) {
+      double v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int b = b0 + 256 * j;
+        v[j] = vpartial[(int64_t)(b < nwaves ? b : nwaves - 1) * (k + 1) + c];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (b0 + 256 * j < nwaves) ? v[j] : 0.0;
+    }
+  }
   s = block_sum_256(s, red, tid);
   if (tid == 0 && c <= k) {
     if (c < k) colnorm2[c] = s;
