@@ -1175,40 +1175,63 @@ v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles_pack; tile += wstride) {
     const int64_t row0 = tile * 32;
     float vn[NT][16];
+    // Everything below is written BRANCH-FREE around its loads (clamped addresses, masked uses): behind a per-element
+    // `if` the compiler gives every load a block of its own with a full wait after it -- this kernel was a chain of up
+    // to 35 (k = 64) / 128 (k = 128) dependent memory round trips per tile.
     if constexpr (STAGED) {
       float* T = stage[wave];
       const int rows_here = row0 < n ? (int)(n - row0 < 32 ? n - row0 : 32) : 0;
       const int run4 = rows_here * kc / 4;                  // float4 per rank block
-      for (int b = 0; b < nblocks_src; ++b) {
-        const float4* src = reinterpret_cast<const float4*>(v_recv + (int64_t)b * blk_stride + row0 * kc);
-        for (int f = lane; f < run4; f += 64) {
-          const float4 x = src[f];
-          const int e = 4 * f, rr = e / kc, cc = e - rr * kc;
-          float* d = T + rr * PITCH + b * kc + cc;
-          d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
-        }
+      const int total4 = nblocks_src * run4;                // <= 8 KP = 64 lanes x 4 NT
+      float4 x[4 * NT];
+      int dst[4 * NT];
+#pragma unroll
+      for (int j = 0; j < 4 * NT; ++j) {
+        const int q = lane + 64 * j;
+        const bool on = q < total4;
+        const int qq = on ? q : 0;
+        const int b = run4 > 0 ? qq / run4 : 0, f = qq - b * run4;
+        const int e = 4 * f, rr = e / kc, cc = e - rr * kc;
+        dst[j] = on ? rr * PITCH + b * kc + cc : -1;
+        x[j] = reinterpret_cast<const float4*>(v_recv + (int64_t)b * blk_stride + (rows_here > 0 ? row0 : 0) * kc)[f];     // tiles past n read row 0 (unused)
       }
+#pragma unroll
+      for (int j = 0; j < 4 * NT; ++j)
+        if (dst[j] >= 0) {
+          float* d = T + dst[j];
+          d[0] = x[j].x; d[1] = x[j].y; d[2] = x[j].z; d[3] = x[j].w;
+        }
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int col = 32 * t + c;
       const int colc = col < k ? col : k - 1;
       const int64_t cb = (int64_t)(colc / kc) * blk_stride + (colc % kc);
+      int ps[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int64_t row = row0 + rr;
-        float v = 0.f;
-        if (row < n && col < k) {
-          if constexpr (STAGED) v = stage[wave][rr * PITCH + col];
-          else v = v_recv[cb + row * kc];
-          V[row * k + col] = v;
-          if (pos_all) {             // V_new on the active supports, for the deferred objective (prmf_end)
-            const int ps = pos_all[row * k + col];
-            if (ps >= 0) vsup[(unsigned)col * (unsigned)max_support + (unsigned)ps] = v;
-          }
+        const int64_t row = row0 + rr, rowc = row < n ? row : n - 1;
+        if constexpr (STAGED) vn[t][i] = stage[wave][rr * PITCH + col];
+        else vn[t][i] = v_recv[cb + rowc * kc];
+        ps[i] = -1;
+      }
+      if (pos_all) {               // uniform: ONE block with the tile column's 16 position loads
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          ps[i] = pos_all[(row < n ? row : n - 1) * k + colc];
         }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const bool valid = row < n && col < k;
+        const float v = valid ? vn[t][i] : 0.f;
         vn[t][i] = v;
+        if (valid) V[row * k + col] = v;
+        // V_new on the active supports, for the deferred objective (prmf_end)
+        if (valid && ps[i] >= 0) vsup[(unsigned)col * (unsigned)max_support + (unsigned)ps[i]] = v;
       }
     }
     if constexpr (GRAM) {
@@ -1444,9 +1467,25 @@ v_update_kernel(const float* __restrict__ V, int64_t n, int k, int col0, int nco
   constexpr int KP = 32 * NT, HALF = KP / 2, OW = 32 * NTO;
   __shared__ float Gs[KP * OW];                  // G[:, col0 .. col0 + ncols), zero beyond
   __shared__ double red[4][OW + 1];
-  for (int i = threadIdx.x; i < KP * OW; i += 256) {
-    const int q = i / OW, oc = i - q * OW;
-    Gs[i] = (q < k && oc < ncols) ? (float)Gu[q * k + col0 + oc] : 0.f;
+  {
+    // loads in batches BEFORE the LDS stores of the batch, indices clamped and values masked (see stage_gram: one load and
+    // one store per loop iteration is a chain of KP OW / 256 dependent L2 round trips)
+    constexpr int PER = KP * OW / 256, B = PER % 16 == 0 ? 16 : (PER % 12 == 0 ? 12 : (PER % 8 == 0 ? 8 : 4));
+    static_assert(PER % B == 0, "whole batches");
+#pragma unroll 1
+    for (int b0 = 0; b0 < PER; b0 += B) {
+      double v[B];
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const int i = (int)threadIdx.x + 256 * (b0 + j);
+        const int q = i / OW, oc = i - q * OW;
+        const bool in = q < k && oc < ncols;
+        v[j] = Gu[in ? q * k + col0 + oc : 0];
+        if (!in) v[j] = 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < B; ++j) Gs[(int)threadIdx.x + 256 * (b0 + j)] = (float)v[j];
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
