@@ -233,6 +233,19 @@ int prmf_end(prmf_ctx* ctx, int n_steps, double* obj_out, double* gamma_delta_ou
 #define PRMF_COMM_ID_BYTES 128
 int prmf_comm_unique_id(void* id_out /* PRMF_COMM_ID_BYTES */);
 int prmf_comm_init(prmf_ctx* ctx, const void* id /* PRMF_COMM_ID_BYTES */);
+/* The number of samples over ALL ranks.  The threshold below which a record's identity-based recon is replaced by the
+ * direct residual (PRMF_RECON_* above) contains min(m, n): every rank has to evaluate it with the same m, or ranks whose
+ * shards differ by a row would raise different flags and enter different collectives.  prmf_comm_init all-reduces the
+ * local counts itself; a caller that drives the collectives (prmf_phase_*) calls this instead.  Unknown (never set,
+ * nranks > 1): the library uses n alone -- rank-invariant as well. */
+int prmf_set_global_rows(prmf_ctx* ctx, int64_t m_global);
+/* Failure behaviour of the in-library collectives.  If an nccl* call fails on this rank, the open RCCL group is closed,
+ * the communicator is ABORTED (ncclCommAbort), the call returns PRMF_ERR_HIP and every later prmf_step_dist on this
+ * context returns PRMF_ERR_STATE: the caller is expected to exit non-zero so that its launcher ends the job.  A rank whose
+ * peer has died is left inside a collective kernel; its wait for the stream (prmf_end inside prmf_step_dist) is therefore
+ * bounded: after `seconds` (default 300; 0 = wait for ever) it aborts its communicator and returns PRMF_ERR_HIP too.  No
+ * call hangs. */
+int prmf_set_comm_timeout(prmf_ctx* ctx, double seconds);
 /* multi-rank prmf_step: same arguments and results (every rank gets the same
  * objective records); requires prmf_comm_init.  Also valid with nranks == 1. */
 int prmf_step_dist(prmf_ctx* ctx, float* dU, float* dV, int n_steps,
@@ -277,7 +290,7 @@ int prmf_quantile_transform(int device, double* dX, int64_t m, int64_t n, int64_
 
 /*
  * Direct reconstruction error of this rank's rows: *out_local = sum_ij (X_g - U_g V^T)_ij^2 over the stored X
- * (float64 sum; X - U V^T formed on the bf16 MFMA with hi/lo-split factors, X exact), what the reference computes at
+ * (float64 sum; X - U V^T formed on the bf16 MFMA with both factors split into three exact bf16 pieces, X exact), what the reference computes at
  * prmf_runner.py:337 before the square root.  One sweep over X; needs prmf_set_x only.  dU (m_local x k), dV (n x k):
  * float32 device buffers.  With nranks > 1 the caller sums *out_local over the ranks.  Synchronises `stream`.
  */

@@ -43,6 +43,19 @@ int prmf_debug_swap(prmf_ctx* a, prmf_ctx* b, int which);
  * reduction slices, slabs per panel (upper bound), factor chunk double-buffered (0 | 1), panels }. */
 int prmf_debug_plan_sweep(int x_dtype, long long rows, long long depth, int k, int n_cus, int* out);
 
+/* Calibration: a pure stream of the resident matrix (which = 0: the padded copy of X, 1: of X^T) -- one workgroup per
+ * resident slot of the sweep, every wave instruction 1 KiB contiguous, 8 non-temporal loads in flight per lane: the
+ * sweep's loads without its LDS bounce, factor and MFMAs.  One warm-up launch, then `reps` launches between two HIP
+ * events on `stream`; *ms_out = average launch time, *bytes_out (nullable) = bytes read per launch.  bench.py reports the
+ * sweep's rate as a fraction of this one (`roofline.frac_of_stream`), which separates the kernel from the box it ran on.
+ * Synchronises `stream`. */
+int prmf_debug_stream(prmf_ctx* ctx, int which, int reps, double* ms_out, int64_t* bytes_out, void* stream);
+
+/* The library's bounded wait for a stream that may carry collectives (prmf_set_comm_timeout), callable on its own:
+ * PRMF_OK when the stream has drained, PRMF_ERR_HIP (and the communicator aborted) when the time limit passed first.
+ * tests/test_gpu_eightway.py drives the timeout path with it. */
+int prmf_debug_sync_stream(prmf_ctx* ctx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,22 @@ class Pathway(object):
         return Ln
 
 
+    def L_normal_rebuilt(self):
+        """normalize_laplacian as the reference RUNS it, every iteration, for every latent factor
+        (prmf_runner.py:56-65, called at :349): one sparse element access L[ind, ind] per support index in a
+        Python loop, a dia_matrix with setdiag, two sparse products.  Same matrix as L_normal(); kept separate
+        because its cost is part of the reference's iteration (bench.py's `rebuild_laplacians` baseline)."""
+        L = self.L
+        D_to_minus_half = sp.dia_matrix(L.shape)
+        values = np.zeros(L.shape[0])
+        for ind in self.support:
+            v = L[ind, ind]
+            if v != 0:
+                values[ind] = v ** (-1 / 2)
+        D_to_minus_half.setdiag(values)
+        return D_to_minus_half.dot(L.dot(D_to_minus_half))
+
+
 def pathway_from_edges(n, edges, nodes, weights=None):
     """Build a Pathway from an undirected edge list over nodelist indices.
 
@@ -129,20 +145,22 @@ def pathway_from_graph(G, nodelist, node_to_index=None):
 # --------------------------------------------------------------------------
 # objective  (prmf_runner.py:336-372)
 # --------------------------------------------------------------------------
-def objective_graph_terms(V, active):
+def objective_graph_terms(V, active, rebuild_laplacians=False):
     """manifold = sum_k vhat_k^T Lhat_k vhat_k ; ignore = sum_k sum_{i in S_k} 1/(vhat_ik + 1)
-    with vhat_k = V[:,k]/||V[:,k]||  (prmf_runner.py:344-352)."""
+    with vhat_k = V[:,k]/||V[:,k]||  (prmf_runner.py:344-352).  rebuild_laplacians: normalise every Laplacian
+    anew as the reference does at :349 (same numbers, the reference's cost)."""
     manifold = 0.0
     ignore = 0.0
     for k, pw in enumerate(active):
         v = V[:, k]
         vhat = v / np.linalg.norm(v)
-        manifold += pw.L_normal().dot(vhat).dot(vhat)
+        Ln = pw.L_normal_rebuilt() if rebuild_laplacians else pw.L_normal()
+        manifold += Ln.dot(vhat).dot(vhat)
         ignore += np.sum(1.0 / (vhat[pw.support] + 1.0))
     return manifold, ignore
 
 
-def nmf_manifold_vec_obj(X, U, V, active, gamma=1.0, delta=1.0, lean=False, norm_X_sq=None):
+def nmf_manifold_vec_obj(X, U, V, active, gamma=1.0, delta=1.0, lean=False, norm_X_sq=None, rebuild_laplacians=False):
     """Objective record of prmf_runner.py:336-372.
 
     faithful (lean=False): recon = ||X - U V^T||_F on the materialised residual
@@ -157,7 +175,7 @@ def nmf_manifold_vec_obj(X, U, V, active, gamma=1.0, delta=1.0, lean=False, norm
         recon = math.sqrt(max(norm_X_sq - 2.0 * cross + gg, 0.0))
     else:
         recon = np.linalg.norm(X - U.dot(V.T))
-    manifold, ignore = objective_graph_terms(V, active)
+    manifold, ignore = objective_graph_terms(V, active, rebuild_laplacians)
     fro = np.sum(np.multiply(U, U))
     obj = recon + gamma * manifold + delta * ignore + fro
     return {"recon": recon, "manifold": manifold, "ignore": ignore, "fro": fro,
@@ -198,7 +216,7 @@ def update_step(X, U, V, active, gamma, delta):
 
 
 def nmf_manifold_vec_update(X, U, V, active, n_steps=10, gamma=1.0, delta=1.0,
-                            trace=None, lean=False, norm_X_sq=None):
+                            trace=None, lean=False, norm_X_sq=None, rebuild_laplacians=False):
     """prmf_runner.py:374-451.  `active[k]` is the Pathway of latent column k
     (the reference passes k_to_W / k_to_D / k_to_L / k_to_feat_inds dicts).
     If `trace` is a list, the per-step objective records are appended to it
@@ -206,7 +224,8 @@ def nmf_manifold_vec_update(X, U, V, active, n_steps=10, gamma=1.0, delta=1.0,
     obj_data = None
     for _ in range(n_steps):
         U, V = update_step(X, U, V, active, gamma, delta)
-        obj_data = nmf_manifold_vec_obj(X, U, V, active, gamma, delta, lean=lean, norm_X_sq=norm_X_sq)
+        obj_data = nmf_manifold_vec_obj(X, U, V, active, gamma, delta, lean=lean, norm_X_sq=norm_X_sq,
+                                        rebuild_laplacians=rebuild_laplacians)
         if trace is not None:
             trace.append(obj_data)
     return U, V, obj_data

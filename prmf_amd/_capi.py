@@ -67,6 +67,8 @@ SIGNATURES = {
     "prmf_comm_unique_id": (_i, [_vp]),
     "prmf_comm_init": (_i, [_vp, _vp]),
     "prmf_step_dist": (_i, [_vp, _vp, _vp, _i, _d, _d, _d, _vp, _vp, _vp]),
+    "prmf_set_global_rows": (_i, [_vp, _i64]),
+    "prmf_set_comm_timeout": (_i, [_vp, _d]),
     "prmf_score_candidates": (_i, [_vp, _vp, _vp, _vp]),
     "prmf_cv_error": (_i, [_vp, _vp, _vp, _vp]),
     "prmf_residual_sq": (_i, [_vp, _vp, _vp, C.POINTER(_d), _vp]),
@@ -86,6 +88,8 @@ DEBUG_SIGNATURES = {
     "prmf_debug_bump_cursor": (_i, [_vp]),
     "prmf_debug_swap": (_i, [_vp, _vp, _i]),
     "prmf_debug_plan_sweep": (_i, [_i, C.c_longlong, C.c_longlong, _i, _i, C.POINTER(_i)]),
+    "prmf_debug_stream": (_i, [_vp, _i, _i, C.POINTER(_d), C.POINTER(_i64), _vp]),
+    "prmf_debug_sync_stream": (_i, [_vp, _vp]),
 }
 
 _lib = None

@@ -7,12 +7,14 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -35,6 +37,7 @@ struct prmf_ctx {
   bool split_f32 = false;             // f32 X multiplied as three bf16 pieces on the bf16 MFMA (see prmf_create)
   bool w16 = false;                   // packed factors in the fragment order of the 16x16x32 MFMA (bf16 X, k > 64: gemm.hip)
   int nranks = 1, rank = 0;
+  int64_t m_global = -1;              // samples over all ranks (prmf_comm_init all-reduces it, or prmf_set_global_rows); -1: unknown
   // Layout ranks: how many column blocks the V update is split into.  Column-sharded mode (default for nranks > 1):
   // lr = nranks (each rank updates kc = ceil(k / nranks) columns; reduce-scatter of Q, all-gather of V).  Replicated mode
   // (PRMF_FLAG_REPLICATED): lr = 1 -- every rank updates all of V from the all-reduced Q with the single-rank fused
@@ -136,6 +139,8 @@ struct prmf_ctx {
 
   // RCCL (resolved at run time, see prmf_comm_init)
   ncclComm_t comm = nullptr;
+  bool comm_broken = false;           // a collective failed or timed out: the communicator was aborted (comm_fail)
+  double comm_timeout_s = 300.0;      // multi-rank: how long a stream synchronisation may wait for a collective (prmf_set_comm_timeout)
 
   // direct residual (residual.hip): device request flag, per-wave partials, the (all-reduced) sum
   int n_cus = 256;
@@ -166,6 +171,7 @@ struct RcclApi {
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;     // optional
   ncclResult_t (*GroupStart)() = nullptr;                             // optional: without them the two exchanges after
   ncclResult_t (*GroupEnd)() = nullptr;                               //   phase_q are two launches instead of one
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                    // optional: after a failed collective (comm_fail)
   bool ok = false;
 };
 RcclApi& rccl() {
@@ -189,6 +195,7 @@ RcclApi& rccl() {
     PRMF_SYM(CommUserRank, "ncclCommUserRank");
     PRMF_SYM(GroupStart, "ncclGroupStart");
     PRMF_SYM(GroupEnd, "ncclGroupEnd");
+    PRMF_SYM(CommAbort, "ncclCommAbort");
 #undef PRMF_SYM
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.ReduceScatter && a.AllGather && a.GetErrorString;
     return a;
@@ -216,9 +223,20 @@ int dev_alloc(prmf_ctx* c, T** p, size_t count, bool zero = true) {
   hipError_t e = hipMalloc((void**)p, bytes);
   if (e != hipSuccess) return fail(c, PRMF_ERR_HIP, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
   if (zero) {
+    // hipMemset runs on the NULL stream and need not have finished when it returns; the caller's stream may be a
+    // non-blocking one (torch's side streams; one per rank thread), which the null stream is not ordered with: without
+    // the wait a kernel of the caller's stream could write the buffer first and be zeroed afterwards
     e = hipMemset(*p, 0, bytes);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) return fail(c, PRMF_ERR_HIP, "hipMemset: %s", hipGetErrorString(e));
   }
+  return PRMF_OK;
+}
+
+// Setup copies (hipMemcpy from pageable host memory, null stream) may return before the DMA has reached the device;
+// nothing the caller's stream launches afterwards may overtake them.
+int null_stream_done(prmf_ctx* c) {
+  HIP_TRY(c, hipStreamSynchronize(nullptr));
   return PRMF_OK;
 }
 
@@ -339,11 +357,46 @@ SweepPrologue mid_prologue(prmf_ctx* c, int it) {
   return p;
 }
 
-#define NCCL_TRY(ctx, expr)                                                                          \
-  do {                                                                                               \
-    ncclResult_t _r = (expr);                                                                        \
-    if (_r != ncclSuccess) return fail(ctx, PRMF_ERR_HIP, "%s: %s", #expr, rccl().GetErrorString(_r)); \
+// A collective failed on this rank (or the stream did not come back from one in time): this rank's peers may be inside
+// the same collective waiting for it.  The communicator is aborted -- ncclCommAbort releases what it holds and, with the
+// test double, wakes the peers -- and the context refuses further multi-rank steps; the caller gets PRMF_ERR_HIP and is
+// expected to end the process non-zero so that the launcher ends the job (with RCCL a peer's kernel can only be ended that
+// way; the peers' own stream timeouts, sync_stream below, turn their wait into the same error).
+int comm_fail(prmf_ctx* c, const char* what, const char* why) {
+  if (c->comm) {
+    if (rccl().CommAbort) (void)rccl().CommAbort(c->comm);
+    else (void)rccl().CommDestroy(c->comm);
+  }
+  c->comm = nullptr;
+  c->comm_broken = true;
+  c->batch_open = false;
+  return fail(c, PRMF_ERR_HIP, "%s: %s (rank %d of %d; the communicator was aborted)", what, why, c->rank, c->nranks);
+}
+
+#define NCCL_TRY(ctx, expr)                                                       \
+  do {                                                                            \
+    ncclResult_t _r = (expr);                                                     \
+    if (_r != ncclSuccess) return comm_fail(ctx, #expr, rccl().GetErrorString(_r)); \
   } while (0)
+
+// hipStreamSynchronize for a stream that may carry collectives: with several ranks the wait is bounded
+// (c->comm_timeout_s) -- a peer that died leaves this rank's collective kernel spinning for ever, and a library call
+// must not hang with it.  One rank: the plain call.
+int sync_stream(prmf_ctx* c, hipStream_t s) {
+  if (c->nranks == 1 || !c->comm || !(c->comm_timeout_s > 0.0)) {
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return PRMF_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return PRMF_OK;
+    if (e != hipErrorNotReady) return fail(c, PRMF_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(e));
+    if (spins > 20000) std::this_thread::sleep_for(std::chrono::microseconds(50));      // a batch normally ends within the spin
+    if ((spins & 255) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->comm_timeout_s)
+      return comm_fail(c, "stream synchronisation", "timed out waiting for a collective -- a peer rank may have failed");
+  }
+}
 
 // Can this context replace a record's identity-based recon by the direct residual?  One rank: always.  Several ranks:
 // the local sums have to be added up, which the library can only do itself (RCCL communicator, inside prmf_step_dist).
@@ -357,8 +410,11 @@ bool direct_forced(const prmf_ctx* c) { return (c->flags & PRMF_FLAG_DIRECT_RESI
 // recon^2 (identity) below this value is too small to trust: kernels.h RECON_DIRECT_THRESHOLD*
 // plus the part of the error that comes from the 16-bit packed factors: it averages over the min(m, n) k entries of the
 // smaller factor only (2.6e-7 ||X||^2 measured at 100 x 1000, k = 6: profiles/r03_recon_identity_terms.txt)
+// Several ranks: the GLOBAL sample count (every rank must raise the same flags and take the same collectives: shard sizes
+// differ by one when nranks does not divide m, and a rank may hold no rows at all); unknown -> the gene count alone.
 double direct_below(const prmf_ctx* c) {
-  const double entries = (double)(c->m < c->n ? (c->m > 0 ? c->m : 1) : c->n) * c->k;
+  const int64_t m_all = c->nranks == 1 ? c->m : (c->m_global >= 0 ? c->m_global : c->n);
+  const double entries = (double)(m_all < c->n ? (m_all > 0 ? m_all : 1) : c->n) * c->k;
   return ((c->NT <= 2 ? RECON_DIRECT_THRESHOLD_LO : RECON_DIRECT_THRESHOLD) + RECON_DIRECT_FACTOR_TERM / std::sqrt(entries)) * c->norm_x_sq;
 }
 
@@ -460,6 +516,12 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   c->split_f32 = x_dtype == PRMF_X_F32;
   c->pack_dtype = c->split_f32 ? PRMF_X_BF16 : x_dtype;
   c->w16 = c->NT > 2 || (x_dtype == PRMF_X_F32 && c->NT == 2);    // gemm.hip SweepW16
+  // the 8-wave sweeps need more than 64 KiB of dynamic LDS: raised once per context (= per device), no state in the launcher
+  if (launch_gemm(x_dtype, c->plan_xv, nullptr, 0, 0, nullptr, c->NT, nullptr, 0, nullptr, c->split_f32, nullptr, true) != hipSuccess ||
+      launch_gemm(x_dtype, c->plan_xtu, nullptr, 0, 0, nullptr, c->NT, nullptr, 0, nullptr, c->split_f32, nullptr, true) != hipSuccess) {
+    fail(c, PRMF_ERR_HIP, "hipFuncSetAttribute(sweep kernel, dynamic LDS) failed");
+    return bail(PRMF_ERR_HIP);
+  }
   // slabs are written as whole 32-row tiles of whole panels (fragment order, no row masking)
   c->slab_stride_p = (int64_t)c->plan_xv.panels * c->plan_xv.panel_rows * c->KP;
   c->slab_stride_q = (int64_t)c->plan_xtu.panels * c->plan_xtu.panel_rows * c->KP;
@@ -510,6 +572,7 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
     return bail(PRMF_ERR_HIP);
   }
   if ((flags & PRMF_FLAG_TIMING) && (rc = prmf_set_timing(c, 1))) return bail(rc);
+  if ((rc = null_stream_done(c))) return bail(rc);
   *out = c;
   return PRMF_OK;
 }
@@ -675,6 +738,7 @@ int prmf_set_pathway_library(prmf_ctx* c, int P, const int64_t* sup_ptr, const i
   c->obj_scratch_all = c->obj_scratch;
   if (c->kc != c->k && (rc = dev_alloc(c, &c->obj_scratch_all, (size_t)c->k * max_sup))) return rc;
   if ((rc = dev_alloc(c, &c->vsup_ring, (size_t)MAX_RECORDS * c->k * max_sup))) return rc;
+  if ((rc = null_stream_done(c))) return rc;
   c->have_lib = true;
   return PRMF_OK;
 }
@@ -952,9 +1016,10 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
                               (size_t)n_steps * PRMF_OBJ_STRIDE * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipMemcpyAsync(c->hyper_host, c->hyper, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
   if (lazy_direct) HIP_TRY(c, hipMemcpyAsync(c->need_host, c->need_dev, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipStreamSynchronize(s));
+  if ((rc = sync_stream(c, s))) return rc;
   // The last record of the batch is the one the outer loop acts on: if its identity-based recon^2 was too small to trust
-  // (the record kernel raised the flag -- identically on every rank), the direct residual is evaluated now and that
+  // (the record kernel raised the flag -- identically on every rank: the records are computed from all-reduced / replicated
+  // quantities and the threshold from global sizes, direct_below), the direct residual is evaluated now and that
   // record is fetched again.  The common case costs nothing: no launch, no second synchronisation.
   if (lazy_direct && c->need_host[0] != 0) {
     double* last = c->records + (size_t)(c->cursor - 1) * PRMF_OBJ_STRIDE;
@@ -962,7 +1027,7 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
     if (n_steps > 0)
       HIP_TRY(c, hipMemcpyAsync(c->records_host + (size_t)(n_steps - 1) * PRMF_OBJ_STRIDE, last, PRMF_OBJ_STRIDE * sizeof(double),
                                 hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    if ((rc = sync_stream(c, s))) return rc;
   }
   if ((c->flags & PRMF_FLAG_TIMING) && c->m > 0) {
     c->ms_xv = c->ms_xtu = 0;
@@ -1037,17 +1102,42 @@ int prmf_comm_init(prmf_ctx* c, const void* id_in) {
   if ((rc = set_device(c))) return rc;
   ncclUniqueId id;
   std::memcpy(&id, id_in, sizeof id);
+  if (c->comm_broken) return fail(c, PRMF_ERR_STATE, "this context's communicator was aborted after a failed collective; create a new context");
   ncclResult_t r = rccl().CommInitRank(&c->comm, c->nranks, id, c->rank);
   if (r != ncclSuccess) {
     c->comm = nullptr;
     return fail(c, PRMF_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", c->rank, c->nranks, rccl().GetErrorString(r));
   }
+  // the global sample count, once: the direct-residual threshold (direct_below) must be the same number on every rank
+  if (c->nranks > 1) {
+    const double mine = (double)c->m;
+    HIP_TRY(c, hipMemcpy(c->resid_sq + 1, &mine, sizeof(double), hipMemcpyHostToDevice));
+    NCCL_TRY(c, rccl().AllReduce(c->resid_sq + 1, c->resid_sq + 1, 1, ncclFloat64, ncclSum, c->comm, (hipStream_t) nullptr));
+    if ((rc = sync_stream(c, (hipStream_t) nullptr))) return rc;
+    double all = 0.0;
+    HIP_TRY(c, hipMemcpy(&all, c->resid_sq + 1, sizeof(double), hipMemcpyDeviceToHost));
+    c->m_global = (int64_t)(all + 0.5);
+  }
+  return PRMF_OK;
+}
+
+int prmf_set_global_rows(prmf_ctx* c, int64_t m_global) {
+  if (!c) return PRMF_ERR_ARG;
+  if (m_global < c->m) return fail(c, PRMF_ERR_ARG, "m_global=%lld < this rank's %lld rows", (long long)m_global, (long long)c->m);
+  c->m_global = m_global;
+  return PRMF_OK;
+}
+
+int prmf_set_comm_timeout(prmf_ctx* c, double seconds) {
+  if (!c || !(seconds >= 0.0)) return PRMF_ERR_ARG;
+  c->comm_timeout_s = seconds;
   return PRMF_OK;
 }
 
 int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma, double delta, double tradeoff,
                    double* obj_out, double* gamma_delta_out, void* stream) {
   if (!c) return PRMF_ERR_ARG;
+  if (c->comm_broken) return fail(c, PRMF_ERR_STATE, "the communicator was aborted after a failed collective (rank %d); create a new context", c->rank);
   if (!c->comm) return fail(c, PRMF_ERR_STATE, "prmf_comm_init has not been called");
   if (n_steps < 0) return fail(c, PRMF_ERR_ARG, "n_steps < 0");
   hipStream_t s = (hipStream_t)stream;
@@ -1074,13 +1164,31 @@ int prmf_step_dist(prmf_ctx* c, float* dU, float* dV, int n_steps, double gamma,
       // or all-reduce in place in the replicated mode.  The latency-bound 32 KB message rides with the bandwidth-bound
       // one instead of waiting on a side stream for the persistent sweep grid to leave it a CU
       // (profiles/r03_side_stream_cosched.txt).
-      if (grouped) NCCL_TRY(c, N.GroupStart());
-      NCCL_TRY(c, N.AllReduce(c->gram_buf, c->gram_buf, (size_t)c->k * c->k, ncclFloat64, ncclSum, c->comm, s));
-      if (c->replicated)
-        NCCL_TRY(c, N.AllReduce(c->q_send, c->q_send, (size_t)c->n * c->k, ncclFloat32, ncclSum, c->comm, s));
-      else if (c->nranks > 1 || c->q_recv != c->q_send)
-        NCCL_TRY(c, N.ReduceScatter(c->q_send, c->q_recv, (size_t)c->n * c->kc, ncclFloat32, ncclSum, c->comm, s));
-      if (grouped) NCCL_TRY(c, N.GroupEnd());
+      // A member that fails must not leave the group open (ncclGroupEnd is still called) before the communicator is aborted.
+      {
+        const char* what = "ncclGroupStart";
+        ncclResult_t r = grouped ? N.GroupStart() : ncclSuccess;
+        const bool opened = grouped && r == ncclSuccess;
+        if (r == ncclSuccess) {
+          what = "ncclAllReduce(U^T U)";
+          r = N.AllReduce(c->gram_buf, c->gram_buf, (size_t)c->k * c->k, ncclFloat64, ncclSum, c->comm, s);
+        }
+        if (r == ncclSuccess && c->replicated) {
+          what = "ncclAllReduce(X^T U)";
+          r = N.AllReduce(c->q_send, c->q_send, (size_t)c->n * c->k, ncclFloat32, ncclSum, c->comm, s);
+        } else if (r == ncclSuccess && (c->nranks > 1 || c->q_recv != c->q_send)) {
+          what = "ncclReduceScatter(X^T U)";
+          r = N.ReduceScatter(c->q_send, c->q_recv, (size_t)c->n * c->kc, ncclFloat32, ncclSum, c->comm, s);
+        }
+        if (opened) {
+          const ncclResult_t re = N.GroupEnd();
+          if (r == ncclSuccess && re != ncclSuccess) {
+            what = "ncclGroupEnd";
+            r = re;
+          }
+        }
+        if (r != ncclSuccess) return comm_fail(c, what, N.GetErrorString(r));
+      }
       if (ptime) HIP_TRY(c, hipEventRecord(c->ev_phase[pe + 2], s));
       if ((rc = prmf_phase_v(c, stream))) return rc;
       // Exchange 2 (column-sharded mode): all-gather of the updated own columns (+ their sums in the tail)
@@ -1241,6 +1349,39 @@ int prmf_quantile_transform(int device, double* dX, int64_t m, int64_t n, int64_
   (void)hipFree(drows);
   if (e != hipSuccess) return fail(nullptr, PRMF_ERR_HIP, "prmf_quantile_transform: %s", hipGetErrorString(e));
   return PRMF_OK;
+}
+
+int prmf_debug_stream(prmf_ctx* c, int which, int reps, double* ms_out, int64_t* bytes_out, void* stream) {
+  if (!c || (which != 0 && which != 1) || reps < 1 || !ms_out) return PRMF_ERR_ARG;
+  if (!c->have_x) return fail(c, PRMF_ERR_STATE, "prmf_set_x has not been called");
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const void* p = which == 0 ? c->X : c->XT;
+  const size_t bytes = which == 0 ? c->x_bytes : c->xt_bytes;
+  hipEvent_t a = nullptr, b = nullptr;
+  HIP_TRY(c, hipEventCreate(&a));
+  HIP_TRY(c, hipEventCreate(&b));
+  hipError_t e = launch_stream_read(p, bytes, c->n_cus, c->resid_partial, s);      // warm-up (code object, clocks)
+  if (e == hipSuccess) e = hipEventRecord(a, s);
+  for (int r = 0; r < reps && e == hipSuccess; ++r) e = launch_stream_read(p, bytes, c->n_cus, c->resid_partial, s);
+  if (e == hipSuccess) e = hipEventRecord(b, s);
+  if (e == hipSuccess) e = hipEventSynchronize(b);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  if (e != hipSuccess) return fail(c, PRMF_ERR_HIP, "prmf_debug_stream: %s", hipGetErrorString(e));
+  *ms_out = (double)ms / reps;
+  if (bytes_out) *bytes_out = (int64_t)bytes;
+  return PRMF_OK;
+}
+
+int prmf_debug_sync_stream(prmf_ctx* c, void* stream) {
+  if (!c) return PRMF_ERR_ARG;
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  return sync_stream(c, (hipStream_t)stream);
 }
 
 int prmf_debug_bump_cursor(prmf_ctx* c) {

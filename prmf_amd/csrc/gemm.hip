@@ -824,20 +824,15 @@ unsigned long long* g_sweep_stamps = nullptr;   // debug: per-workgroup start/en
 
 template <int MODE, int NW, bool BDB, int MTV>
 static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda16, int64_t M_store, const void* Bp,
-                                  int NT, float* slabs, int64_t slab_stride, hipStream_t s, const SweepPrologue& pro) {
-  // dynamic LDS only for the 8-wave shape (see the kernel)
+                                  int NT, float* slabs, int64_t slab_stride, hipStream_t s, const SweepPrologue& pro, bool attr_only) {
+  // dynamic LDS only for the 8-wave shape (see the kernel).  More than 64 KiB of it needs the function attribute raised
+  // on the device once: prmf_create does that for the context's two plans (attr_only) -- no state is kept here.
   const size_t dyn = NW == 8 ? (size_t)((BDB ? 2 : 1) * (MODE == 1 ? 512 : 256) * NT + NW * MTV * 256) * 16 : 0;
 #define PRMF_LAUNCH(NTV)                                                                                       \
-  if (dyn > 64 * 1024) {   /* once per (kernel, device): remembered per column-tile count of this instantiation */ \
-    static int attr_dev[5] = {-1, -1, -1, -1, -1};                                                             \
-    int dev_now = -1;                                                                                          \
-    if (hipGetDevice(&dev_now) != hipSuccess) return hipErrorInvalidDevice;                                    \
-    if (attr_dev[NTV] != dev_now) {                                                                            \
-      const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<MODE, MTV, NTV, NW, BDB>), \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);         \
-      if (ea != hipSuccess) return ea;                                                                         \
-      attr_dev[NTV] = dev_now;                                                                                 \
-    }                                                                                                          \
+  if (attr_only) {                                                                                             \
+    if (dyn <= 64 * 1024) return hipSuccess;                                                                   \
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<MODE, MTV, NTV, NW, BDB>),           \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                          \
   }                                                                                                            \
   sweep_kernel<MODE, MTV, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), dyn, s>>>(                                \
       (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, 0, p.ngroups, p.nx, p.pmax, 0, slabs, slab_stride, \
@@ -873,11 +868,11 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
 
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
                        const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s, bool split,
-                       const SweepPrologue* prologue) {
+                       const SweepPrologue* prologue, bool attr_only) {
   const int64_t lda16 = lda * elem_bytes(x_dtype) / 16;
   SweepPrologue pro = prologue ? *prologue : SweepPrologue{};
   if (pro.kind != PROLOGUE_NONE && pro.nparts > GRAM_MAX_PARTS) return hipErrorInvalidValue;
-  if (pro.kind != PROLOGUE_NONE) {
+  if (pro.kind != PROLOGUE_NONE && !attr_only) {
     // The prologue's jobs (k^2 / 8 Gram entries + k + 1 column sums) are dealt over the sweep's workgroups.  A small
     // matrix launches few of them (one for 100 x 2000): at k = 64 its 512 jobs then ran one after the other -- 0.79 ms
     // in front of a 10 us sweep (tools/shape_scan.py).  More than 4 jobs per workgroup: a launch of their own.
@@ -895,20 +890,20 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
   if (p.nw == SWEEP_NW_WIDE) {
     if (NT < 2 || !p.bdb) return hipErrorInvalidValue;
     if (mode == 2) {
-      if (p.mt == 1) return launch_sweep_nt<2, SWEEP_NW_WIDE, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
-      return launch_sweep_nt<2, SWEEP_NW_WIDE, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
+      if (p.mt == 1) return launch_sweep_nt<2, SWEEP_NW_WIDE, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro, attr_only);
+      return launch_sweep_nt<2, SWEEP_NW_WIDE, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro, attr_only);
     }
     if (p.mt != SWEEP_MT) return hipErrorInvalidValue;
-    return launch_sweep_nt<1, SWEEP_NW_WIDE, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
+    return launch_sweep_nt<1, SWEEP_NW_WIDE, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro, attr_only);
   }
   if (p.nw != SWEEP_NW || p.mt != f32_wave_tiles(x_dtype, NT) || p.bdb != (NT <= 2)) return hipErrorInvalidValue;
   if (NT <= 2) {
-    if (mode == 1) return launch_sweep_nt<1, SWEEP_NW, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
-    if (p.mt == 1) return launch_sweep_nt<2, SWEEP_NW, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
-    return launch_sweep_nt<2, SWEEP_NW, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
+    if (mode == 1) return launch_sweep_nt<1, SWEEP_NW, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro, attr_only);
+    if (p.mt == 1) return launch_sweep_nt<2, SWEEP_NW, true, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro, attr_only);
+    return launch_sweep_nt<2, SWEEP_NW, true, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro, attr_only);
   }
-  if (mode == 1) return launch_sweep_nt<1, SWEEP_NW, false, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
-  return launch_sweep_nt<2, SWEEP_NW, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro);
+  if (mode == 1) return launch_sweep_nt<1, SWEEP_NW, false, SWEEP_MT>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro, attr_only);
+  return launch_sweep_nt<2, SWEEP_NW, false, 1>(p, A, lda16, M_store, packedB, NT, slabs, slab_stride, s, pro, attr_only);
 }
 
 // the prologue work without a sweep behind it (end of a batch)
@@ -925,6 +920,36 @@ hipError_t launch_prologue_alone(const SweepPrologue& p, hipStream_t s) {
   const int extra = p.kind == PROLOGUE_POST ? p.k + 1 : 0;
   if (jobs < extra) jobs = extra;
   prologue_alone_kernel<<<jobs, 256, 0, s>>>(p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// calibration: a pure stream of the resident matrix (prmf_debug_stream; bench.py's `roofline.stream_gbs`)
+// ---------------------------------------------------------------------------
+// What this box delivers for the sweep's bytes with nothing else going on: one workgroup per resident slot of the
+// sweep (2 per CU x 256 threads), each a contiguous share, every wave instruction 1 KiB contiguous (16 B per lane),
+// 8 non-temporal loads in flight per lane -- the loads of the sweep without its LDS bounce, factor and MFMAs.  The sweep's
+// rate divided by this one separates the kernel from the box (boxes of the pool differ by up to 8%).
+__global__ void __launch_bounds__(256) stream_read_kernel(const u32x4* __restrict__ src, size_t n16, unsigned* __restrict__ sink) {
+  const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
+  const size_t lo = per * blockIdx.x, hi = lo + per < n16 ? lo + per : n16;
+  unsigned acc = 0;
+  for (size_t base = lo; base < hi; base += 256 * 8) {
+    u32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const size_t i = base + (size_t)j * 256 + threadIdx.x;
+      v[j] = __builtin_nontemporal_load(src + (i < hi ? i : lo));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += v[j][0] ^ v[j][1] ^ v[j][2] ^ v[j][3];
+  }
+  if (acc == 0x12345678u && lo > hi) sink[blockIdx.x] = acc;   // never true: keeps the loads alive
+}
+
+hipError_t launch_stream_read(const void* p, size_t bytes, int n_cus, void* sink, hipStream_t s) {
+  if (!p || bytes < 16) return hipSuccess;
+  stream_read_kernel<<<dim3(2 * n_cus), 256, 0, s>>>((const u32x4*)p, bytes / 16, (unsigned*)sink);
   return hipGetLastError();
 }
 

@@ -134,7 +134,9 @@ extern unsigned long long* g_epi_stamps;     // debug only (column-split epilogu
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
                        const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s,
                        bool split = false /* f32 X as three bf16 pieces, packedB in the bf16 hi/lo layout */,
-                       const SweepPrologue* prologue = nullptr /* runs inside the sweep when its jobs fit the grid, else as a launch of its own */);
+                       const SweepPrologue* prologue = nullptr /* runs inside the sweep when its jobs fit the grid, else as a launch of its own */,
+                       bool attr_only = false /* launch nothing: raise the kernel's dynamic-LDS limit on the current device (prmf_create) */);
+hipError_t launch_stream_read(const void* p, size_t bytes, int n_cus, void* sink /* >= 2 n_cus ints, never written */, hipStream_t s);
 // Pathway terms of the V update as extra workgroups of the U epilogue launch (they depend on the OLD V and gamma / delta
 // only; the epilogue leaves a quarter of the chip's slots idle and runs longer than the terms' dependent-load chain, so
 // they cost nothing there -- as a prologue of the X^T U sweep they delayed k of its workgroups by 6-9 us).  ncols = 0: none.

@@ -31,78 +31,58 @@ the math of each phase is the same lines split by rows of X / columns of V.
 `engine` is anything with the phase interface of prmf_amd.solver.PrmfEngine
 (comm_buffers/begin/phase_*/end); tests drive this module over gloo with a
 CPU stand-in engine to check the sharding and exchange logic without a GPU.
+Who the ranks are -- processes of a torch.distributed group or threads of one
+process -- is prmf_amd.ranks' business.
 """
-import torch
-import torch.distributed as dist
+from .ranks import TorchRanks, as_ranks
 
-
-class Collectives(object):
-    """The three exchanges, on whatever backend the process group has.  NCCL/RCCL
-    runs them on device buffers directly; gloo (tests) stages through the host and
-    builds reduce_scatter from all_reduce (gloo has no reduce_scatter)."""
-
-    def __init__(self, group=None):
-        self.group = group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
-        self.native = dist.get_backend(group) == "nccl"
-
-    def all_reduce_sum(self, t):
-        if self.native or not t.is_cuda:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        else:
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
-            t.copy_(h)
-
-    def reduce_scatter_sum(self, out, inp):
-        if self.native:
-            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group)
-            return
-        h = inp.cpu() if inp.is_cuda else inp.clone()
-        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
-        n = out.numel()
-        out.copy_(h.view(-1)[self.rank * n:(self.rank + 1) * n].view_as(out))
-
-    def all_gather(self, out, inp):
-        if self.native or not inp.is_cuda:
-            dist.all_gather_into_tensor(out, inp, group=self.group)
-        else:
-            ho = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_gather_into_tensor(ho, inp.cpu(), group=self.group)
-            out.copy_(ho)
+# the device-tensor exchanges live with the rank groups (prmf_amd.ranks); the old name stays importable
+Collectives = TorchRanks
 
 
 class DistributedPrmf(object):
     """Drives one engine per rank through the iteration.
 
-    native=True (default when the process group's backend is "nccl"): the library
+    `group`: a torch.distributed process group (None: the world) or a rank view of prmf_amd.ranks.LocalRanks (ranks as
+    threads of one process).
+
+    native=True (default when the process group's backend is "nccl", and for thread ranks): the library
     itself issues the RCCL collectives on the stream between its phases
     (`prmf_step_dist`), n_steps iterations per host call.  native=False: the four
-    phases are called from here with torch.distributed collectives in between --
-    the form the gloo tests exercise, and the fallback if the in-library
-    communicator cannot be created.  With world size 1 no collective is issued."""
+    phases are called from here with the group's collectives in between --
+    the form the gloo tests exercise.  With world size 1 no collective is issued.
+
+    There is NO silent fallback: if the in-library communicator cannot be created (every rank learns it together,
+    `engine.comm_init` decides collectively) the constructor raises on every rank.  A caller that wants the host-driven
+    path asks for it with native=False; `PRMF_ALLOW_HOST_COLLECTIVES=1` turns the error into the old warning + fallback."""
 
     def __init__(self, engine, group=None, native=None):
+        import os
         self.engine = engine
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.ranks = as_ranks(group)
+        self.world = self.ranks.world
         if self.world != engine.nranks:
             raise ValueError("engine was created for %d ranks, process group has %d" % (engine.nranks, self.world))
         if native is None:
-            native = self.world > 1 and dist.get_backend(group) == "nccl" and hasattr(engine, "comm_init")
+            native = self.world > 1 and self.ranks.on_gpu and hasattr(engine, "comm_init")
         self.native = False
         if native:
-            # engine.comm_init decides collectively: it either succeeds on every rank or raises on every rank, so the
-            # fallback below is taken by all ranks together (never a mix of nccl* calls and torch.distributed calls)
+            # engine.comm_init decides collectively: it either succeeds on every rank or raises on every rank, so no
+            # rank ever ends up inside nccl* calls while another one is in the group's own collectives
             try:
                 engine.comm_init(group)
                 self.native = True
-            except Exception as e:      # keep running on the host-driven path, but say so
+            except Exception as e:
+                if not os.environ.get("PRMF_ALLOW_HOST_COLLECTIVES"):
+                    raise
                 import sys
                 sys.stderr.write("prmf_amd: in-library RCCL communicator unavailable (%s); "
-                                 "using host-driven collectives\n" % e)
-        self.coll = Collectives(group) if (self.world > 1 and not self.native) else None
+                                 "PRMF_ALLOW_HOST_COLLECTIVES is set: using host-driven collectives\n" % e)
+        self.coll = self.ranks if (self.world > 1 and not self.native) else None
         self.buf = None if self.native else engine.comm_buffers()
+        if self.coll is not None and hasattr(engine, "set_global_rows"):
+            # host-driven: the library cannot all-reduce the sample count itself (prmf_hip.h: prmf_set_global_rows)
+            engine.set_global_rows(int(round(self.ranks.sum_float(engine.m, "cuda:%d" % engine.device))))
 
     def step(self, U, V, n_steps, gamma, delta, tradeoff=None):
         e = self.engine

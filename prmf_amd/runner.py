@@ -242,7 +242,9 @@ def initial_factors(args, X, manifolds, nodelist, write=True):
     fewer than k given -> the rest drawn with random.sample, more -> np.random.choice (the reference's RNG calls)."""
     chosen = list(args.manifolds_init)
     if len(chosen) < args.k_latent:
-        rest = list(set(manifolds.paths) - set(chosen))
+        # the reference draws from list(set(...)), whose order depends on the process's string-hash seed; sorted here so
+        # that a seed names one run -- in every process of a multi-rank launch too
+        rest = sorted(set(manifolds.paths) - set(chosen))
         chosen += random.sample(rest, args.k_latent - len(chosen))
     elif len(chosen) > args.k_latent:
         chosen = [chosen[i] for i in np.random.choice(len(chosen), args.k_latent)]
@@ -295,6 +297,10 @@ Solve an optimization problem of the form
     parser.add_argument("--n-gpus", type=int, default=1,
                         help="shard the solve over N GPUs of this node: re-launches this command under torch.distributed.run "
                              "(one process per GPU); not needed when the command is already started by that launcher")
+    parser.add_argument("--launcher", default="processes", choices=["processes", "threads"],
+                        help="how --n-gpus N becomes N ranks: `processes` (default) = one process per GPU under "
+                             "torch.distributed.run; `threads` = one host thread per GPU inside this process (inputs are "
+                             "read and normalised once, the ranks only run the solve)")
     parser.add_argument("--library-cache", default=None,
                         help="keep the built pathway library (support lists + support-local adjacency of every manifold over this "
                              "nodelist) in this .npz file and reuse it when the same manifold files and nodelist come back")
@@ -303,6 +309,11 @@ Solve an optimization problem of the form
     args = parser.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.n_gpus > 1 and args.launcher == "threads":
+        if args.seed is None:
+            args.seed = random.randrange(2 ** 31)
+        _run(args, 0, 1, local_ranks=args.n_gpus)
+        return
     if world == 1 and args.n_gpus > 1:
         # launcher mode: nothing in this process has touched the GPU (or imported torch); the ranks are children
         import socket
@@ -339,14 +350,23 @@ Solve an optimization problem of the form
             sys.stdout = open(os.devnull, "w")
     try:
         _run(args, rank, world)
-    finally:
+    except BaseException:
+        # no barrier on the way out of a failure: the other ranks may be inside a different collective (or gone); this
+        # process ends non-zero and the launcher ends the job
         if group_ready:
-            import torch.distributed as dist
-            dist.barrier()
-            dist.destroy_process_group()
+            try:
+                import torch.distributed as dist
+                dist.destroy_process_group()
+            except Exception:
+                pass
+        raise
+    if group_ready:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
-def _run(args, rank, world):
+def _run(args, rank, world, local_ranks=0):
     manifolds = ManifoldSet.from_args(args)
     if args.seed is not None:                              # both legacy streams, as the reference seeds them
         np.random.seed(int(args.seed))
@@ -378,10 +398,17 @@ def _run(args, rank, world):
             library = PathwayLibrary.from_graphs(manifolds.graphs, nodelist)       # exactly what nmf_pathway would build
             if rank == 0:
                 library.save(args.library_cache, key=h.hexdigest())
-    U, V, obj_data = nmf_pathway(X, manifolds.graphs, nodelist=nodelist, gamma=args.gamma,       # the GPU solve (:1067)
-                                 tradeoff=None if args.tradeoff == -1 else args.tradeoff, k_latent=args.k_latent,
-                                 U_init=U_init, V_init=V_init, verbose=args.verbose, x_dtype=args.x_dtype,
-                                 dist_mode=args.dist_mode, library=library)
+    solve = dict(nodelist=nodelist, gamma=args.gamma, tradeoff=None if args.tradeoff == -1 else args.tradeoff,
+                 k_latent=args.k_latent, U_init=U_init, V_init=V_init, verbose=args.verbose, x_dtype=args.x_dtype,
+                 dist_mode=args.dist_mode, library=library)
+    if local_ranks > 1:                                     # --launcher threads: the ranks share everything read so far
+        from .pathways import PathwayLibrary
+        from .ranks import LocalRanks
+        if solve["library"] is None:
+            solve["library"] = PathwayLibrary.from_graphs(manifolds.graphs, nodelist)
+        U, V, obj_data = LocalRanks(local_ranks).run(lambda view: nmf_pathway(X, manifolds.graphs, group=view, **solve))[0]
+    else:
+        U, V, obj_data = nmf_pathway(X, manifolds.graphs, **solve)                                # the GPU solve (:1067)
     if rank != 0:                                          # every rank holds the same U, V, obj_data; rank 0 writes them
         return
     if X_test is not None:                                 # :1073-1079: one sweep + batched NNLS (prmf/__init__.py:768-798)

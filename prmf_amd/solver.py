@@ -275,40 +275,49 @@ class PrmfEngine(object):
     # -- collectives inside the library (RCCL on the stream; no per-iteration host work) ----
     def comm_init(self, group=None):
         """Create this rank's RCCL communicator inside the library: rank 0 draws the
-        unique id, torch.distributed broadcasts the 128 bytes, every rank joins.
+        unique id, the rank group (prmf_amd.ranks: a torch.distributed group or thread ranks) hands the 128 bytes
+        round, every rank joins.
 
         Every decision is taken COLLECTIVELY so that no rank ends up inside ncclCommInitRank (or later inside
-        prmf_step_dist's nccl* calls) while another one has fallen back: (1) every rank checks that the library can
+        prmf_step_dist's nccl* calls) while another one has given up: (1) every rank checks that the library can
         bind RCCL at all and the flags are MIN-reduced before anything else; (2) after ncclCommInitRank the result
         flags are MIN-reduced again.  Any failure raises PrmfError on EVERY rank."""
-        torch = self.torch
+        import os
+        from .ranks import as_ranks
         idbuf = np.zeros(_capi.PRMF_COMM_ID_BYTES, dtype=np.uint8)
+        t = os.environ.get("PRMF_COLLECTIVE_TIMEOUT_S")
+        if t:
+            self.set_comm_timeout(float(t))
         if self.nranks == 1:
             self._check_create(self.lib.prmf_comm_unique_id(_ptr(idbuf)))
             self._check(self.lib.prmf_comm_init(self.ctx, _ptr(idbuf)))
             self._native_comm = True
             return
-        import torch.distributed as dist
-        on_gpu = dist.get_backend(group) == "nccl"
-        cdev = "cuda:%d" % self.device if on_gpu else "cpu"
+        ranks = as_ranks(group)
+        if ranks.world != self.nranks or ranks.rank != self.rank:
+            raise ValueError("engine is rank %d of %d, the group says %d of %d" % (self.rank, self.nranks, ranks.rank, ranks.world))
+        cdev = "cuda:%d" % self.device
 
         def all_ok(local_ok, what):
-            flag = torch.tensor([1 if local_ok else 0], dtype=torch.int32, device=cdev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-            if int(flag.item()) == 0:
+            if ranks.min_int(1 if local_ok else 0, cdev) == 0:
                 raise _capi.PrmfError(_capi.PRMF_ERR_UNSUPPORTED,
                                       "%s failed on at least one rank (this rank: %s); no rank uses the in-library collectives"
                                       % (what, "ok" if local_ok else self.lib.prmf_last_error(None).decode()))
 
         scratch = np.zeros(_capi.PRMF_COMM_ID_BYTES, dtype=np.uint8)
-        rc = self.lib.prmf_comm_unique_id(_ptr(idbuf if dist.get_rank(group) == 0 else scratch))   # binds librccl
+        rc = self.lib.prmf_comm_unique_id(_ptr(idbuf if ranks.rank == 0 else scratch))   # binds librccl
         all_ok(rc == _capi.PRMF_OK, "binding RCCL (prmf_comm_unique_id)")
-        t = torch.from_numpy(idbuf).to(cdev)
-        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        idbuf = t.cpu().numpy().copy()
+        idbuf = np.ascontiguousarray(ranks.bytes_from_rank0(idbuf, cdev))
         rc = self.lib.prmf_comm_init(self.ctx, _ptr(idbuf))
         all_ok(rc == _capi.PRMF_OK, "prmf_comm_init (ncclCommInitRank)")
         self._native_comm = True
+
+    def set_global_rows(self, m_global):
+        """samples over all ranks (host-driven collectives; prmf_comm_init finds it out itself)"""
+        self._check(self.lib.prmf_set_global_rows(self.ctx, int(m_global)))
+
+    def set_comm_timeout(self, seconds):
+        self._check(self.lib.prmf_set_comm_timeout(self.ctx, float(seconds)))
 
     def _check_create(self, rc):
         if rc != _capi.PRMF_OK:
@@ -358,6 +367,14 @@ class PrmfEngine(object):
         info = _capi.SweepInfo()
         self._check(self.lib.prmf_get_sweep_info(self.ctx, C.byref(info)))
         return info
+
+    def stream_read(self, which="x", reps=5):
+        """(ms per launch, bytes per launch) of a pure non-temporal stream of the resident X ("x") or X^T ("xt"): the
+        calibration bench.py prices the sweeps against (include/prmf_hip_debug.h: prmf_debug_stream)."""
+        ms, nbytes = C.c_double(), C.c_int64()
+        self._check(self.lib.prmf_debug_stream(self.ctx, 0 if which == "x" else 1, int(reps), C.byref(ms), C.byref(nbytes),
+                                               self._stream()))
+        return ms.value, nbytes.value
 
     def set_timing(self, enabled):
         self._check(self.lib.prmf_set_timing(self.ctx, 1 if enabled else 0))
@@ -521,63 +538,6 @@ def force_distinct_lapls(V, library, latent_to_pathway_data, k_to_lapl, gamma, d
     return latent_to_pathway_data
 
 
-class _Ranks(object):
-    """Which rank of which process group this call of nmf_pathway is (one process per GPU, torch.distributed).  The
-    reference has no counterpart (one process, script/prmf_runner.py:556); the rules that keep N ranks one solve:
-    rank 0's legacy RNG is THE stream -- what it draws (U_init / V_init, the per-round pathway samples) is broadcast --
-    and everything else every rank computes itself from replicated state (V, the records), so all ranks take the same
-    decisions without further exchange."""
-
-    def __init__(self, group):
-        self.group, self.world, self.rank, self.dist = group, 1, 0, None
-        try:
-            import torch.distributed as dist
-        except ImportError:
-            return
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            self.dist, self.world, self.rank = dist, dist.get_world_size(group), dist.get_rank(group)
-
-    @property
-    def multi(self):
-        return self.world > 1
-
-    def src(self):
-        return self.dist.get_global_rank(self.group, 0) if self.group is not None else 0
-
-    def from_rank0(self, obj):
-        """rank 0's value of a small host object on every rank"""
-        if not self.multi:
-            return obj
-        box = [obj if self.rank == 0 else None]
-        self.dist.broadcast_object_list(box, src=self.src(), group=self.group)
-        return box[0]
-
-    def sum_float(self, torch, value, device):
-        if not self.multi:
-            return float(value)
-        on_gpu = self.dist.get_backend(self.group) == "nccl"
-        t = torch.tensor([value], dtype=torch.float64, device=device if on_gpu else "cpu")
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        return float(t.item())
-
-    def gather_rows(self, torch, t, m):
-        """row shards (sizes differ by at most one) -> the full m x k matrix on every rank, as a host array"""
-        if not self.multi:
-            return t.cpu().numpy()
-        from .synthetic import shard_rows
-        on_gpu = self.dist.get_backend(self.group) == "nccl"
-        rows = max(shard_rows(m, self.world, r)[1] - shard_rows(m, self.world, r)[0] for r in range(self.world))
-        pad = torch.zeros((rows, t.shape[1]), dtype=t.dtype, device=t.device if on_gpu else "cpu")
-        pad[:t.shape[0]] = t if on_gpu else t.cpu()
-        out = [torch.empty_like(pad) for _ in range(self.world)]
-        self.dist.all_gather(out, pad, group=self.group)
-        parts = []
-        for r in range(self.world):
-            lo, hi = shard_rows(m, self.world, r)
-            parts.append(out[r][:hi - lo].cpu().numpy())
-        return np.concatenate(parts, axis=0)
-
-
 def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3, max_iter=1000, nodelist=None,
                 modulus=10, U_init=None, V_init=None, verbose=False, x_dtype="f32", library=None, round_log=None,
                 trace=None, group=None, dist_mode=None):
@@ -590,36 +550,46 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
     rand(m,k), rand(n,k) (:651-653), one multinomial draw per latent per round (:723).
 
     Multi-GPU: called by every rank of an initialised torch.distributed process group (one process per GPU; `group`,
-    default the world) with the same arguments, the solve is sharded -- rank r keeps rows shard_rows(m, N, r) of X and
+    default the world) -- or of a prmf_amd.ranks.LocalRanks group (one thread per GPU; `group` = the rank's view) --
+    with the same arguments, the solve is sharded -- rank r keeps rows shard_rows(m, N, r) of X and
     U on its GPU, V is replicated, each iteration exchanges the k x k Gram U^T U and the n x k product X^T U over RCCL
     (prmf_amd.distributed; dist_mode "colshard" (default) or "replicated").  Rank 0's RNG stream is the solve's: its
     draws are broadcast.  Every rank returns the same (U, V, obj_data) -- U gathered to all m rows; only rank 0 prints."""
     from scipy.stats import multinomial
-    ranks = _Ranks(group)
+    from .ranks import as_ranks
+    ranks = as_ranks(group)
     say = print if ranks.rank == 0 else (lambda *a, **kw: None)
-    X = np.asarray(X)
+    X = np.asarray(X) if not hasattr(X, "rows") else X        # RowSource (rank-local input): .shape, .rows(lo, hi)
     m, n = X.shape
     lo, hi = 0, m
     if ranks.multi:
         from .synthetic import shard_rows
         lo, hi = shard_rows(m, ranks.world, ranks.rank)
     engine = PrmfEngine(hi - lo, n, k_latent, x_dtype=x_dtype, nranks=ranks.world, rank=ranks.rank,
-                        dist_mode=dist_mode if ranks.multi else None)
+                        dist_mode=dist_mode if ranks.multi else None, device=ranks.device_index)
     try:
         torch = engine.torch
         dev = "cuda:%d" % engine.device
-        Xd = engine.device_tensor(X[lo:hi], engine.torch_x_dtype)
-        norm_sq = ranks.sum_float(torch, engine.local_norm_sq(Xd), dev)
+        Xd = engine.device_tensor(X.rows(lo, hi) if hasattr(X, "rows") else X[lo:hi], engine.torch_x_dtype)
+        norm_sq = ranks.sum_float(engine.local_norm_sq(Xd), dev)
         engine.set_x(Xd, norm_x_sq=norm_sq)
         del Xd
         norm_X = math.sqrt(norm_sq)                                 # :640 (of the X the GPUs hold)
         say("norm(X) = {}".format(norm_X))                          # :641
         gamma = gamma * norm_X / k_latent                           # :644
         delta = delta * 10 / norm_X                                 # :645
-        if U_init is None:
-            U_init = ranks.from_rank0(3 * (1 - np.random.rand(m, k_latent)) if ranks.rank == 0 else None)
-        if V_init is None:
-            V_init = ranks.from_rank0(3 * (1 - np.random.rand(n, k_latent)) if ranks.rank == 0 else None)
+        # rank 0's factors are THE factors, drawn here (:651-653) or handed in: every rank takes rank 0's (a caller's
+        # per-rank initialisers need not agree, e.g. set iteration order under different hash seeds); as tensors
+        given = ranks.from_rank0((U_init is not None, V_init is not None)) if ranks.multi else (U_init is not None, V_init is not None)
+        if ranks.rank == 0 or not ranks.multi:
+            if not given[0]:
+                U_init = 3 * (1 - np.random.rand(m, k_latent))
+            if not given[1]:
+                V_init = 3 * (1 - np.random.rand(n, k_latent))
+        if ranks.multi:
+            shp = ranks.from_rank0((np.shape(U_init), np.shape(V_init)) if ranks.rank == 0 else None)
+            U_init = ranks.array_from_rank0(U_init, shp[0], dev)
+            V_init = ranks.array_from_rank0(V_init, shp[1], dev)
         if U_init.shape != (m, k_latent):
             raise ValueError("Invalid U_init with shape {} != (m_obs, k_latent) = {}".format(U_init.shape, (m, k_latent)))
         if V_init.shape != (n, k_latent):

@@ -64,6 +64,23 @@ def test_lean_objective_equals_faithful(golden_dir):
     assert abs(od["obj"] - g["obj"][-1][6]) < 1e-10 * g["obj"][-1][6]
 
 
+def test_rebuilt_laplacians_equal_cached_and_reference(golden_dir):
+    """The oracle's reference-cost mode (normalize_laplacian restated as it runs every iteration, prmf_runner.py:56-65 /
+    :349; bench.py's CPU baseline) gives the records of the cached form and of the reference golden."""
+    g = load(golden_dir, "g2_inner25.npz")
+    case = synth.small_case(seed=1)
+    pws = oracle_pathways(case)
+    active = pws[:case["k"]]
+    for pw in active:
+        assert abs(pw.L_normal_rebuilt() - pw.L_normal()).max() <= 1e-15      # scalar ** vs array ** : an ulp
+    U, V = g["U"][-1], g["V"][-1]
+    a = orc.nmf_manifold_vec_obj(case["X"], U, V, active, case["gamma"], case["delta"], rebuild_laplacians=True)
+    b = orc.nmf_manifold_vec_obj(case["X"], U, V, active, case["gamma"], case["delta"])
+    for j, key in enumerate(["recon", "manifold", "ignore", "fro", "gamma", "delta", "obj"]):
+        assert abs(a[key] - b[key]) <= 1e-13 * max(1.0, abs(b[key])), key
+        assert abs(a[key] - g["obj"][-1][j]) <= TOL * max(1.0, abs(g["obj"][-1][j])), key
+
+
 def test_tradeoff_matches_reference(golden_dir):
     g = load(golden_dir, "g4_tradeoff15.npz")
     case = synth.small_case(seed=1)
