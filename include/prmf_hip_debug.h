@@ -24,8 +24,10 @@ int prmf_debug_slab_sum(prmf_ctx* ctx, int which, float* out_dev, void* stream);
  * each against float64.  PRMF_ERR_STATE if the last batch was not a deferred one. */
 int prmf_debug_recon_terms(prmf_ctx* ctx, int it, double* cross, double* gu, double* gv);
 
-/* Device buffer (uint64) receiving per-workgroup start / end wall-clock stamps (and, in a -DPRMF_PHASE_PROF=1 build,
- * per-wave phase sums) of the next sweep launches; NULL switches it off.  tools/wg_spread.py, tools/sweep_phases.py */
+/* Device buffer (uint64, >= 8192 entries; >= 2048 + 32 * workgroups * waves in a -DPRMF_PHASE_PROF=1 build) receiving
+ * per-workgroup start / end wall-clock stamps of the next sweep launches ([2 b], [2 b + 1] for workgroup b), where each
+ * workgroup ran ([6144 + b] = XCC_ID << 32 | HW_ID) and, in a phase-profile build, per-wave phase sums from [2048];
+ * NULL switches it off.  tools/wg_spread.py, tools/wg_where.py, tools/sweep_phases.py */
 int prmf_debug_set_stamps(void* dev_buf);
 /* The same for the fused epilogues: 8 stamps per workgroup.  tools/epi_phases.py */
 int prmf_debug_set_epi_stamps(void* dev_buf);
@@ -50,6 +52,13 @@ int prmf_debug_plan_sweep(int x_dtype, long long rows, long long depth, int k, i
  * sweep's rate as a fraction of this one (`roofline.frac_of_stream`), which separates the kernel from the box it ran on.
  * Synchronises `stream`. */
 int prmf_debug_stream(prmf_ctx* ctx, int which, int reps, double* ms_out, int64_t* bytes_out, void* stream);
+
+/* Probe of a hand-off inside the sweep's tail (tools/tail_probe.py): with a device buffer of 64 + 2 * 4096 ints set, every
+ * workgroup of the following `which` sweeps (0: X V, 1: X^T U; unsliced plans) publishes its slabs behind a release fence
+ * and an agent-scope atomic per panel, claims groups of `tiles_per_group` output tiles from a ticket counter, waits for
+ * the group's panel (acquire) and reads its tiles of slab 0 -- what a fused epilogue would pay before any arithmetic.
+ * Results are unchanged.  dev_buf[3] != 0 afterwards: a wait gave up.  NULL switches it off. */
+int prmf_debug_set_tail_probe(prmf_ctx* ctx, int which, int* dev_buf, int tiles_per_group);
 
 /* The library's bounded wait for a stream that may carry collectives (prmf_set_comm_timeout), callable on its own:
  * PRMF_OK when the stream has drained, PRMF_ERR_HIP (and the communicator aborted) when the time limit passed first.

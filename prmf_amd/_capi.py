@@ -90,6 +90,7 @@ DEBUG_SIGNATURES = {
     "prmf_debug_plan_sweep": (_i, [_i, C.c_longlong, C.c_longlong, _i, _i, C.POINTER(_i)]),
     "prmf_debug_stream": (_i, [_vp, _i, _i, C.POINTER(_d), C.POINTER(_i64), _vp]),
     "prmf_debug_sync_stream": (_i, [_vp, _vp]),
+    "prmf_debug_set_tail_probe": (_i, [_vp, _i, _vp, _i]),
 }
 
 _lib = None

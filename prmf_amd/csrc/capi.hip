@@ -1384,6 +1384,26 @@ int prmf_debug_sync_stream(prmf_ctx* c, void* stream) {
   return sync_stream(c, (hipStream_t)stream);
 }
 
+int prmf_debug_set_tail_probe(prmf_ctx* c, int which, int* dev_buf, int tiles_per_group) {
+  if (!dev_buf) { prmf::g_tail_probe = nullptr; prmf::g_tail_plan = nullptr; return PRMF_OK; }
+  if (!c || (which != 0 && which != 1) || tiles_per_group < 1) return PRMF_ERR_ARG;
+  const GemmPlan& p = which == 0 ? c->plan_xv : c->plan_xtu;
+  if (p.panels > 4096 || p.nx != 1) return fail(c, PRMF_ERR_UNSUPPORTED, "tail probe: unsliced plans with <= 4096 panels only");
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  std::vector<int> host((size_t)64 + 2 * 4096, 0);
+  const int64_t tiles = (int64_t)p.panels * p.panel_rows / 32;
+  host[1] = (int)((tiles + tiles_per_group - 1) / tiles_per_group);
+  host[2] = tiles_per_group;
+  for (int q = 0; q < p.panels; ++q) host[(size_t)64 + 4096 + q] = __builtin_popcountll((unsigned long long)p.segmask[(size_t)q]);
+  HIP_TRY(c, hipMemcpy(dev_buf, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipDeviceSynchronize());
+  prmf::g_tail_launch = 0;
+  prmf::g_tail_probe = dev_buf;
+  prmf::g_tail_plan = &p;
+  return PRMF_OK;
+}
+
 int prmf_debug_bump_cursor(prmf_ctx* c) {
   if (!c || c->cursor + 1 >= MAX_RECORDS) return PRMF_ERR_ARG;
   c->cursor++;

@@ -370,6 +370,13 @@ constexpr bool LOADS_FIRST = PRMF_LOADS_FIRST != 0;
 // overlaps a wave's load burst with MFMAs) 2.214 -> 2.059 ms; the 4-wave form (two workgroups per CU that alternate
 // phases by themselves) 2.132 -> 2.319 ms, 25000 x 25000 equal -- hence the 8-wave form only.
 template <int NW> struct Sprinkle { static constexpr bool value = PRMF_SPRINKLE != 0 && (PRMF_SPRINKLE == NW || PRMF_SPRINKLE == 1); };
+#ifndef PRMF_TAIL_PROBE
+#define PRMF_TAIL_PROBE 0     // 1: the hand-off probe behind the segments loop is compiled in (it costs the kernels 2 registers)
+#endif
+#ifndef PRMF_ABL_B_HOT
+#define PRMF_ABL_B_HOT 0      // ABLATION (wrong arithmetic): every workgroup reads its factor chunks from one window of this many
+                              // chunks, which then stays in every L2 -- prices the factor's trips through the fabric (tools/ab_sweep.py)
+#endif
 #ifndef PRMF_UNIT_CHUNKS
 #define PRMF_UNIT_CHUNKS 2
 #endif
@@ -421,8 +428,15 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : PRMF_SWEEP_MINW)   // t
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
              const uint4* __restrict__ Bp, int npanels, int g_begin, int ngroups /* work units (UNIT chunks each) [g_begin, g_begin+ngroups) of every row */,
              int nx, int pmax, int seg_base, float* __restrict__ slabs, int64_t slab_stride, int slab_nt,
-             unsigned long long* __restrict__ stamps /* debug, may be null */, const SweepPrologue pro) {
-  if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x] = wall_clock64();
+             unsigned long long* __restrict__ stamps /* debug, may be null */, const SweepPrologue pro,
+             int* __restrict__ tail /* debug (tools/tail_probe.py), may be null */, int tail_launch) {
+  if (stamps && threadIdx.x == 0) {
+    stamps[2 * blockIdx.x] = wall_clock64();
+    // where this workgroup runs (tools/wg_where.py): HW_ID (wave / SIMD / CU / SH / SE ids) and XCC_ID, for the question
+    // what the systematic finish-time spread of equal shares goes with
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    stamps[6144 + blockIdx.x] = ((unsigned long long)xcc << 32) | hw;
+  }
   constexpr int NTHR = 64 * NW;
   constexpr int BCH = MODE == 1 ? 512 * NT : 256 * NT;   // uint4 per packed chunk (64 bf16 or 32 f32 elements of the reduction)
   constexpr int BPT = (BCH + NTHR - 1) / NTHR;      // uint4 staged per thread per chunk (last one may be partial)
@@ -514,6 +528,11 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   // uniform bases (SGPR) + per-lane byte offsets (VGPR, < panel rows * row bytes)
   const uint4* abase = A + prow0 * lda16 + (int64_t)c0 * 8;         // chunk = 8 x 16 B of each row
   const uint4* bbase = Bp + (int64_t)c0 * BCH;
+#if PRMF_ABL_B_HOT
+#define B_CHUNK_AT(ci) (Bp + (int64_t)((c0 + (ci)) % PRMF_ABL_B_HOT) * BCH)
+#else
+#define B_CHUNK_AT(ci) (bbase + (int64_t)(ci) * BCH)
+#endif
 
   f32x16 acc[MT][NT];
   constexpr bool HAS_LO = SweepLo<MODE, NT>::value;
@@ -532,7 +551,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   u32x4 bs[BPT];
 
   // prologue: B(0), A(0) -> LDS
-  load_b_chunk<BPT, NTHR, BCH>(bs, bbase, tid);
+  load_b_chunk<BPT, NTHR, BCH>(bs, B_CHUNK_AT(0), tid);
   load_a_chunk<MT>(a, avoff, abase);
   store_b_chunk<BPT, NTHR, BCH>(sB[0], bs, tid);
 #pragma unroll
@@ -559,7 +578,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
         if constexpr (LOADS_FIRST && LF_MODE_OK && STEPS == 0) {
           // the next chunk's loads are in flight while this chunk is computed from LDS
           if (next) {
-            load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
+            load_b_chunk<BPT, NTHR, BCH>(bs, B_CHUNK_AT(cn), tid);
             load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -582,7 +601,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
           // no branch around the loads (behind one the compiler waits vmcnt(0) before every load): the last chunk of a
           // segment re-loads itself, one wasted chunk per segment
           const int cl = next ? cn : c + u;
-          const u32x4* const bnext = reinterpret_cast<const u32x4*>(bbase + (int64_t)cl * BCH);
+          const u32x4* const bnext = reinterpret_cast<const u32x4*>(B_CHUNK_AT(cl));
           const char* const anext = reinterpret_cast<const char*>(abase + (int64_t)cl * 8);
           auto hook = [&](int j) {
 #pragma unroll
@@ -606,7 +625,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
         PH_MARK(2);
         if constexpr (!(LOADS_FIRST && LF_MODE_OK) && STEPS == 0) {
           if (next) {
-            load_b_chunk<BPT, NTHR, BCH>(bs, bbase + (int64_t)cn * BCH, tid);
+            load_b_chunk<BPT, NTHR, BCH>(bs, B_CHUNK_AT(cn), tid);
             load_a_chunk<MT>(a, avoff, abase + (int64_t)cn * 8);
           }
         } else {
@@ -679,7 +698,66 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
       }
   }
   }
+#undef B_CHUNK_AT
   }   // segments
+#if PRMF_TAIL_PROBE
+  // ---- PROBE (a -DPRMF_TAIL_PROBE=1 variant build; tools/tail_probe.py): what would a hand-off to an epilogue in the sweep's tail cost?  Every
+  // workgroup publishes its slabs (release fence + one agent-scope atomic per panel it touched), then claims groups of
+  // output tiles from a ticket counter, waits until the group's panel has all its segments (acquire) and reads the
+  // group's tiles of slab 0.  No arithmetic depends on it.  Counters only grow: launch L works with tickets
+  // [L (ngroups + grid), ..) and panel targets (L + 1) expected[p].  Layout: tail[0] ticket counter, [1] ngroups,
+  // [2] tiles per group, [3] error flag, [4] checksum sink, [64 + p] arrivals of panel p, [64 + 4096 + p] expected[p].
+  // PRMF_TAIL_PROBE = 2: the same without cache-wide operations -- no release fence (the wave only waits for its own
+  // stores, s_waitcnt vmcnt(0)) and relaxed agent-scope atomics instead of acquire / release: what the hand-off costs if
+  // the slabs themselves travel with system-scope (sc0 sc1) stores and loads, which need no L2 write-back / invalidate
+  constexpr int TAIL_REL = PRMF_TAIL_PROBE == 2 ? __ATOMIC_RELAXED : __ATOMIC_RELEASE;
+  constexpr int TAIL_ACQ = PRMF_TAIL_PROBE == 2 ? __ATOMIC_RELAXED : __ATOMIC_ACQUIRE;
+  if (tail) {
+    if constexpr (PRMF_TAIL_PROBE == 2) __builtin_amdgcn_s_waitcnt(0);
+    else __threadfence();
+    __syncthreads();
+    {
+      const int64_t u0 = L > 0 ? T * wj / Gx : 0;
+      if (threadIdx.x == 0 && unit_end > u0)
+        for (int pp = (int)(u0 / L); pp <= (int)((unit_end - 1) / L); ++pp)
+          __hip_atomic_fetch_add(&tail[64 + pp], 1, TAIL_REL, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int ngroups = tail[1], gtiles = tail[2], per_launch = ngroups + (int)gridDim.x;
+    __shared__ int s_ticket;
+    float sink = 0.f;
+    for (;;) {
+      if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&tail[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tail_launch * per_launch;
+      __syncthreads();
+      const int g = s_ticket;
+      __syncthreads();
+      if (g >= ngroups) break;
+      const int pp = (int)(((int64_t)g * gtiles * 32) / (32 * MT * NW));
+      const int target = (tail_launch + 1) * tail[64 + 4096 + pp];
+      if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(&tail[64 + pp], TAIL_ACQ, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1 << 20) || __hip_atomic_load(&tail[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {      // never hang: give up, flagged,
+            __hip_atomic_store(&tail[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                 // and nobody waits after that
+            break;
+          }
+        }
+      }
+      __syncthreads();
+      if (lane == 0) (void)__hip_atomic_load(&tail[64 + pp], TAIL_ACQ, __HIP_MEMORY_SCOPE_AGENT);      // every wave acquires
+      const f32x4* sl = reinterpret_cast<const f32x4*>(slabs + (int64_t)seg_base * slab_stride);
+      for (int tt = wave; tt < gtiles; tt += NW) {
+        const int64_t tile = (int64_t)g * gtiles + tt;
+#pragma unroll
+        for (int q = 0; q < 4 * NT; ++q) {
+          const f32x4 v = sl[(tile * NT * 4 + q) * 64 + lane];
+          sink += v[0] + v[3];
+        }
+      }
+    }
+    if (sink == 1.2345e-33f) tail[4] = 1;
+  }
+#endif
 #if PRMF_PHASE_PROF
   if (stamps && lane == 0)
     for (int i = 0; i < 6; ++i) stamps[2048 + (blockIdx.x * 4 + wave) * 8 + i] = ph_sum[i];
@@ -821,6 +899,9 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
 }
 
 unsigned long long* g_sweep_stamps = nullptr;   // debug: per-workgroup start/end stamps (tools/wg_spread.py)
+int* g_tail_probe = nullptr;                    // debug: hand-off probe in the sweep's tail (tools/tail_probe.py)
+int g_tail_launch = 0;
+const GemmPlan* g_tail_plan = nullptr;          // the one plan whose launches carry the probe
 
 template <int MODE, int NW, bool BDB, int MTV>
 static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda16, int64_t M_store, const void* Bp,
@@ -836,7 +917,7 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
   }                                                                                                            \
   sweep_kernel<MODE, MTV, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), dyn, s>>>(                                \
       (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, 0, p.ngroups, p.nx, p.pmax, 0, slabs, slab_stride, \
-      p.slab_nt ? 1 : 0, g_sweep_stamps, pro)
+      p.slab_nt ? 1 : 0, g_sweep_stamps, pro, (&p == g_tail_plan) ? g_tail_probe : nullptr, (&p == g_tail_plan) ? g_tail_launch++ : 0)
   if constexpr (NW == 8) {
     // bf16 X: k > 32; f32 X: k = 33..64 with 64-row wave tiles, k > 64 with 32-row ones (f32_wave_tiles)
     constexpr bool K64 = MODE == 1 || MTV == SWEEP_MT, KWIDE = MODE == 1 || MTV == 1;

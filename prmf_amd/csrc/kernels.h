@@ -131,6 +131,9 @@ struct SweepTuning {
 GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, const SweepTuning& tune);
 extern unsigned long long* g_sweep_stamps;   // debug only
 extern unsigned long long* g_epi_stamps;     // debug only (column-split epilogue phases)
+extern int* g_tail_probe;                     // debug only (tools/tail_probe.py)
+extern int g_tail_launch;
+extern const GemmPlan* g_tail_plan;
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
                        const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s,
                        bool split = false /* f32 X as three bf16 pieces, packedB in the bf16 hi/lo layout */,

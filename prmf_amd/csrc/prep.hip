@@ -2,7 +2,7 @@
 // (script/prmf_runner.py:1019-1020: sklearn.preprocessing.quantile_transform, n_quantiles = 1000, uniform output,
 // axis 0).  On the host it is an np.apply_along_axis loop over the genes (one partition + two np.interp per
 // column): minutes at 50000 x 20000.  Here: column blocks are gathered into contiguous segments, sorted with a
-// segmented radix sort (rocPRIM through hipCUB), the n_quantiles order statistics are interpolated exactly as
+// segmented radix sort (rocprim::segmented_radix_sort_keys, a library primitive: one-time preprocessing, not the hot path), the n_quantiles order statistics are interpolated exactly as
 // numpy's `linear` percentile does, and every element is mapped with the mean of an ascending and a descending
 // np.interp -- all in float64, operation for operation, so that the result equals scikit-learn's to the last bits:
 //
@@ -11,7 +11,7 @@
 //   quantiles = maximum.accumulate(quantiles)
 //   y = 0.5 * (interp(x, quantiles, references) - interp(-x, -quantiles[::-1], -references[::-1]))
 //   y = 1 where x == quantiles[-1];  y = 0 where x == quantiles[0]        (in that order)
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include "kernels.h"
 
@@ -175,16 +175,16 @@ hipError_t quantile_transform_device(double* dX, int64_t m, int64_t n, int64_t l
     PQ(hipMemcpyAsync(offsets, off.data(), off.size() * 4, hipMemcpyHostToDevice, s));
     PQ(hipStreamSynchronize(s));
   }
-  PQ(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, temp_bytes, cols, sorted, (int)(cb * n_fit), (int)cb, offsets, offsets + 1,
-                                                0, 64, s));
+  PQ(rocprim::segmented_radix_sort_keys(nullptr, temp_bytes, cols, sorted, (unsigned)(cb * n_fit), (unsigned)cb, offsets, offsets + 1,
+                                        0, 64, s));
   PQ(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
   for (int64_t c0 = 0; c0 < n; c0 += cb) {
     const int nc = (int)(n - c0 < cb ? n - c0 : cb);
     gather_cols_kernel<<<dim3((unsigned)((n_fit + TT - 1) / TT), (unsigned)((nc + TT - 1) / TT)), 256, 0, s>>>(
         dX, ld, fit_rows_dev, n_fit, c0, nc, cols);
     PQ(hipGetLastError());
-    PQ(hipcub::DeviceSegmentedRadixSort::SortKeys(temp, temp_bytes, cols, sorted, (int)((int64_t)nc * n_fit), nc, offsets, offsets + 1,
-                                                  0, 64, s));
+    PQ(rocprim::segmented_radix_sort_keys(temp, temp_bytes, cols, sorted, (unsigned)((int64_t)nc * n_fit), (unsigned)nc, offsets, offsets + 1,
+                                          0, 64, s));
     quantiles_kernel<<<dim3((unsigned)((nq + 255) / 256), (unsigned)nc), 256, 0, s>>>(sorted, n_fit, nc, qs, nq, Q);
     accumulate_max_kernel<<<(nc + 63) / 64, 64, 0, s>>>(Q, nc, nq);
     int64_t rb = (m + 3) / 4;

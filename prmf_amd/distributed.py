@@ -89,6 +89,14 @@ class DistributedPrmf(object):
         if self.native:
             return e.step_dist(U, V, n_steps, gamma, delta, tradeoff)
         b, c = self.buf, self.coll
+        if c is not None and tradeoff is not None and not getattr(self, "_warned_tradeoff", False) and hasattr(e, "lib"):
+            # the library can only sum the ranks' direct residuals itself (prmf_step_dist); driven from here the feedback
+            # gamma = delta = (1 - t) recon / (t manifold) runs on the Gram-identity recon, whose 1e-7 ||X||^2 error the
+            # feedback amplifies: say so instead of differing silently from the in-library path
+            import warnings
+            warnings.warn("prmf_amd: --tradeoff with host-driven collectives uses the Gram-identity reconstruction error in the "
+                          "feedback; the in-library RCCL step (native=True) uses the direct residual", RuntimeWarning)
+            self._warned_tradeoff = True
         replicated = getattr(e, "dist_mode", "colshard") == "replicated"
         objs_all = []
         gd = (gamma, delta)

@@ -118,16 +118,36 @@ class PathwayLibrary(object):
         return cls(n, supports, adjs, names)
 
     # ---- cache (the built library as one .npz) -------------------------
+    @staticmethod
+    def cache_path(path):
+        """np.savez appends '.npz' to a name without it; `save` and `load` agree on the name through this."""
+        return path if str(path).endswith(".npz") else str(path) + ".npz"
+
     def save(self, path, key=""):
-        """The flat arrays (what the GPU gets) + names + a caller-chosen `key` naming the inputs they were built from."""
-        np.savez_compressed(path, n=np.int64(self.n), names=np.array([str(x) for x in self.names]), key=np.array(str(key)),
-                            sup_ptr=self.sup_ptr, sup_idx=self.sup_idx, row_ptr=self.row_ptr, col_local=self.col_local, w=self.w)
+        """The flat arrays (what the GPU gets) + names + a caller-chosen `key` naming the inputs they were built from.
+        Written to a temporary file and renamed into place: a concurrent `load` (another rank, another job) sees the old
+        file or the new one, never a truncated archive."""
+        import os
+        import tempfile
+        path = self.cache_path(path)
+        fd, tmp = tempfile.mkstemp(suffix=".npz", dir=os.path.dirname(os.path.abspath(path)) or ".")
+        try:
+            with os.fdopen(fd, "wb") as fh:
+                np.savez_compressed(fh, n=np.int64(self.n), names=np.array([str(x) for x in self.names]), key=np.array(str(key)),
+                                    sup_ptr=self.sup_ptr, sup_idx=self.sup_idx, row_ptr=self.row_ptr, col_local=self.col_local, w=self.w)
+            os.replace(tmp, path)
+        except BaseException:
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
+            raise
 
     @classmethod
     def load(cls, path, key=None):
         """Library saved by `save`; None if `key` is given and the file was built from something else (or is unreadable)."""
         try:
-            z = np.load(path)
+            z = np.load(cls.cache_path(path))
             if key is not None and str(z["key"]) != str(key):
                 return None
             sup_ptr, row_ptr = z["sup_ptr"], z["row_ptr"]
@@ -138,7 +158,7 @@ class PathwayLibrary(object):
                 supports.append(z["sup_idx"][s0:s1].astype(np.int64))
                 adjs.append(sp.csr_matrix((z["w"][e0:e1], z["col_local"][e0:e1], row_ptr[s0:s1 + 1] - e0), shape=(s1 - s0, s1 - s0)))
             return cls(int(z["n"]), supports, adjs, [str(x) for x in z["names"]])
-        except (OSError, KeyError, ValueError):
+        except Exception:      # missing, truncated, corrupt (zipfile.BadZipFile, EOFError, pickle errors ...): rebuild
             return None
 
     # ---- host-side helpers used by the outer solver -------------------------

@@ -28,6 +28,25 @@ def _subsample_rows(m, random_state=None):
     return np.ascontiguousarray(idx[:SUBSAMPLE], dtype=np.int64)
 
 
+def quantile_transform_block(Xb, fit_rows=None, n_quantiles=1000, device=0):
+    """The same transform for a block of GENES (all samples x some columns, float64, C-contiguous) with the row
+    subsample already drawn (None: all rows): columns are independent, so a matrix can be normalised block by block --
+    what the rank-local input path of the multi-GPU CLI does (prmf_amd.runner.RowSource)."""
+    import torch
+    lib = _capi.load()
+    m, nb = Xb.shape
+    if m == 0 or nb == 0:
+        return Xb
+    Xd = torch.from_numpy(Xb).to("cuda:%d" % device)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    rc = lib.prmf_quantile_transform(int(device), C.c_void_p(Xd.data_ptr()), m, nb, nb,
+                                     fit_rows.ctypes.data_as(C.c_void_p) if fit_rows is not None else None,
+                                     len(fit_rows) if fit_rows is not None else m, int(n_quantiles), stream)
+    if rc != _capi.PRMF_OK:
+        raise _capi.PrmfError(rc, lib.prmf_last_error(None).decode())
+    return Xd.cpu().numpy()
+
+
 def quantile_transform(X, n_quantiles=1000, random_state=None, device=0, copy=True):
     """Drop-in for sklearn.preprocessing.quantile_transform(X) (uniform output, axis 0): numpy in, numpy out."""
     import torch

@@ -80,6 +80,17 @@ class TorchRanks(object):
         self.dist.broadcast(t, src=self._src(), group=self.group)
         return t.cpu().numpy()
 
+    def array_from_rank(self, src, a, shape, device="cpu"):
+        """rank `src`'s float64 host array (shape known to everybody) on every rank, as a tensor broadcast"""
+        if not self.multi:
+            return a
+        import torch
+        cdev = self._cdev(device)
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(cdev) if self.rank == src else \
+            torch.empty(tuple(shape), dtype=torch.float64, device=cdev)
+        self.dist.broadcast(t, src=self.dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
+        return t.cpu().numpy()
+
     def bytes_from_rank0(self, buf, device="cpu"):
         """uint8 numpy array of fixed length, rank 0's content on every rank"""
         if not self.multi:
@@ -260,6 +271,9 @@ class LocalRankView(object):
 
     def array_from_rank0(self, a, shape, device="cpu"):
         return self._exchange(a)[0] if self.multi else a
+
+    def array_from_rank(self, src, a, shape, device="cpu"):
+        return self._exchange(a)[src] if self.multi else a
 
     def bytes_from_rank0(self, buf, device="cpu"):
         return self._exchange(buf)[0].copy() if self.multi else buf

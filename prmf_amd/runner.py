@@ -51,7 +51,9 @@ def add_prmf_arguments(parser):
     parser.add_argument("--seed", default=None)
     parser.add_argument("--gamma", default=1.0, type=float, help="Tradeoff between reconstruction error and manifold regularization term; Default = 1.0")
     parser.add_argument("--delta", default=1.0, type=float, help="Regularization parameter for penalty for ignoring manifold; Default = 1.0")
-    parser.add_argument("--tradeoff", default=-1, type=float, help="If set, automatically update gamma and delta each iteration. Must be in [0,1]; -1 disables. Default = -1.")
+    parser.add_argument("--tradeoff", default=-1, type=float, help="If set, automatically update gamma and delta each iteration. Must be in [0,1]; -1 disables. Default = -1. "
+                             "(Here: with the feedback on, every iteration's reconstruction error comes from one more sweep over X -- the "
+                             "materialised residual the reference computes -- so an iteration costs about twice a plain one.)")
     parser.add_argument("--high-dimensional", default=True, type=bool, help="If True, ensure that <data> is of shape m x n with m < n ; otherwise ensure that X is m x n with m > n. Default = True.")
     parser.add_argument("--no-normalize", action='store_true', help="If flag is provided, don't quantile normalize the data")
     parser.add_argument("--delimiter", default=",", help="Field delimiter in <--data>")
@@ -193,8 +195,14 @@ class ManifoldSet(object):
 class DataMatrix(object):
     """--data as read from disk: a frame oriented samples x genes, whether it carried row names / a header."""
 
-    def __init__(self, args):
+    def __init__(self, args, header_only=False):
         import pandas as pd
+        if header_only:           # a .npy matrix whose rows the ranks read themselves (RowSource): only the sample index
+            self.has_header = self.has_row_names = False
+            shape = np.load(args.data, mmap_mode="r").shape
+            self.samples = list(range(shape[0]))           # the frame's RangeIndex, taken before the orientation step as always
+            self.frame = None
+            return
         if args.data.endswith(".npy"):
             # extension: a binary matrix (samples x genes, no header, no row names -> --nodelist is required), for sizes
             # where parsing 1e9 delimited numbers would dominate the run; everything downstream is unchanged
@@ -228,6 +236,61 @@ class DataMatrix(object):
                     nodelist.append(node)
                     seen.add(node)
         return embed_arr(nodelist, measured, self.frame.to_numpy()), nodelist
+
+
+class RowSource(object):
+    """This rank's rows of the data matrix, for a multi-rank run started with a binary (.npy) --data: the file is
+    memory-mapped and every rank converts ONLY what it needs -- its row shard for the solve and, unless --no-normalize, its
+    column shard for the per-gene quantile normalisation (:1019-1020; genes are independent, so rank r normalises genes
+    shard(n, N, r) over all samples in column sub-blocks and the ranks hand each other the rows they own, one sub-block at a
+    time) -- instead of every rank reading, orienting and normalising the whole matrix (8 x the parse time and 8 x the
+    host memory on one node).  nmf_pathway takes it in place of X: `.shape` and `.rows(lo, hi)`.
+    `peak_bytes` = the largest total of float64 arrays this object held at once (tests/test_gpu_sharded_solver.py)."""
+
+    SUB_BLOCK_BYTES = 64 << 20
+
+    def __init__(self, path, high_dimensional, ranks, normalize, device):
+        from .ranks import shard_of
+        mm = np.load(path, mmap_mode="r")
+        if mm.ndim != 2:
+            raise ValueError("--data must be a 2-D matrix")
+        m, n = mm.shape
+        view = mm.T if ((m > n) if high_dimensional else (m < n)) else mm          # :946-952
+        self.shape = view.shape
+        m, n = self.shape
+        self.lo, self.hi = shard_of(m, ranks.world, ranks.rank)
+        held = lambda *arrs: sum(a.nbytes for a in arrs if a is not None)
+        self.peak_bytes = 0
+        if not normalize:
+            self.local = np.ascontiguousarray(view[self.lo:self.hi], dtype=np.float64)
+            self.peak_bytes = held(self.local)
+            return
+        from .preprocess import SUBSAMPLE, _subsample_rows, quantile_transform_block
+        self.local = np.empty((self.hi - self.lo, n), dtype=np.float64)
+        fit_rows = _subsample_rows(m) if m > SUBSAMPLE else None                  # the same draw on every rank (same seed): as one call would make it
+        block_bytes = int(os.environ.get("PRMF_INPUT_BLOCK_BYTES", self.SUB_BLOCK_BYTES))     # (tests shrink it)
+        step = max(1, block_bytes // max(1, 8 * m))                                # genes per sub-block
+        spans = [shard_of(n, ranks.world, r) for r in range(ranks.world)]
+        rounds = max((c1 - c0 + step - 1) // step for c0, c1 in spans)
+        for i in range(rounds):
+            mine = None
+            c0, c1 = spans[ranks.rank]
+            a0, a1 = min(c0 + i * step, c1), min(c0 + (i + 1) * step, c1)
+            if a1 > a0:
+                mine = quantile_transform_block(np.ascontiguousarray(view[:, a0:a1], dtype=np.float64), fit_rows, device=device)
+            for src, (s0, s1) in enumerate(spans):
+                b0, b1 = min(s0 + i * step, s1), min(s0 + (i + 1) * step, s1)
+                if b1 <= b0:
+                    continue
+                piece = ranks.array_from_rank(src, mine if src == ranks.rank else None, (m, b1 - b0), "cuda:%d" % device)
+                self.peak_bytes = max(self.peak_bytes, held(self.local, mine, piece if piece is not mine else None))
+                self.local[:, b0:b1] = piece[self.lo:self.hi]
+                del piece
+
+    def rows(self, lo, hi):
+        if (lo, hi) != (self.lo, self.hi):
+            raise ValueError("this rank holds rows [%d, %d), asked for [%d, %d)" % (self.lo, self.hi, lo, hi))
+        return self.local
 
 
 def hold_out(X, samples, fraction):
@@ -371,15 +434,31 @@ def _run(args, rank, world, local_ranks=0):
     if args.seed is not None:                              # both legacy streams, as the reference seeds them
         np.random.seed(int(args.seed))
         random.seed(int(args.seed))
-    data = DataMatrix(args)
-    X, nodelist = data.resolve_genes(args, manifolds)
-    manifolds.coverage(nodelist)
-    samples, X_test = data.samples, None
-    if args.cross_validation is not None:
-        X, X_test, samples = hold_out(X, samples, args.cross_validation)
-    if not args.no_normalize:                              # :1019-1020, on the GPU (prmf_quantile_transform)
-        from .preprocess import quantile_transform
-        X = quantile_transform(X)
+    rank_local = (world > 1 and args.data.endswith(".npy") and args.nodelist is not None and args.cross_validation is None
+                  and args.manifolds_init is None)
+    if rank_local:
+        # several process ranks, binary input: nobody reads the whole matrix (RowSource)
+        import torch
+        from .ranks import TorchRanks
+        with open(args.nodelist) as fh:
+            nodelist = parse_nodelist(fh)
+        data = DataMatrix(args, header_only=True)
+        manifolds.coverage(nodelist)
+        X = RowSource(args.data, args.high_dimensional, TorchRanks(None), not args.no_normalize, torch.cuda.current_device())
+        if args.verbose:
+            sys.stderr.write("rank %d: rows [%d, %d) of %d x %d, peak %.1f MB of float64 input held\n"
+                             % (rank, X.lo, X.hi, X.shape[0], X.shape[1], X.peak_bytes / 1e6))
+        samples, X_test = data.samples, None
+    else:
+        data = DataMatrix(args)
+        X, nodelist = data.resolve_genes(args, manifolds)
+        manifolds.coverage(nodelist)
+        samples, X_test = data.samples, None
+        if args.cross_validation is not None:
+            X, X_test, samples = hold_out(X, samples, args.cross_validation)
+        if not args.no_normalize:                              # :1019-1020, on the GPU (prmf_quantile_transform)
+            from .preprocess import quantile_transform
+            X = quantile_transform(X)
     U_init = V_init = None
     if args.manifolds_init is not None:
         U_init, V_init = initial_factors(args, X, manifolds, nodelist, write=rank == 0)

@@ -123,3 +123,42 @@ def test_cli_two_ranks_vs_reference(golden_dir, tmp_path, norm):
     assert et < 1e-4 and eu < 1e-4 and ev < 1e-4
     for key in ref:
         assert abs(vals[key] - ref[key]) <= 1e-4 * abs(ref[key]) + 1e-5, key
+
+
+@pytest.mark.parametrize("norm", ["nonorm", "norm"])
+def test_cli_rank_local_npy_input(golden_dir, tmp_path, norm):
+    """`--n-gpus 3` with a binary --data: every rank memory-maps the file and converts only its row shard -- and, with the
+    quantile normalisation on, only its COLUMN shard of the transform, handed round in sub-blocks (runner.RowSource;
+    PRMF_INPUT_BLOCK_BYTES shrinks the sub-blocks so that this 100 x 1000 matrix takes several rounds).  The run must be the
+    reference's run of the delimited file (g6 goldens), and no rank may hold more than 1.5 x its share of float64 input."""
+    import re
+    import pandas as pd
+    g = np.load(os.path.join(golden_dir, "g6_%s.npz" % norm))
+    c = synth.cli_case(str(tmp_path), variant=1)
+    npy = str(tmp_path / "data.npy")
+    np.save(npy, c["X"])
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    env = dict(os.environ, PRMF_DIST_BACKEND="gloo", PRMF_SHARE_GPU="1", PRMF_INPUT_BLOCK_BYTES=str(32 << 10))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "script", "prmf_runner.py"), "--n-gpus", "3", "--data", npy, "--verbose",
+                        "--manifolds"] + c["manifolds"] + ["--node-attribute", "name", "--nodelist", c["nodelist"], "--outdir", out,
+                                                           "--seed", "1"] + (["--no-normalize"] if norm == "nonorm" else []),
+                       cwd=str(tmp_path), capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    peaks = {int(a): (int(lo), int(hi), float(mb)) for a, lo, hi, mb in
+             re.findall(r"rank (\d+): rows \[(\d+), (\d+)\) of 100 x 1000, peak ([0-9.]+) MB", r.stderr)}
+    assert sorted(peaks) == [0, 1, 2], r.stderr[-2000:]
+    for rank, (lo, hi, mb) in peaks.items():
+        share_mb = (hi - lo) * 1000 * 8 / 1e6
+        assert mb <= 1.5 * share_mb + 1e-9, (rank, mb, share_mb)
+    # "<iteration> <objective>" lines; --verbose also prints "<latent> <pathway>" pairs (two integers)
+    lines = [l for l in r.stdout.splitlines() if len(l.split()) == 2 and l.split()[0].isdigit() and "." in l.split()[1]]
+    trace = np.array([float(l.split()[1]) for l in lines])
+    vals, mapping = _read_obj(os.path.join(out, "obj.txt"))
+    U = pd.read_csv(os.path.join(out, "U.csv"))
+    V = pd.read_csv(os.path.join(out, "V.csv"), index_col=0)
+    eu, ev, et = rel(U.to_numpy(), g["U"]), rel(V.to_numpy(), g["V"]), relmax(trace, g["trace"][:len(trace)])
+    report("cli_rank_local_npy[%s]" % norm, iterations=len(trace), rel_trace=et, rel_U=eu, rel_V=ev,
+           peak_over_share=max(mb / ((hi - lo) * 8e-3) for lo, hi, mb in peaks.values()))
+    assert len(trace) == len(g["trace"]) and mapping == json.loads(str(g["mapping"]))
+    assert et < 1e-4 and eu < 1e-4 and ev < 1e-4

@@ -153,6 +153,17 @@ def test_pathway_library_cache_roundtrip(tmp_path):
         assert a.dtype == b.dtype and np.array_equal(a, b)
     v = np.random.RandomState(0).rand(300)
     assert all(got.laplacian_quadratic(p, v) == lib.laplacian_quadratic(p, v) for p in range(5))
+    # a name without the suffix is the same cache (np.savez would have appended '.npz' behind load's back), a truncated or
+    # corrupt archive is "no cache" (rebuilt), not a crash, and no temporary file is left behind
+    bare = str(tmp_path / "cache_without_suffix")
+    lib.save(bare, key="abc")
+    assert PathwayLibrary.load(bare, key="abc").names == lib.names and (tmp_path / "cache_without_suffix.npz").exists()
+    raw = open(fp, "rb").read()
+    open(fp, "wb").write(raw[:len(raw) // 2])
+    assert PathwayLibrary.load(fp, key="abc") is None
+    open(fp, "wb").write(b"not a zip archive")
+    assert PathwayLibrary.load(fp, key="abc") is None
+    assert sorted(x.name for x in tmp_path.iterdir()) == ["cache_without_suffix.npz", "lib.npz"]
 
 
 def test_fast_matching_equals_networkx():

@@ -18,12 +18,12 @@ eng.begin(U, V, 1.0, 1.0)
 for i in range(3):
     eng.phase_u(); eng.phase_q(); eng.phase_v(); eng.phase_post()
 torch.cuda.synchronize()
-st = torch.zeros(2 * 1024, dtype=torch.int64, device=dev)
+st = torch.zeros(8192, dtype=torch.int64, device=dev)   # [0, 2048): start/end stamps; [6144, 7168): HW ids
 eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()))
 for name, ph in (("X*V", eng.phase_u), ("X^T*U", eng.phase_q)):
     st.zero_(); torch.cuda.synchronize()
     ph(); torch.cuda.synchronize()
-    a = st.cpu().numpy().reshape(-1, 2); a = a[a[:, 1] > 0]
+    a = st.cpu().numpy()[:2048].reshape(-1, 2); a = a[a[:, 1] > 0]
     t0 = a[:, 0].min(); start = (a[:, 0] - t0) / 100.0; end = (a[:, 1] - t0) / 100.0   # microseconds
     print("%-6s WGs %d  start: p50 %.1f p90 %.1f max %.1f us | end: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f us | mean dur %.1f" % (
         name, len(a), np.percentile(start, 50), np.percentile(start, 90), start.max(), end.min(), np.percentile(end, 10), np.percentile(end, 50), np.percentile(end, 90), end.max(), (end - start).mean()))
@@ -40,7 +40,7 @@ eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()))
 for rep in range(4):
     st.zero_(); torch.cuda.synchronize()
     eng.phase_u(); torch.cuda.synchronize()
-    a = st.cpu().numpy().reshape(-1, 2)[:512]
+    a = st.cpu().numpy()[:2048].reshape(-1, 2)[:512]
     durs.append((a[:, 1] - a[:, 0]) / 100.0)
     eng.phase_q(); eng.phase_v(); eng.phase_post(); torch.cuda.synchronize()
 eng.lib.prmf_debug_set_stamps(None)
@@ -59,7 +59,7 @@ for rep in range(3):
     eng.phase_u(); torch.cuda.synchronize()
     st.zero_(); torch.cuda.synchronize()
     eng.phase_q(); torch.cuda.synchronize()
-    a = st.cpu().numpy().reshape(-1, 2)[:512]
+    a = st.cpu().numpy()[:2048].reshape(-1, 2)[:512]
     durs.append((a[:, 1] - a[:, 0]) / 100.0)
     eng.phase_v(); eng.phase_post(); torch.cuda.synchronize()
 eng.lib.prmf_debug_set_stamps(None)
