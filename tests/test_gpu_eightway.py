@@ -432,3 +432,73 @@ def test_direct_residual_decision_is_rank_invariant(mock, eps, steps, expect_dir
             own = math.sqrt(own0 + own1)
             assert abs(objs0[-1]["recon"] - own) < 1e-5 * own
         report("rank_invariant_direct_decision[%s-eps%g]" % (mode, eps), recon_sq_over_normx_sq=frac, flags=flags0[-1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# host-driven collectives between thread ranks (no RCCL at all): the group's own device-tensor exchanges on the GPU
+# ---------------------------------------------------------------------------------------------------------------------
+def _host_driven_case(k, tradeoff):
+    # with the feedback on: the problem of test_gpu_distributed.py::test_two_ranks_tradeoff_feedback (gamma grows 1e4-fold in
+    # five steps there; on a larger one the host-driven path's identity-based recon leaves gamma 1.007e-4 off after five)
+    if tradeoff is not None:
+        return synth.small_case(seed=23, m=301, n=800, k=k, P=4, order=60)
+    return synth.small_case(seed=13, m=301, n=1500, k=k, P=6, order=80)
+
+
+def _host_driven_worker(world, k, mode, tradeoff, q):
+    import torch
+    from prmf_amd import PathwayLibrary
+    from prmf_amd.distributed import DistributedPrmf
+    from prmf_amd.ranks import LocalRanks
+    from prmf_amd.solver import PrmfEngine
+    from prmf_amd.synthetic import shard_rows
+    case = _host_driven_case(k, tradeoff)
+    X = case["X"]
+
+    def body(view):
+        lo, hi = shard_rows(X.shape[0], view.world, view.rank)
+        eng = PrmfEngine(hi - lo, X.shape[1], k, x_dtype="f32", device=0, nranks=view.world, rank=view.rank, dist_mode=mode)
+        eng.set_x(X[lo:hi], norm_x_sq=float(np.sum(X * X)))
+        eng.set_library(PathwayLibrary.from_edge_lists(X.shape[1], case["pathways"]))
+        eng.set_active(np.arange(k) % len(case["pathways"]))
+        U = eng.device_tensor(case["U0"][lo:hi], torch.float32)
+        V = eng.device_tensor(case["V0"], torch.float32)
+        runner = DistributedPrmf(eng, group=view, native=False)
+        assert not runner.native and runner.coll is view
+        objs, gd = runner.step(U, V, 5, case["gamma"], case["delta"], tradeoff)
+        out = (view.gather_rows(torch, U, X.shape[0]), V.cpu().numpy(), objs, gd, eng.sizes.kc)
+        eng.close()
+        return out
+
+    q.put(LocalRanks(world, timeout_s=300).run(body))
+
+
+@pytest.mark.parametrize("world,k,mode,tradeoff", [(4, 3, "colshard", None), (4, 16, "replicated", None), (5, 13, "colshard", None),
+                                                  (4, 8, "colshard", 0.4)])
+def test_host_driven_thread_ranks_on_the_gpu(world, k, mode, tradeoff):
+    """The phase calls with the rank group's OWN exchanges in between (prmf_amd.ranks.LocalRankView: device tensors handed
+    between the threads, summed in rank order) -- no RCCL, no double: 4 ranks with k = 3 (a rank without a column), 5 ranks
+    with 301 samples (61- and 60-row shards), the tradeoff feedback -- against the oracle."""
+    import warnings
+    from oracle import prmf_oracle as orc
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = _in_worker(_host_driven_worker, (world, k, mode, tradeoff), {}, deadline_s=600)
+    U, V, objs, gd, kc = res[0]
+    for other in res[1:]:
+        assert np.array_equal(other[0], U) and np.array_equal(other[1], V) and other[2] == objs
+    assert kc == (k if mode == "replicated" else -(-k // world))
+    case = _host_driven_case(k, tradeoff)
+    pws = [orc.pathway_from_edges(case["X"].shape[1], e, nodes, w) for (e, w, nodes) in case["pathways"]]
+    act = [pws[i % len(pws)] for i in range(k)]
+    tr = []
+    if tradeoff is None:
+        Ur, Vr, od = orc.nmf_manifold_vec_update(case["X"], case["U0"], case["V0"], act, n_steps=5, gamma=case["gamma"], delta=case["delta"], trace=tr)
+    else:
+        Ur, Vr, od, g2, d2 = orc.nmf_manifold_vec_update_tradeoff(case["X"], case["U0"], case["V0"], act, n_steps=5, tradeoff=tradeoff,
+                                                                  gamma=case["gamma"], delta=case["delta"], trace=tr)
+        assert abs(gd[0] - g2) < 1e-4 * g2
+    eu, ev = rel(U, Ur), rel(V, Vr)
+    eo = max(relmax([o[key] for o in objs], [t[key] for t in tr]) for key in KEYS)
+    report("host_driven_thread_ranks[%d-%d-%s]" % (world, k, mode), rel_U=eu, rel_V=ev, rel_obj=eo)
+    assert eu < 1e-4 and ev < 1e-4 and eo < 1e-4
