@@ -160,6 +160,58 @@ def test_step_dist_four_and_eight_ranks_at_real_share_shapes(workload, variants,
             assert v < (tol if key in ("recon", "obj") else 1e-5), (world, mode, key, v)
 
 
+def _small_worker(world, k, x_dtype, mode, m, q):
+    import torch
+    from prmf_amd import PathwayLibrary
+    from prmf_amd.distributed import DistributedPrmf
+    from prmf_amd.ranks import LocalRanks
+    from prmf_amd.solver import PrmfEngine
+    from prmf_amd.synthetic import shard_rows
+    case = synth.small_case(seed=13, m=m, n=1500, k=k, P=6, order=80, bf16_x=(x_dtype == "bf16"))
+    X = case["X"]
+
+    def body(view):
+        lo, hi = shard_rows(X.shape[0], view.world, view.rank)
+        eng = PrmfEngine(hi - lo, X.shape[1], k, x_dtype=x_dtype, device=0, nranks=view.world, rank=view.rank, dist_mode=mode)
+        eng.set_x(X[lo:hi], norm_x_sq=float(np.sum(X * X)))
+        eng.set_library(PathwayLibrary.from_edge_lists(X.shape[1], case["pathways"]))
+        eng.set_active(np.arange(k) % 6)
+        U = eng.device_tensor(case["U0"][lo:hi], torch.float32)
+        V = eng.device_tensor(case["V0"], torch.float32)
+        objs, _ = DistributedPrmf(eng, group=view, native=True).step(U, V, 6, case["gamma"], case["delta"])
+        out = (U.cpu().numpy(), V.cpu().numpy(), objs, eng.sizes.kc, (eng.ctx is not None))
+        eng.close()
+        return out
+
+    q.put([LocalRanks(world, timeout_s=300).run(body) for _ in range(2)])      # twice: the sharded step is reproducible bit for bit
+
+
+@pytest.mark.parametrize("world,k,x_dtype,mode,m", [(8, 13, "bf16", "colshard", 700), (8, 13, "bf16", "replicated", 700), (8, 100, "f32", "colshard", 700),
+                                                    (8, 6, "f32", "colshard", 5), (6, 64, "bf16", "colshard", 333), (8, 128, "bf16", "replicated", 700)])
+def test_step_dist_eight_ranks_small_shapes_vs_oracle(mock, world, k, x_dtype, mode, m):
+    """Ragged everything on 8 (and 6) ranks through the in-library step: k = 13 (kc = 2: one rank with one column, one with
+    none), k = 100 and 128 (the column-split epilogues, kc = 13 / 16), 5 samples on 8 ranks (three ranks without rows),
+    87- and 88-row shards -- against the oracle, and run twice: bit-identical."""
+    from oracle import prmf_oracle as orc
+    runs = _in_worker(_small_worker, (world, k, x_dtype, mode, m), {"PRMF_RCCL_LIB": mock, "MOCK_RCCL_TIMEOUT_S": "60"}, deadline_s=600)
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    res = runs[0]
+    for other in res[1:]:
+        assert np.array_equal(other[1], res[0][1]) and other[2] == res[0][2]
+    assert res[0][3] == (k if mode == "replicated" else -(-k // world))
+    U = np.concatenate([r[0] for r in res])
+    case = synth.small_case(seed=13, m=m, n=1500, k=k, P=6, order=80, bf16_x=(x_dtype == "bf16"))
+    pws = [orc.pathway_from_edges(1500, e, nodes, w) for (e, w, nodes) in case["pathways"]]
+    tr = []
+    Ur, Vr, od = orc.nmf_manifold_vec_update(case["X"], case["U0"], case["V0"], [pws[i % 6] for i in range(k)], n_steps=6,
+                                             gamma=case["gamma"], delta=case["delta"], trace=tr)
+    eu, ev = rel(U, Ur), rel(res[0][1], Vr)
+    eo = max(relmax([o[key] for o in res[0][2]], [t[key] for t in tr]) for key in KEYS)
+    report("step_dist_small_shapes[%d-%d-%s-%s-m%d]" % (world, k, x_dtype, mode, m), rel_U=eu, rel_V=ev, rel_obj=eo)
+    assert eu < 1e-4 and ev < 1e-4 and eo < 1e-4
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # (b) nmf_pathway / the CLI on 8 ranks: k = 6 on 8 ranks (ranks 6 and 7 own no latent column), 100 samples (13- and
 #     12-row shards)
