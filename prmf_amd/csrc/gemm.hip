@@ -370,6 +370,15 @@ constexpr bool LOADS_FIRST = PRMF_LOADS_FIRST != 0;
 // overlaps a wave's load burst with MFMAs) 2.214 -> 2.059 ms; the 4-wave form (two workgroups per CU that alternate
 // phases by themselves) 2.132 -> 2.319 ms, 25000 x 25000 equal -- hence the 8-wave form only.
 template <int NW> struct Sprinkle { static constexpr bool value = PRMF_SPRINKLE != 0 && (PRMF_SPRINKLE == NW || PRMF_SPRINKLE == 1); };
+#ifndef PRMF_PP
+#define PRMF_PP 0             // 1: the 8-wave bf16 sweeps from PRMF_PP_MIN_NT column tiles up run the ping-pong chunk loop (see the kernel)
+#endif
+#ifndef PRMF_PP_MIN_NT
+#define PRMF_PP_MIN_NT 3
+#endif
+#ifndef PRMF_PP_MAX_FACTOR_MB
+#define PRMF_PP_MAX_FACTOR_MB 0   // > 0: only plans whose packed factor is smaller than this
+#endif
 #ifndef PRMF_TAIL_PROBE
 #define PRMF_TAIL_PROBE 0     // 1: the hand-off probe behind the segments loop is compiled in (it costs the kernels 2 registers)
 #endif
@@ -423,7 +432,7 @@ __device__ __forceinline__ void store_b_chunk(u32x4* sb, const u32x4 (&src)[NB],
 // BDB = false: B single-buffered, two barriers per chunk, 16*NT KiB less LDS per
 //              workgroup -> more resident workgroups (bytes in flight) per CU
 // The chunk loop is unrolled x2 with compile-time LDS buffer offsets; a segment may have any number of chunks.
-template <int MODE, int MT, int NT, int NW, bool BDB>
+template <int MODE, int MT, int NT, int NW, bool BDB, bool PP = false>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : PRMF_SWEEP_MINW)   // two workgroups of 4 waves per CU, or one of 8: at most 256 registers (arch + accumulator) per wave
 sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B units */, int64_t M_store,
              const uint4* __restrict__ Bp, int npanels, int g_begin, int ngroups /* work units (UNIT chunks each) [g_begin, g_begin+ngroups) of every row */,
@@ -558,6 +567,81 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int i = 0; i < 4; ++i) myA[mt * 256 + i * 64 + lane] = a[mt][i];
+  if constexpr (PP) {
+    // ---- PING-PONG chunk loop (8 waves, one workgroup per CU; round 4) ------------------------------------------------
+    // The two waves of a SIMD belong to the same workgroup and used to run the same phase at the same time: while both
+    // waited for their loads, wrote LDS and met at the barrier the matrix pipe idled (k = 128: 65 % MFMA-busy).  Here the
+    // workgroup is two halves -- waves 0-3 (H0) and 4-7 (H1), one wave of each per SIMD -- half a chunk apart:
+    //     slot 2c    : H0 COMPUTE(c) [its loads for chunk c + 1 go out between the MFMA steps]   | H1 STAGE
+    //     slot 2c + 1: H0 STAGE: wait, A(c + 1) -> its tile, its half of B(c + 1) -> buffer (c+1)&1 | H1 COMPUTE(c)
+    // so that exactly one wave per SIMD is in its MFMA phase at any time.  Every slot ends at one workgroup barrier
+    // (H1 takes one extra barrier in front of its loop, H0 one behind: equal counts).  The factor chunk stays
+    // double-buffered: H0 stages its slice of B(c + 1) in slot 2c + 1, H1 its slice of B(c + 2) in slot 2c + 2 (H1 loads
+    // the factor two chunks ahead, its slice of B(1) in the segment prologue); buffer (c+1)&1 was last read in slot
+    // 2c - 1 (H1's COMPUTE(c - 1)), buffer c&1 in slot 2c + 1 (H1's COMPUTE(c)): nobody overwrites what is being read.
+    constexpr int STEPS = SweepSteps<MODE, NT>::value;
+    static_assert(NW == 8 && BDB && STEPS > 0 && UNIT == 2, "ping-pong: the 8-wave double-buffered form, an even number of chunks per segment");
+    const int half = __builtin_amdgcn_readfirstlane(wave >> 2);
+    if (half == 1) {      // H1's slice of B(1)
+      load_b_chunk<BPT, NTHR, BCH>(bs, B_CHUNK_AT(nch > 1 ? 1 : 0), tid);
+      store_b_chunk<BPT, NTHR, BCH>(sB[1], bs, tid);
+    }
+    // PRMF_PP == 2: the loads do not go out between the MFMA steps of COMPUTE but at the END of STAGE, straight after the
+    // registers they land in have been written to LDS -- one chunk further ahead (A(c + 2); the factor slice c + 2 / c + 3),
+    // in flight through the barrier, the whole COMPUTE slot and the next STAGE's wait: a wave's 12 KiB are on their way
+    // practically all the time instead of from the middle of its COMPUTE to its STAGE, and the wave that queues them is the
+    // one that has no MFMAs to issue.
+    constexpr bool LOADS_IN_STAGE = PRMF_PP == 2;
+    auto issue_loads = [&](int ca, int cb) {
+      load_b_chunk<BPT, NTHR, BCH>(bs, B_CHUNK_AT(cb), tid);
+      load_a_chunk<MT>(a, avoff, abase + (int64_t)ca * 8);
+    };
+    if constexpr (LOADS_IN_STAGE) issue_loads(nch > 1 ? 1 : 0, 1 + half < nch ? 1 + half : nch - 1);
+    __syncthreads();
+    if (half == 1) __syncthreads();      // H1 starts one slot later
+    constexpr int NLD = BPT + 4 * MT, LPS = PRMF_SPRINKLE_LPS * STEPS >= NLD ? PRMF_SPRINKLE_LPS : (NLD + STEPS - 1) / STEPS;
+    for (int c = 0; c < nch; c += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int cc = c + u;                                           // < nch: a segment is whole units of two chunks
+        const int ca = cc + 1 < nch ? cc + 1 : cc;                      // the last chunk re-loads itself (no branch around loads)
+        const int cb = cc + 1 + half < nch ? cc + 1 + half : nch - 1;
+        const u32x4* const bnext = reinterpret_cast<const u32x4*>(B_CHUNK_AT(cb));
+        const char* const anext = reinterpret_cast<const char*>(abase + (int64_t)ca * 8);
+        auto hook = [&](int j) {
+          if constexpr (LOADS_IN_STAGE) return;
+#pragma unroll
+          for (int q = 0; q < LPS; ++q) {
+            const int li = j * LPS + q;
+            if (li < BPT) {
+              if ((li + 1) * NTHR <= BCH || tid + NTHR * li < BCH) bs[li] = bnext[tid + NTHR * li];
+            } else if (li < NLD) {
+              const u32x4* src = reinterpret_cast<const u32x4*>(anext + avoff[(li - BPT) / 4][(li - BPT) % 4]);
+              a[(li - BPT) / 4][(li - BPT) % 4] = NT_LOADS ? __builtin_nontemporal_load(src) : *src;
+            }
+          }
+        };
+#if PRMF_SWEEP_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+        sweep_compute<MODE, MT, NT>(acc, acc_lo, myA, sB[u], lane, hook);
+#if PRMF_SWEEP_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                                // end of this half's COMPUTE slot
+        store_b_chunk<BPT, NTHR, BCH>(half == 0 ? sB[u ^ 1] : sB[u], bs, tid);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) myA[mt * 256 + i * 64 + lane] = a[mt][i];
+        if constexpr (LOADS_IN_STAGE)       // the next-but-one chunk (clamped to the segment: the last ones re-load the last chunk)
+          issue_loads(cc + 2 < nch ? cc + 2 : nch - 1, cc + 2 + half < nch ? cc + 2 + half : nch - 1);
+        __syncthreads();                                                // end of this half's STAGE slot
+      }
+    }
+    if (half == 0) __syncthreads();      // H0 waits for H1's last slot: the halves leave the segment together
+  } else {
   __syncthreads();
 
   // The chunk loop is unrolled x2 so that the LDS buffer offsets are compile-time constants; it handles any number of
@@ -646,6 +730,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
       }
     }
   }
+  }   // !PP
 
   // epilogue: the accumulators go out in FRAGMENT order -- slab[seg][tile32][t][q4][lane][4 floats]: every
   // store instruction writes 1 KiB contiguous (whole 128-B lines), non-temporal (the slab is read next by
@@ -811,6 +896,7 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
   if (NT >= 2 && factor_bytes >= SWEEP_WIDE_SMALL_FACTOR_BYTES) {
     p.nw = SWEEP_NW_WIDE;
     p.bdb = true;
+    p.pp = PRMF_PP != 0 && x_dtype == 1 && NT >= PRMF_PP_MIN_NT && (PRMF_PP_MAX_FACTOR_MB <= 0 || factor_bytes < PRMF_PP_MAX_FACTOR_MB * 1048576.0);
   }
   p.panel_rows = p.nw * 32 * p.mt;
   p.panels = (int)(round_up(M, p.panel_rows) / p.panel_rows);
@@ -909,24 +995,35 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
   // dynamic LDS only for the 8-wave shape (see the kernel).  More than 64 KiB of it needs the function attribute raised
   // on the device once: prmf_create does that for the context's two plans (attr_only) -- no state is kept here.
   const size_t dyn = NW == 8 ? (size_t)((BDB ? 2 : 1) * (MODE == 1 ? 512 : 256) * NT + NW * MTV * 256) * 16 : 0;
-#define PRMF_LAUNCH(NTV)                                                                                       \
+#define PRMF_LAUNCH_PP(NTV, PPV)                                                                               \
   if (attr_only) {                                                                                             \
     if (dyn <= 64 * 1024) return hipSuccess;                                                                   \
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<MODE, MTV, NTV, NW, BDB>),           \
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<MODE, MTV, NTV, NW, BDB, PPV>),      \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                          \
   }                                                                                                            \
-  sweep_kernel<MODE, MTV, NTV, NW, BDB><<<dim3(p.grid), dim3(64 * NW), dyn, s>>>(                                \
+  sweep_kernel<MODE, MTV, NTV, NW, BDB, PPV><<<dim3(p.grid), dim3(64 * NW), dyn, s>>>(                           \
       (const uint4*)A, lda16, M_store, (const uint4*)Bp, p.panels, 0, p.ngroups, p.nx, p.pmax, 0, slabs, slab_stride, \
       p.slab_nt ? 1 : 0, g_sweep_stamps, pro, (&p == g_tail_plan) ? g_tail_probe : nullptr, (&p == g_tail_plan) ? g_tail_launch++ : 0)
+#define PRMF_LAUNCH(NTV) PRMF_LAUNCH_PP(NTV, false)
+  // the ping-pong chunk loop exists for bf16 X in the 8-wave form (plan_gemm decides: p.pp)
+#define PRMF_LAUNCH_8W(NTV)                                                    \
+  do {                                                                         \
+    if constexpr (PRMF_PP != 0 && MODE == 1 && NTV >= PRMF_PP_MIN_NT) {        \
+      if (p.pp) { PRMF_LAUNCH_PP(NTV, true); } else { PRMF_LAUNCH_PP(NTV, false); } \
+    } else {                                                                   \
+      if (p.pp) return hipErrorInvalidValue;                                   \
+      PRMF_LAUNCH_PP(NTV, false);                                              \
+    }                                                                          \
+  } while (0)
   if constexpr (NW == 8) {
     // bf16 X: k > 32; f32 X: k = 33..64 with 64-row wave tiles, k > 64 with 32-row ones (f32_wave_tiles)
     constexpr bool K64 = MODE == 1 || MTV == SWEEP_MT, KWIDE = MODE == 1 || MTV == 1;
     if (NT == 2) {
-      if constexpr (K64) { PRMF_LAUNCH(2); } else return hipErrorInvalidValue;
+      if constexpr (K64) { PRMF_LAUNCH_8W(2); } else return hipErrorInvalidValue;
     } else if (NT == 3) {
-      if constexpr (KWIDE) { PRMF_LAUNCH(3); } else return hipErrorInvalidValue;
+      if constexpr (KWIDE) { PRMF_LAUNCH_8W(3); } else return hipErrorInvalidValue;
     } else if (NT == 4) {
-      if constexpr (KWIDE) { PRMF_LAUNCH(4); } else return hipErrorInvalidValue;
+      if constexpr (KWIDE) { PRMF_LAUNCH_8W(4); } else return hipErrorInvalidValue;
     } else {
       return hipErrorInvalidValue;
     }
@@ -944,6 +1041,8 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
     }
   }
 #undef PRMF_LAUNCH
+#undef PRMF_LAUNCH_8W
+#undef PRMF_LAUNCH_PP
   return hipGetLastError();
 }
 

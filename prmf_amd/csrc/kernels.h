@@ -113,6 +113,7 @@ struct GemmPlan {
   int nw = 8;               // waves per workgroup
   int mt = 1;               // 32-row tiles per wave
   bool bdb = true;          // packed factor double-buffered in LDS
+  bool pp = false;          // 8-wave form: the two waves of a SIMD half a chunk apart (ping-pong chunk loop, gemm.hip)
   int panel_rows = 0;       // rows per panel (= rows of one workgroup tile)
   int panels = 0;           // row panels
   int nchunks = 0;          // reduction chunks per row (even)
