@@ -42,7 +42,7 @@ int prmf_debug_swap(prmf_ctx* a, prmf_ctx* b, int which);
 /* The sweep planner's decision for one sweep C = A (rows x depth) * packed factor (depth x k) -- pure host arithmetic, no GPU
  * touched (the CPU test suite pins the plan of every benchmark shape with it).  x_dtype as in prmf_create; n_cus = compute
  * units of the device (256 on MI355X).  out[8] = { waves per workgroup, 32-row tiles per wave, panel rows, workgroups,
- * reduction slices, slabs per panel (upper bound), factor chunk double-buffered (0 | 1), panels }. */
+ * reduction slices, slabs per panel (upper bound), bit 0: factor chunk double-buffered, bit 1: ping-pong chunk loop, panels }. */
 int prmf_debug_plan_sweep(int x_dtype, long long rows, long long depth, int k, int n_cus, int* out);
 
 /* Calibration: a pure stream of the resident matrix (which = 0: the padded copy of X, 1: of X^T) -- one workgroup per

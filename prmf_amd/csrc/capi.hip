@@ -1443,7 +1443,7 @@ int prmf_debug_plan_sweep(int x_dtype, long long rows, long long depth, int k, i
   if (!out || rows < 0 || depth < 1 || k < 1 || k > 128 || n_cus < 1 || (x_dtype != PRMF_X_F32 && x_dtype != PRMF_X_BF16)) return PRMF_ERR_ARG;
   const int NT = (k + 31) / 32;
   const GemmPlan p = plan_gemm(x_dtype, rows > 0 ? rows : 1, round_up(depth, K_PAD), NT, n_cus, SweepTuning{});
-  const int v[8] = {p.nw, p.mt, p.panel_rows, p.grid, p.nx, p.max_seg, p.bdb ? 1 : 0, p.panels};
+  const int v[8] = {p.nw, p.mt, p.panel_rows, p.grid, p.nx, p.max_seg, (p.bdb ? 1 : 0) | (p.pp ? 2 : 0), p.panels};
   for (int i = 0; i < 8; ++i) out[i] = v[i];
   return PRMF_OK;
 }

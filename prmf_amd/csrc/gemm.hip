@@ -371,13 +371,25 @@ constexpr bool LOADS_FIRST = PRMF_LOADS_FIRST != 0;
 // phases by themselves) 2.132 -> 2.319 ms, 25000 x 25000 equal -- hence the 8-wave form only.
 template <int NW> struct Sprinkle { static constexpr bool value = PRMF_SPRINKLE != 0 && (PRMF_SPRINKLE == NW || PRMF_SPRINKLE == 1); };
 #ifndef PRMF_PP
-#define PRMF_PP 0             // 1: the 8-wave bf16 sweeps from PRMF_PP_MIN_NT column tiles up run the ping-pong chunk loop (see the kernel)
+#define PRMF_PP 1             // 1: the 8-wave bf16 sweeps of PRMF_PP_MIN_NT..PRMF_PP_MAX_NT column tiles run the ping-pong chunk loop (see the
+                              // kernel); 2: the same with the loads issued at the end of STAGE (k = 128: spills, 2.4x slower); 0: off.
+                              // Same-session A/B (profiles/r04_ab_pingpong_k64.txt): C3 X V -2.5 %, X^T U -5.5 %, iteration -3.3 %; its
+                              // two-rank share -5.9 %; k > 64 equal (profiles/r04_ab_k128_pingpong.txt), f32 X +2.8 % -- hence bf16, k = 33..64 only
 #endif
 #ifndef PRMF_PP_MIN_NT
-#define PRMF_PP_MIN_NT 3
+#define PRMF_PP_MIN_NT 2      // column tiles from / up to which the 8-wave sweeps take the ping-pong loop
 #endif
-#ifndef PRMF_PP_MAX_FACTOR_MB
-#define PRMF_PP_MAX_FACTOR_MB 0   // > 0: only plans whose packed factor is smaller than this
+#ifndef PRMF_PP_MAX_NT
+#define PRMF_PP_MAX_NT 2
+#endif
+#ifndef PRMF_PP_F32
+#define PRMF_PP_F32 0         // 1: f32 X (three-piece split) too
+#endif
+#ifndef PRMF_PP_WIDE_MB
+#define PRMF_PP_WIDE_MB 4.0   // a ping-pong plan takes the 8-wave form from this factor size (instead of PRMF_WIDE_SMALL_MB) ...
+#endif
+#ifndef PRMF_PP_WIDE_MIN_ROWS
+#define PRMF_PP_WIDE_MIN_ROWS 16384   // ... when the matrix has at least this many rows (enough 512-row panels)
 #endif
 #ifndef PRMF_TAIL_PROBE
 #define PRMF_TAIL_PROBE 0     // 1: the hand-off probe behind the segments loop is compiled in (it costs the kernels 2 registers)
@@ -860,6 +872,8 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 //   4 waves x 64 rows (MT = 2), two workgroups per CU;
 //   k <= 64: factor chunk double-buffered in LDS (32 KiB of A tiles + 2 x 8 NT KiB), one barrier per chunk;
 //   k  > 64: factor chunk single-buffered (k = 128: 32 + 32 KiB, 116 VGPRs + 128 accumulator registers), two barriers.
+//   bf16 X, k = 33..64, packed factor >= 4 MB and >= 16384 rows (round 4): the 8-wave form with the PING-PONG chunk loop (its two
+//   waves per SIMD half a chunk apart; see the kernel) -- both sweeps of 50000 x 20000 run it.
 //   bf16 X, k > 64, packed factor >= 32 MB (round 3): ONE workgroup of 8 waves x 64 rows per CU with the factor chunk
 //   double-buffered (64 KiB of A tiles + 2 x 32 KiB at k = 128, dynamic LDS), one barrier per chunk.  Same-session A/B
 //   (profiles/r03_ab_k128_8wave_double_buffer.txt): X^T U of 200000 x 25000 (102 MB factor, re-read from the Infinity
@@ -870,7 +884,10 @@ constexpr int SWEEP_NW = 4, SWEEP_MT = 2, SWEEP_WGS_PER_CU = 2, SWEEP_NW_WIDE = 
 #define PRMF_WIDE_MB 32.0
 #endif
 constexpr double SWEEP_WIDE_FACTOR_BYTES = PRMF_WIDE_MB * 1024 * 1024;
-constexpr double SWEEP_WIDE_SMALL_FACTOR_BYTES = 8.0 * 1024 * 1024;      // the 8-wave form from this factor size up (unsliced below the 32 MB)
+#ifndef PRMF_WIDE_SMALL_MB
+#define PRMF_WIDE_SMALL_MB 8.0
+#endif
+constexpr double SWEEP_WIDE_SMALL_FACTOR_BYTES = PRMF_WIDE_SMALL_MB * 1024 * 1024;      // the 8-wave form from this factor size up (unsliced below the 32 MB)
 
 // 32-row tiles per wave.  bf16 X: 2 at every k.  f32 X (three-piece split, two accumulator sets): 2 at k = 33..64; 1 at
 // k > 64, where two do not fit 256 registers, and at k <= 32, where the 128-row panels measure 4% faster on the
@@ -893,10 +910,12 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
   // 0.8325 ms, 7 of 7 interleaved rounds; with 2 slices it is slower than the 4-wave form.
   // f32 X too (three-piece split; hook per 16-column tile): X^T U at the C3 shape 0.777 -> 0.745 ms, the N = 8 share of C5
   // 0.725 / 0.715 -> 0.711 / 0.705 ms -- unsliced; with the 4 slices of the 4-wave form it had measured equal.
-  if (NT >= 2 && factor_bytes >= SWEEP_WIDE_SMALL_FACTOR_BYTES) {
+  const bool pp_ok = PRMF_PP != 0 && (x_dtype == 1 || (PRMF_PP_F32 != 0 && NT == 2)) && NT >= PRMF_PP_MIN_NT && NT <= PRMF_PP_MAX_NT;
+  const double wide_from = (pp_ok && M >= PRMF_PP_WIDE_MIN_ROWS) ? PRMF_PP_WIDE_MB * 1024 * 1024 : SWEEP_WIDE_SMALL_FACTOR_BYTES;
+  if (NT >= 2 && factor_bytes >= wide_from) {
     p.nw = SWEEP_NW_WIDE;
     p.bdb = true;
-    p.pp = PRMF_PP != 0 && x_dtype == 1 && NT >= PRMF_PP_MIN_NT && (PRMF_PP_MAX_FACTOR_MB <= 0 || factor_bytes < PRMF_PP_MAX_FACTOR_MB * 1048576.0);
+    p.pp = pp_ok;
   }
   p.panel_rows = p.nw * 32 * p.mt;
   p.panels = (int)(round_up(M, p.panel_rows) / p.panel_rows);
@@ -1008,7 +1027,7 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
   // the ping-pong chunk loop exists for bf16 X in the 8-wave form (plan_gemm decides: p.pp)
 #define PRMF_LAUNCH_8W(NTV)                                                    \
   do {                                                                         \
-    if constexpr (PRMF_PP != 0 && MODE == 1 && NTV >= PRMF_PP_MIN_NT) {        \
+    if constexpr (PRMF_PP != 0 && (MODE == 1 || (PRMF_PP_F32 != 0 && NTV == 2)) && NTV >= PRMF_PP_MIN_NT && NTV <= PRMF_PP_MAX_NT) { \
       if (p.pp) { PRMF_LAUNCH_PP(NTV, true); } else { PRMF_LAUNCH_PP(NTV, false); } \
     } else {                                                                   \
       if (p.pp) return hipErrorInvalidValue;                                   \

@@ -79,13 +79,20 @@ def test_sweep_plans_of_the_benchmark_shapes():
         keys = ("waves", "tiles_per_wave", "panel_rows", "grid", "slices", "max_slabs", "double_buffered", "panels")
         return dict(zip(keys, list(out)))
 
-    # C3 50000 x 20000, k = 64, bf16: X V (5.1 MB factor) in the 4-wave form, unsliced; X^T U (12.8 MB) in the 8-wave form, unsliced
+    # C3 50000 x 20000, k = 64, bf16 (round 4): BOTH sweeps in the 8-wave form with the ping-pong chunk loop, unsliced -- X V (5.1 MB
+    # factor: >= 4 MB and >= 16384 rows) and X^T U (12.8 MB); "double_buffered" carries the ping-pong flag in bit 1
     xv, xtu = plan(BF16, 50000, 20000, 64), plan(BF16, 20000, 50000, 64)
-    assert (xv["waves"], xv["panel_rows"], xv["grid"], xv["slices"], xv["panels"]) == (4, 256, 512, 1, 196)
-    assert (xtu["waves"], xtu["panel_rows"], xtu["grid"], xtu["slices"], xtu["panels"]) == (8, 512, 256, 1, 40)
-    # the same shape with f32 X: the same forms (64-row wave tiles at k = 33..64)
+    assert (xv["waves"], xv["panel_rows"], xv["grid"], xv["slices"], xv["panels"], xv["double_buffered"]) == (8, 512, 256, 1, 98, 3)
+    assert (xtu["waves"], xtu["panel_rows"], xtu["grid"], xtu["slices"], xtu["panels"], xtu["double_buffered"]) == (8, 512, 256, 1, 40, 3)
+    # the same shape with f32 X: X V 4-wave, X^T U 8-wave, no ping-pong (64-row wave tiles at k = 33..64)
     xv, xtu = plan(F32, 50000, 20000, 64), plan(F32, 20000, 50000, 64)
-    assert (xv["waves"], xv["tiles_per_wave"], xv["slices"]) == (4, 2, 1) and (xtu["waves"], xtu["tiles_per_wave"], xtu["slices"]) == (8, 2, 1)
+    assert (xv["waves"], xv["tiles_per_wave"], xv["slices"], xv["double_buffered"]) == (4, 2, 1, 1)
+    assert (xtu["waves"], xtu["tiles_per_wave"], xtu["slices"], xtu["double_buffered"]) == (8, 2, 1, 1)
+    # the two- and four-rank shares of C3: 25000 rows take the ping-pong form for X V, 12500 rows (< 16384) keep the 4-wave one
+    assert (plan(BF16, 25000, 20000, 64)["waves"], plan(BF16, 25000, 20000, 64)["double_buffered"]) == (8, 3)
+    assert (plan(BF16, 12500, 20000, 64)["waves"], plan(BF16, 12500, 20000, 64)["double_buffered"]) == (4, 1)
+    # k > 64: no ping-pong (measured equal: profiles/r04_ab_k128_pingpong.txt)
+    assert plan(BF16, 200000, 25000, 128)["double_buffered"] == 1
     # C5 200000 x 25000, k = 128, bf16: both sweeps 8-wave; X V (12.8 MB) unsliced, X^T U (102 MB) sliced
     xv, xtu = plan(BF16, 200000, 25000, 128), plan(BF16, 25000, 200000, 128)
     assert (xv["waves"], xv["slices"], xv["double_buffered"], xv["panels"]) == (8, 1, 1, 391)
