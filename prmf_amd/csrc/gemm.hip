@@ -954,7 +954,10 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
     // 100000 / 200000 rows x 25000 genes, k = 128 (12.8 MB factor): 0.3215 -> 0.3162, 0.5798 -> 0.5701, 1.127 -> 1.050,
     // 2.166 -> 2.083 ms (and 2.108 in the 4-wave form with 4 slices); from 51 MB up the slices stay (X^T U of 100000
     // samples 1.066 against 1.085 ms unsliced; 200000 samples equal).  profiles/r03_ab_sprinkled_loads.txt.
-    if (p.nw == SWEEP_NW_WIDE && factor_bytes < SWEEP_WIDE_FACTOR_BYTES) p.nx = 1;
+#ifndef PRMF_WIDE_KEEP_SLICES
+#define PRMF_WIDE_KEEP_SLICES 0     // experiment: 1 = an 8-wave plan keeps the two slices a 4-7 MB factor gets on short shares
+#endif
+    if (p.nw == SWEEP_NW_WIDE && factor_bytes < SWEEP_WIDE_FACTOR_BYTES && !(PRMF_WIDE_KEEP_SLICES && p.nx == 2 && factor_bytes < 7.0 * 1048576)) p.nx = 1;
     if (tune.force_slices == 1 || tune.force_slices == 2 || tune.force_slices == 4 || tune.force_slices == 8) p.nx = tune.force_slices;
   }
   if (G < 1) G = 1;
