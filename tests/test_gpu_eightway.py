@@ -314,6 +314,25 @@ def test_bench_eight_rank_rehearsal(mock):
     report("bench_eight_rank_rehearsal", recon_err=line["recon_err"], ms_per_step_shared_gpu=line["ms_per_step"])
 
 
+def test_bench_under_the_process_launcher(mock):
+    """The driver's launch line for N > 1 -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` -- with
+    four process ranks sharing the GPU (gloo for torch.distributed, the in-library step through the double): rank 0's
+    one JSON line, ranks = processes, the communicator the double reports, max-over-ranks timing."""
+    port = 29500 + (os.getpid() % 400)
+    env = dict(os.environ, PRMF_RCCL_LIB=mock, PRMF_BENCH_BACKEND="gloo", PRMF_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "c2", "--steps", "6",
+                        "--warmup", "2", "--reps", "2"], cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 alone prints
+    line = json.loads(lines[0])
+    d = line["distributed"]
+    assert line["n_gpus"] == 4 and d["rccl_comm_world_size"] == 4 and "processes" in d["ranks_are"] and d["collectives"].startswith("in-library")
+    assert line["scaling"] == "strong" and line["value"] > 0 and math.isfinite(line["recon_err"]) and "cpu_baseline" not in line
+    report("bench_process_launcher_rehearsal", recon_err=line["recon_err"], ms_per_step_shared_gpu=line["ms_per_step"])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # (d) a collective fails
 # ---------------------------------------------------------------------------------------------------------------------
