@@ -300,6 +300,7 @@ static GraphJob graph_job(const prmf_ctx* c) {
   gj.active = c->active_dev;
   gj.col0 = c->col0;
   gj.ncols = c->ncols;
+
   gj.nsplit = graph_job_split(c->lib.max_support);
   gj.V = c->V;
   gj.hyper = c->hyper;
