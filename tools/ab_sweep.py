@@ -16,7 +16,10 @@ res = {}
 for rnd in range(rounds):
     for wl in workloads:
         for name, path in variants:
+            # a variant may carry environment settings behind its library:  name=lib.so:PRMF_SWEEP_LDX=64:OTHER=1
+            path, *extra = path.split(":")
             env = dict(os.environ, PRMF_HIP_LIB=os.path.join(ROOT, path), WORKLOAD=wl)
+            env.update(kv.split("=", 1) for kv in extra)
             r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_knobs.py")], env=env, capture_output=True, text=True)
             m = re.search(r"xv ([0-9.]+) ms .* xtu ([0-9.]+) ms .* iteration ([0-9.]+) ms", r.stdout)
             if not m:
