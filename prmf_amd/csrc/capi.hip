@@ -645,7 +645,6 @@ int prmf_set_x(prmf_ctx* c, const void* dX, int64_t ld, double norm_x_sq, void* 
   hipStream_t s = (hipStream_t)stream;
   const int eb = elem_bytes(c->x_dtype);
   const int64_t rows_x = round_up(c->m > 0 ? c->m : 1, M_PAD), rows_xt = round_up(c->n, M_PAD);
-  // row stride = padded reduction length (extra padding of the stride was measured: no effect)
   // row stride = padded reduction length.  Extra padding between the rows (128 B ... 2 KiB, either copy) was measured again in
   // round 4 against the ping-pong sweeps: no effect (profiles/r04_ab_row_stride_padding.txt; one 3-round A/B that showed -2.7 % did
   // not repeat over 5 rounds in separate processes -- buffer placement, not the stride)
