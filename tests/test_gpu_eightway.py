@@ -318,7 +318,11 @@ def test_bench_under_the_process_launcher(mock):
     """The driver's launch line for N > 1 -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` -- with
     four process ranks sharing the GPU (gloo for torch.distributed, the in-library step through the double): rank 0's
     one JSON line, ranks = processes, the communicator the double reports, max-over-ranks timing."""
-    port = 29500 + (os.getpid() % 400)
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
     env = dict(os.environ, PRMF_RCCL_LIB=mock, PRMF_BENCH_BACKEND="gloo", PRMF_BENCH_SHARE_GPU="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "c2", "--steps", "6",
