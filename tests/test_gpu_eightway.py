@@ -160,7 +160,7 @@ def test_step_dist_four_and_eight_ranks_at_real_share_shapes(workload, variants,
             assert v < (tol if key in ("recon", "obj") else 1e-5), (world, mode, key, v)
 
 
-def _small_worker(world, k, x_dtype, mode, m, q):
+def _small_worker(world, k, x_dtype, mode, m, q, tradeoff=None, steps=6):
     import torch
     from prmf_amd import PathwayLibrary
     from prmf_amd.distributed import DistributedPrmf
@@ -178,8 +178,8 @@ def _small_worker(world, k, x_dtype, mode, m, q):
         eng.set_active(np.arange(k) % 6)
         U = eng.device_tensor(case["U0"][lo:hi], torch.float32)
         V = eng.device_tensor(case["V0"], torch.float32)
-        objs, _ = DistributedPrmf(eng, group=view, native=True).step(U, V, 6, case["gamma"], case["delta"])
-        out = (U.cpu().numpy(), V.cpu().numpy(), objs, eng.sizes.kc, (eng.ctx is not None))
+        objs, gd = DistributedPrmf(eng, group=view, native=True).step(U, V, steps, case["gamma"], case["delta"], tradeoff)
+        out = (U.cpu().numpy(), V.cpu().numpy(), objs, eng.sizes.kc, (gd, list(eng.last_flags)))
         eng.close()
         return out
 
@@ -210,6 +210,37 @@ def test_step_dist_eight_ranks_small_shapes_vs_oracle(mock, world, k, x_dtype, m
     eo = max(relmax([o[key] for o in res[0][2]], [t[key] for t in tr]) for key in KEYS)
     report("step_dist_small_shapes[%d-%d-%s-%s-m%d]" % (world, k, x_dtype, mode, m), rel_U=eu, rel_V=ev, rel_obj=eo)
     assert eu < 1e-4 and ev < 1e-4 and eo < 1e-4
+
+
+def _small_tradeoff_worker(world, k, mode, m, steps, q):
+    _small_worker(world, k, "f32", mode, m, q, tradeoff=0.4, steps=steps)
+
+
+# (five samples: gamma runs away in the reference itself -- 1.8e44 at step 6, beyond float32 -- so three steps there)
+@pytest.mark.parametrize("world,k,mode,m,steps", [(8, 8, "colshard", 301, 6), (8, 8, "replicated", 5, 3)])
+def test_tradeoff_feedback_on_eight_ranks(mock, world, k, mode, m, steps):
+    """gamma = delta = (1 - t) recon / (t manifold) (prmf_runner.py:542-548) through the in-library step on 8 ranks: every
+    record from the direct residual -- each rank's sum (X_g - U_g V^T)^2 all-reduced every iteration, ranks without rows
+    (5 samples on 8 ranks) contributing zero -- against the oracle's tradeoff loop; run twice: bit-identical."""
+    from oracle import prmf_oracle as orc
+    runs = _in_worker(_small_tradeoff_worker, (world, k, mode, m, steps), {"PRMF_RCCL_LIB": mock, "MOCK_RCCL_TIMEOUT_S": "60"}, deadline_s=600)
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[4] == b[4]
+    res = runs[0]
+    for other in res[1:]:
+        assert np.array_equal(other[1], res[0][1]) and other[2] == res[0][2] and other[4] == res[0][4]
+    gd, flags = res[0][4]
+    assert all(f & 1 for f in flags), flags                       # PRMF_RECON_DIRECT on every record
+    U = np.concatenate([r[0] for r in res])
+    case = synth.small_case(seed=13, m=m, n=1500, k=k, P=6, order=80)
+    pws = [orc.pathway_from_edges(1500, e, nodes, w) for (e, w, nodes) in case["pathways"]]
+    tr = []
+    Ur, Vr, od, g_ref, d_ref = orc.nmf_manifold_vec_update_tradeoff(case["X"], case["U0"], case["V0"], [pws[i % 6] for i in range(k)], n_steps=steps,
+                                                                   tradeoff=0.4, gamma=case["gamma"], delta=case["delta"], trace=tr)
+    eu, ev = rel(U, Ur), rel(res[0][1], Vr)
+    eo = max(relmax([o[key] for o in res[0][2]], [t[key] for t in tr]) for key in KEYS + ("gamma", "delta"))
+    report("tradeoff_eight_ranks[%s-m%d]" % (mode, m), rel_U=eu, rel_V=ev, rel_obj=eo, rel_gamma=abs(gd[0] - g_ref) / abs(g_ref))
+    assert eu < 1e-4 and ev < 1e-4 and eo < 1e-4 and abs(gd[0] - g_ref) <= 1e-4 * abs(g_ref)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
