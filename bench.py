@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the measurements next to the headline: pure-stream calibration, update-only rate, outer loop")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
+    ap.add_argument("--cpu-baseline-size", default="auto", choices=["auto", "full", "sample"],
+                    help="CPU baseline at the full matrix, on the bounded row sample (extrapolated), or full when the host memory allows (auto)")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed --steps block (median reported)")
     ap.add_argument("--eager-objective", action="store_true",
                     help="A/B switch: evaluate the objective every iteration (7 launches per iteration, the round-1 sequence) "
@@ -95,7 +97,7 @@ def mem_available_gb():
     return None
 
 
-def cpu_baseline(torch, Xd, U0, V0, pathways, active, gamma, delta, m_full, budget_s):
+def cpu_baseline(torch, Xd, U0, V0, pathways, active, gamma, delta, m_full, budget_s, size="auto"):
     """The oracle (float64 NumPy/SciPy restatement of prmf_runner.py:419-447) timed on this box's host cores in
     both modes BASELINE.md section 3 names: `faithful` -- materialises X - U V^T like :337 AND normalises every active
     Laplacian anew each iteration like :349 (oracle `rebuild_laplacians`): the reference-equivalent number, reported as
@@ -116,6 +118,11 @@ def cpu_baseline(torch, Xd, U0, V0, pathways, active, gamma, delta, m_full, budg
     need_gb = 3.4 * m_full * n * 8 / 1e9 + 4.0            # X, X - U V^T, U V^T (float64) + the factors and slack
     avail = info.get("mem_available_gb")
     full = int(Xd.shape[0]) == m_full and avail is not None and avail >= need_gb
+    if size == "sample":
+        full = False
+    elif size == "full":
+        if not full:
+            raise SystemExit("--cpu-baseline-size full: %.0f GB of host memory needed, %s available" % (need_gb, avail))
     m2 = m_full if full else min(int(Xd.shape[0]), 25000)
     m1 = m2 if full else (m2 // 2 if m2 < m_full else m2)
     X2 = np.empty((m2, n), dtype=np.float64)
@@ -167,7 +174,11 @@ def cpu_baseline(torch, Xd, U0, V0, pathways, active, gamma, delta, m_full, budg
         desc += "timed at FULL size (%d x %d), %d + %d iterations after one warm-up each, nothing scaled" % (
             m2, n, out["faithful"]["samples"][-1]["iterations"], out["lean"]["samples"][-1]["iterations"])
     return {"value": out["faithful"]["it_per_s"], "unit": "iterations/s", "cores": int(threads), "kind": "port",
-            "sample": desc, "full_size": bool(m1 == m2 == m_full), "lean_value": out["lean"]["it_per_s"], "modes": out, "host": info}
+            "sample": desc, "full_size": bool(m1 == m2 == m_full), "lean_value": out["lean"]["it_per_s"], "modes": out, "host": info,
+            # how `value` was derived, so that lines of different rounds / boxes are comparable: v3 = faithful mode rebuilds the
+            # active normalised Laplacians every iteration (prmf_runner.py:349; rounds 1-3 cached them: v1 sampled, v2 two-point fit)
+            "method": {"version": 3, "rebuild_laplacians": True, "materialised_residual": True,
+                       "size": "full" if m1 == m2 == m_full else "two-point row sample, t(m) = a + b m", "requested": size}}
 
 
 def outer_loop(torch, Xd, n, k, P, x_dtype, seed, iterations=100):
@@ -385,7 +396,7 @@ def run_rank(args, ranks, proc):
         if not args.no_extras and args.workload in ("c2", "c3", "c3f32", "c5shard", "c5shardf32"):
             out["outer_loop"] = outer_loop(torch, Xd, n, k, P, x_dtype, args.seed)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(torch, Xd, U0, V0, pathways, active, gamma, delta, m, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(torch, Xd, U0, V0, pathways, active, gamma, delta, m, args.cpu_seconds, args.cpu_baseline_size)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     return out
 
@@ -422,6 +433,9 @@ def main():
         dist.destroy_process_group()
     elif args.gpus > 1:                            # N thread ranks inside this process
         from prmf_amd.ranks import LocalRanks
+        sys.stderr.write("bench.py: --gpus %d without a launcher (no RANK / WORLD_SIZE in the environment): running %d THREAD ranks in "
+                         "this process, rank r on device r %% device_count; for one process per GPU start it under "
+                         "`python -m torch.distributed.run --nproc-per-node %d`\n" % (args.gpus, args.gpus, args.gpus))
         outs = LocalRanks(args.gpus).run(lambda view: run_rank(args, view, None))
         print(json.dumps(outs[0]), flush=True)
     else:

@@ -22,6 +22,7 @@
 #ifndef PRMF_HIP_H
 #define PRMF_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -243,8 +244,10 @@ int prmf_set_global_rows(prmf_ctx* ctx, int64_t m_global);
  * the communicator is ABORTED (ncclCommAbort), the call returns PRMF_ERR_HIP and every later prmf_step_dist on this
  * context returns PRMF_ERR_STATE: the caller is expected to exit non-zero so that its launcher ends the job.  A rank whose
  * peer has died is left inside a collective kernel; its wait for the stream (prmf_end inside prmf_step_dist) is therefore
- * bounded: after `seconds` (default 300; 0 = wait for ever) it aborts its communicator and returns PRMF_ERR_HIP too.  No
- * call hangs. */
+ * bounded: after `seconds` (default 300; 0 = wait for ever) plus 2 s per iteration of the batch it is waiting for (a long
+ * healthy batch is not a dead peer) it aborts its communicator and returns PRMF_ERR_HIP too.  No call hangs.  (An RCCL
+ * build without ncclCommAbort: the communicator is leaked rather than destroyed -- ncclCommDestroy would wait for the
+ * collective that is being escaped.) */
 int prmf_set_comm_timeout(prmf_ctx* ctx, double seconds);
 /* multi-rank prmf_step: same arguments and results (every rank gets the same
  * objective records); requires prmf_comm_init.  Also valid with nranks == 1. */

@@ -24,11 +24,14 @@ int prmf_debug_slab_sum(prmf_ctx* ctx, int which, float* out_dev, void* stream);
  * each against float64.  PRMF_ERR_STATE if the last batch was not a deferred one. */
 int prmf_debug_recon_terms(prmf_ctx* ctx, int it, double* cross, double* gu, double* gv);
 
-/* Device buffer (uint64, >= 8192 entries; >= 2048 + 32 * workgroups * waves in a -DPRMF_PHASE_PROF=1 build) receiving
- * per-workgroup start / end wall-clock stamps of the next sweep launches ([2 b], [2 b + 1] for workgroup b), where each
- * workgroup ran ([6144 + b] = XCC_ID << 32 | HW_ID) and, in a phase-profile build, per-wave phase sums from [2048];
- * NULL switches it off.  tools/wg_spread.py, tools/wg_where.py, tools/sweep_phases.py */
-int prmf_debug_set_stamps(void* dev_buf);
+/* Device buffer of `n_entries` uint64 receiving, from the next sweep launches: per-workgroup start / end wall-clock stamps
+ * ([2 b], [2 b + 1] for workgroup b), where each workgroup ran ([where_offset + b] = XCC_ID << 32 | HW_ID) and, in a
+ * -DPRMF_PHASE_PROF=1 build, 8 phase sums per wave at [phase_offset + (8 b + wave) * 8].  The regions are fixed and
+ * disjoint; prmf_debug_stamp_layout returns the entries the buffer must have (and the offsets) -- a shorter buffer is
+ * refused with PRMF_ERR_ARG.  NULL (any length) switches it off.  tools/wg_spread.py, tools/wg_where.py,
+ * tools/sweep_phases.py */
+int prmf_debug_set_stamps(void* dev_buf, size_t n_entries);
+int prmf_debug_stamp_layout(int* where_offset, int* phase_offset, int* max_workgroups);
 /* The same for the fused epilogues: 8 stamps per workgroup.  tools/epi_phases.py */
 int prmf_debug_set_epi_stamps(void* dev_buf);
 

@@ -83,7 +83,8 @@ SIGNATURES = {
 DEBUG_SIGNATURES = {
     "prmf_debug_slab_sum": (_i, [_vp, _i, _vp, _vp]),
     "prmf_debug_recon_terms": (_i, [_vp, _i, C.POINTER(_d), _vp, _vp]),
-    "prmf_debug_set_stamps": (_i, [_vp]),
+    "prmf_debug_set_stamps": (_i, [_vp, C.c_size_t]),
+    "prmf_debug_stamp_layout": (_i, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "prmf_debug_set_epi_stamps": (_i, [_vp]),
     "prmf_debug_bump_cursor": (_i, [_vp]),
     "prmf_debug_swap": (_i, [_vp, _vp, _i]),

@@ -364,10 +364,9 @@ SweepPrologue mid_prologue(prmf_ctx* c, int it) {
 // expected to end the process non-zero so that the launcher ends the job (with RCCL a peer's kernel can only be ended that
 // way; the peers' own stream timeouts, sync_stream below, turn their wait into the same error).
 int comm_fail(prmf_ctx* c, const char* what, const char* why) {
-  if (c->comm) {
-    if (rccl().CommAbort) (void)rccl().CommAbort(c->comm);
-    else (void)rccl().CommDestroy(c->comm);
-  }
+  // Without ncclCommAbort the communicator is leaked on purpose: ncclCommDestroy waits for the outstanding collective
+  // this call is trying to get away from.
+  if (c->comm && rccl().CommAbort) (void)rccl().CommAbort(c->comm);
   c->comm = nullptr;
   c->comm_broken = true;
   c->batch_open = false;
@@ -380,21 +379,32 @@ int comm_fail(prmf_ctx* c, const char* what, const char* why) {
     if (_r != ncclSuccess) return comm_fail(ctx, #expr, rccl().GetErrorString(_r)); \
   } while (0)
 
-// hipStreamSynchronize for a stream that may carry collectives: with several ranks the wait is bounded
-// (c->comm_timeout_s) -- a peer that died leaves this rank's collective kernel spinning for ever, and a library call
-// must not hang with it.  One rank: the plain call.
-int sync_stream(prmf_ctx* c, hipStream_t s) {
+// hipStreamSynchronize for a stream that may carry collectives: with several ranks the wait is bounded -- a peer that
+// died leaves this rank's collective kernel spinning for ever, and a library call must not hang with it.  The bound is
+// c->comm_timeout_s PLUS an allowance per iteration the stream still carries (`pending_iters`: the batch prmf_end waits
+// for), so that a long healthy batch -- many steps, or eight thread ranks sharing one GPU through the test double -- is
+// not taken for a dead peer.  The poll spins briefly (a batch normally ends within it), then sleeps between queries with
+// a growing interval: N rank threads do not burn N cores while they wait.  One rank: the plain call.
+constexpr double SYNC_ALLOWANCE_PER_ITERATION_S = 2.0;
+int sync_stream(prmf_ctx* c, hipStream_t s, int pending_iters = 0) {
   if (c->nranks == 1 || !c->comm || !(c->comm_timeout_s > 0.0)) {
     HIP_TRY(c, hipStreamSynchronize(s));
     return PRMF_OK;
   }
+  const double limit_s = c->comm_timeout_s + SYNC_ALLOWANCE_PER_ITERATION_S * (pending_iters > 0 ? pending_iters : 0);
   const auto t0 = std::chrono::steady_clock::now();
+  unsigned nap_us = 10;
   for (unsigned spins = 0;; ++spins) {
     const hipError_t e = hipStreamQuery(s);
     if (e == hipSuccess) return PRMF_OK;
     if (e != hipErrorNotReady) return fail(c, PRMF_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(e));
-    if (spins > 20000) std::this_thread::sleep_for(std::chrono::microseconds(50));      // a batch normally ends within the spin
-    if ((spins & 255) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->comm_timeout_s)
+    if (spins > 2000) {
+      std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
+      if (nap_us < 200) nap_us += 10;
+    } else if ((spins & 63) == 63) {
+      std::this_thread::yield();
+    }
+    if ((spins & 63) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
       return comm_fail(c, "stream synchronisation", "timed out waiting for a collective -- a peer rank may have failed");
   }
 }
@@ -1019,7 +1029,7 @@ int prmf_end(prmf_ctx* c, int n_steps, double* obj_out, double* gamma_delta_out,
                               (size_t)n_steps * PRMF_OBJ_STRIDE * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipMemcpyAsync(c->hyper_host, c->hyper, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
   if (lazy_direct) HIP_TRY(c, hipMemcpyAsync(c->need_host, c->need_dev, sizeof(int), hipMemcpyDeviceToHost, s));
-  if ((rc = sync_stream(c, s))) return rc;
+  if ((rc = sync_stream(c, s, c->cursor))) return rc;
   // The last record of the batch is the one the outer loop acts on: if its identity-based recon^2 was too small to trust
   // (the record kernel raised the flag -- identically on every rank: the records are computed from all-reduced / replicated
   // quantities and the threshold from global sizes, direct_below), the direct residual is evaluated now and that
@@ -1306,7 +1316,17 @@ int prmf_debug_slab_sum(prmf_ctx* c, int which, float* out_dev, void* stream) {
   return PRMF_OK;
 }
 
-int prmf_debug_set_stamps(void* dev_buf) { prmf::g_sweep_stamps = (unsigned long long*)dev_buf; return 0; }
+int prmf_debug_set_stamps(void* dev_buf, size_t n_entries) {
+  if (dev_buf && n_entries < (size_t)prmf::STAMP_ENTRIES) return PRMF_ERR_ARG;      // the kernels index fixed regions of the buffer
+  prmf::g_sweep_stamps = (unsigned long long*)dev_buf;
+  return 0;
+}
+int prmf_debug_stamp_layout(int* where_offset, int* phase_offset, int* max_workgroups) {
+  if (where_offset) *where_offset = prmf::STAMP_WHERE;
+  if (phase_offset) *phase_offset = prmf::STAMP_PHASE;
+  if (max_workgroups) *max_workgroups = prmf::STAMP_MAX_WGS;
+  return prmf::STAMP_ENTRIES;
+}
 int prmf_debug_set_epi_stamps(void* dev_buf) { prmf::g_epi_stamps = (unsigned long long*)dev_buf; return 0; }
 
 int prmf_debug_recon_terms(prmf_ctx* c, int it, double* cross, double* gu, double* gv) {

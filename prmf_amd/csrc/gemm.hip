@@ -451,12 +451,13 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
              int nx, int pmax, int seg_base, float* __restrict__ slabs, int64_t slab_stride, int slab_nt,
              unsigned long long* __restrict__ stamps /* debug, may be null */, const SweepPrologue pro,
              int* __restrict__ tail /* debug (tools/tail_probe.py), may be null */, int tail_launch) {
+  if (stamps && blockIdx.x >= STAMP_MAX_WGS) stamps = nullptr;      // (no launch has that many workgroups: one per resident slot)
   if (stamps && threadIdx.x == 0) {
     stamps[2 * blockIdx.x] = wall_clock64();
     // where this workgroup runs (tools/wg_where.py): HW_ID (wave / SIMD / CU / SH / SE ids) and XCC_ID, for the question
     // what the systematic finish-time spread of equal shares goes with
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    stamps[6144 + blockIdx.x] = ((unsigned long long)xcc << 32) | hw;
+    stamps[STAMP_WHERE + blockIdx.x] = ((unsigned long long)xcc << 32) | hw;
   }
   constexpr int NTHR = 64 * NW;
   constexpr int BCH = MODE == 1 ? 512 * NT : 256 * NT;   // uint4 per packed chunk (64 bf16 or 32 f32 elements of the reduction)
@@ -857,7 +858,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 #endif
 #if PRMF_PHASE_PROF
   if (stamps && lane == 0)
-    for (int i = 0; i < 6; ++i) stamps[2048 + (blockIdx.x * 4 + wave) * 8 + i] = ph_sum[i];
+    for (int i = 0; i < 6; ++i) stamps[STAMP_PHASE + (blockIdx.x * 8 + wave) * 8 + i] = ph_sum[i];
 #endif
   if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x + 1] = wall_clock64();
 }

@@ -130,6 +130,13 @@ struct SweepTuning {
   int force_slices = 0;     // PRMF_SWEEP_XCD = 1 | 2 | 4 | 8: force the number of reduction slices (decomposition-equivalence test)
 };
 GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, const SweepTuning& tune);
+// debug only (prmf_debug_set_stamps): layout of the sweep's stamp buffer, in uint64 entries.  Fixed regions that do not
+// overlap at any grid (<= STAMP_MAX_WGS workgroups of <= 8 waves):
+//   [0, 2 W)                    start / end wall clock of workgroup b at [2 b], [2 b + 1]
+//   [STAMP_WHERE, + W)          where workgroup b ran: XCC_ID << 32 | HW_ID
+//   [STAMP_PHASE, + W * 8 * 8)  -DPRMF_PHASE_PROF=1 builds: 8 phase sums per wave, wave-major per workgroup (8 waves' room)
+constexpr int STAMP_MAX_WGS = 1024, STAMP_WHERE = 2 * STAMP_MAX_WGS, STAMP_PHASE = 3 * STAMP_MAX_WGS;
+constexpr int STAMP_ENTRIES = STAMP_PHASE + STAMP_MAX_WGS * 8 * 8;
 extern unsigned long long* g_sweep_stamps;   // debug only
 extern unsigned long long* g_epi_stamps;     // debug only (column-split epilogue phases)
 extern int* g_tail_probe;                     // debug only (tools/tail_probe.py)

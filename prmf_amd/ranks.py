@@ -22,7 +22,9 @@ engine's communicator bootstrap and the host-driven collectives need:
     barrier()
     all_reduce_sum(t) / reduce_scatter_sum(out, inp) / all_gather(out, inp)   on device tensors (host-driven exchanges)
 """
+import copy
 import threading
+import time
 
 import numpy as np
 
@@ -174,8 +176,10 @@ class TorchRanks(object):
 
 class LocalRanks(object):
     """N ranks as N threads of this process.  `run(fn, *args)` -> [fn(view_r, *args) for r]; an exception on any rank
-    breaks the barrier the others wait at and is re-raised after every thread has come back (or `join_s` has passed:
-    a rank stuck inside a library call cannot be interrupted -- the library's own timeouts end it)."""
+    breaks the barrier the others wait at and is re-raised after every thread has come back or ONE overall deadline
+    (`timeout_s` for the whole run, not per thread) has passed -- a rank stuck inside a library call cannot be
+    interrupted, the library's own bounded waits end it (prmf_set_comm_timeout).  After a failure the object is spent:
+    its barrier stays broken and abandoned daemon threads may still hold it -- make a new LocalRanks for the next run."""
 
     def __init__(self, world, devices=None, timeout_s=900.0):
         if world < 1:
@@ -184,6 +188,7 @@ class LocalRanks(object):
         self.timeout_s = float(timeout_s)
         self._barrier = threading.Barrier(self.world, timeout=self.timeout_s)
         self._slots = [None] * self.world
+        self._failed = False
         if devices is None:
             try:
                 import torch
@@ -199,6 +204,8 @@ class LocalRanks(object):
         return LocalRankView(self, rank)
 
     def run(self, fn, *args, **kwargs):
+        if self._failed:
+            raise RuntimeError("this LocalRanks group has failed before (broken barrier, ranks possibly abandoned): create a new one")
         results = [None] * self.world
         errors = [None] * self.world
 
@@ -226,9 +233,12 @@ class LocalRanks(object):
         threads = [threading.Thread(target=body, args=(r,), name="prmf-rank-%d" % r, daemon=True) for r in range(self.world)]
         for t in threads:
             t.start()
+        deadline = time.monotonic() + self.timeout_s      # one deadline for the whole job, not timeout_s per thread
         for t in threads:
-            t.join(self.timeout_s)
+            t.join(max(0.0, deadline - time.monotonic()))
         stuck = [t.name for t in threads if t.is_alive()]
+        if stuck or any(e is not None for e in errors):
+            self._failed = True
         first = next((e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)), None)
         if first is None:
             first = next((e for e in errors if e is not None), None)
@@ -266,14 +276,28 @@ class LocalRankView(object):
         if self.multi:
             self.owner._barrier.wait()
 
+    # Like the process ranks (pickle / tensor broadcast) every rank gets an object of its OWN: the source rank keeps
+    # what it passed in, the others a deep copy taken between the two barriers of the exchange -- rank 0 may overwrite
+    # its dict for the next round while a peer still reads (nmf_pathway's k_to_lapl), and a caller's list is not
+    # appended to by N threads.
+    def _from(self, src, value):
+        o = self.owner
+        o._slots[self.rank] = value
+        o._barrier.wait()
+        got = o._slots[src]
+        if self.rank != src:
+            got = copy.deepcopy(got)
+        o._barrier.wait()
+        return got
+
     def from_rank0(self, obj):
-        return self._exchange(obj)[0] if self.multi else obj
+        return self._from(0, obj) if self.multi else obj
 
     def array_from_rank0(self, a, shape, device="cpu"):
-        return self._exchange(a)[0] if self.multi else a
+        return self._from(0, a) if self.multi else a
 
     def array_from_rank(self, src, a, shape, device="cpu"):
-        return self._exchange(a)[src] if self.multi else a
+        return self._from(src, a) if self.multi else a
 
     def bytes_from_rank0(self, buf, device="cpu"):
         return self._exchange(buf)[0].copy() if self.multi else buf

@@ -80,18 +80,21 @@ __global__ void __launch_bounds__(512) ladder(const u32x4* __restrict__ A, long 
         for (int i = 0; i < 4; ++i) acc += v[i][0] ^ v[i][1] ^ v[i][2] ^ v[i][3];
       }
     }
-    if (MODE >= 5 && MODE <= 10) {
+    if ((MODE >= 5 && MODE <= 10) || MODE >= 13) {
       // 5: distinct slab per segment | 6: same, non-temporal stores | 7: one slab per workgroup, overwritten
       // 8: every workgroup writes the same 64 KiB (no write traffic to speak of)
       // 9: as 5 but every store instruction writes 1 KiB contiguous ([q][lane] instead of [lane][q]) | 10: same, non-temporal
       const long slab = MODE == 8 ? 0 : (MODE == 7 ? (long)blockIdx.x * 2 : (long)blockIdx.x * 2 + seg);
-      if (MODE >= 9) {
+      if (MODE >= 9) {      // (13: sc1, 14: sc0 sc1, 15: sc1 nt -- round 5)
         typedef float f4 __attribute__((ext_vector_type(4)));
         f4* o = reinterpret_cast<f4*>(slabs + slab * 16384) + (long)wave * 2 * 256 + lane;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f4 x = {c0[4 * q], c0[4 * q + 1], c0[4 * q + 2], c0[4 * q + 3]}, y = {c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]};
           if (MODE == 10) { __builtin_nontemporal_store(x, o + q * 64); __builtin_nontemporal_store(y, o + 256 + q * 64); }
+          else if (MODE == 13) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(o + q * 64), "v"(x) : "memory"); asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(o + 256 + q * 64), "v"(y) : "memory"); }
+          else if (MODE == 14) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o + q * 64), "v"(x) : "memory"); asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o + 256 + q * 64), "v"(y) : "memory"); }
+          else if (MODE == 15) { asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(o + q * 64), "v"(x) : "memory"); asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(o + 256 + q * 64), "v"(y) : "memory"); }
           else { o[q * 64] = x; o[256 + q * 64] = y; }
         }
         seg ^= 1;
@@ -142,6 +145,9 @@ int main() {
         case 10: ladder<10><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
         case 11: ladder<11><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
         case 12: ladder<12><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
+        case 13: ladder<13><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
+        case 14: ladder<14><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
+        case 15: ladder<15><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
       }
       (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
       float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -151,6 +157,6 @@ int main() {
     printf("mode %d: best %.3f ms %.2f TB/s   mean %.3f ms %.2f TB/s\n", mode, best, bytes / best / 1e9, sum / 6, bytes / (sum / 6) / 1e9);
   };
   for (int rep = 0; rep < 2; ++rep)
-    for (int mode : {2, 4, 12}) run(mode);
+    for (int mode : {0, 3, 4, 5, 7, 8, 9, 10, 13, 14, 15}) run(mode);
   return 0;
 }

@@ -21,18 +21,19 @@ eng.begin(U, V, 1.0, 1.0)
 for i in range(3):
     eng.phase_u(); eng.phase_q(); eng.phase_v(); eng.phase_post()
 torch.cuda.synchronize()
-st = torch.zeros(2048 + 512 * 4 * 8, dtype=torch.int64, device=dev)
-eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()))
+_w, _ph, _mx = C.c_int(), C.c_int(), C.c_int()
+st = torch.zeros(eng.lib.prmf_debug_stamp_layout(C.byref(_w), C.byref(_ph), C.byref(_mx)), dtype=torch.int64, device=dev)
+assert eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()), st.numel()) == 0
 names = ["other", "load issue", "reads+MFMA", "barrier 1", "waits+LDS writes", "barrier 2"]
 for name, ph in (("X*V", eng.phase_u), ("X^T*U", eng.phase_q)):
     st.zero_(); torch.cuda.synchronize()
     ph(); torch.cuda.synchronize()
     a = st.cpu().numpy()
     se = a[:1024].reshape(-1, 2); dur = (se[:, 1] - se[:, 0]) / 100.0
-    p = a[2048:].reshape(512, 4, 8)[:, :, :6].astype(np.float64)
+    p = a[_ph.value:].reshape(_mx.value, 8, 8)[:512, :4, :6].astype(np.float64)      # (4-wave forms; the 8-wave forms fill waves 4..7 too)
     tot = p.sum(axis=2)
     print("%s: kernel WG duration mean %.1f us; wave cycles mean %.0f" % (name, dur[dur > 0].mean(), tot.mean()))
     for i, nm in enumerate(names):
         print("   %-18s mean %8.0f cycles  %5.1f %%   (wave 0: %5.1f %%  wave 3: %5.1f %%)" % (
             nm, p[:, :, i].mean(), 100 * p[:, :, i].sum() / tot.sum(), 100 * p[:, 0, i].sum() / tot[:, 0].sum(), 100 * p[:, 3, i].sum() / tot[:, 3].sum()))
-eng.lib.prmf_debug_set_stamps(None)
+eng.lib.prmf_debug_set_stamps(None, 0)

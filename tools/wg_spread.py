@@ -18,8 +18,9 @@ eng.begin(U, V, 1.0, 1.0)
 for i in range(3):
     eng.phase_u(); eng.phase_q(); eng.phase_v(); eng.phase_post()
 torch.cuda.synchronize()
-st = torch.zeros(8192, dtype=torch.int64, device=dev)   # [0, 2048): start/end stamps; [6144, 7168): HW ids
-eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()))
+_w, _ph, _mx = C.c_int(), C.c_int(), C.c_int()
+st = torch.zeros(eng.lib.prmf_debug_stamp_layout(C.byref(_w), C.byref(_ph), C.byref(_mx)), dtype=torch.int64, device=dev)   # [0, 2 W): start/end stamps; [_w, _w + W): HW ids
+eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()), st.numel())
 for name, ph in (("X*V", eng.phase_u), ("X^T*U", eng.phase_q)):
     st.zero_(); torch.cuda.synchronize()
     ph(); torch.cuda.synchronize()
@@ -29,21 +30,21 @@ for name, ph in (("X*V", eng.phase_u), ("X^T*U", eng.phase_q)):
         name, len(a), np.percentile(start, 50), np.percentile(start, 90), start.max(), end.min(), np.percentile(end, 10), np.percentile(end, 50), np.percentile(end, 90), end.max(), (end - start).mean()))
     if name == "X*V":
         eng.phase_v() if False else None
-eng.lib.prmf_debug_set_stamps(None)
+eng.lib.prmf_debug_set_stamps(None, 0)
 
 if os.environ.get('QUICK'):
     sys.exit(0)
 # --- are the slow workgroups the same ones every launch? (systematic => a weighted static split would fix it)
 import numpy as np
 durs = []
-eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()))
+eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()), st.numel())
 for rep in range(4):
     st.zero_(); torch.cuda.synchronize()
     eng.phase_u(); torch.cuda.synchronize()
     a = st.cpu().numpy()[:2048].reshape(-1, 2)[:512]
     durs.append((a[:, 1] - a[:, 0]) / 100.0)
     eng.phase_q(); eng.phase_v(); eng.phase_post(); torch.cuda.synchronize()
-eng.lib.prmf_debug_set_stamps(None)
+eng.lib.prmf_debug_set_stamps(None, 0)
 durs = np.array(durs)
 if os.environ.get("SAVE"):
     np.save(os.environ["SAVE"] + "_xv.npy", durs)
@@ -53,7 +54,7 @@ m = durs.mean(axis=0)
 print("per-XCD mean duration (block id %% 8):", np.round([m[x::8].mean() for x in range(8)], 1))
 print("by position in XCD (block id // 8) deciles:", np.round([m[np.arange(512) // 8 // 8 == d].mean() for d in range(8)], 1))
 
-eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()))
+eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()), st.numel())
 durs = []
 for rep in range(3):
     eng.phase_u(); torch.cuda.synchronize()
@@ -62,7 +63,7 @@ for rep in range(3):
     a = st.cpu().numpy()[:2048].reshape(-1, 2)[:512]
     durs.append((a[:, 1] - a[:, 0]) / 100.0)
     eng.phase_v(); eng.phase_post(); torch.cuda.synchronize()
-eng.lib.prmf_debug_set_stamps(None)
+eng.lib.prmf_debug_set_stamps(None, 0)
 durs = np.array(durs); m = durs.mean(axis=0)
 if os.environ.get("SAVE"):
     np.save(os.environ["SAVE"] + "_xtu.npy", durs)

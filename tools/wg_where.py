@@ -37,7 +37,9 @@ eng.begin(U, V, 1.0, 1.0)
 for i in range(3):
     eng.phase_u(); eng.phase_q(); eng.phase_v(); eng.phase_post()
 torch.cuda.synchronize()
-st = torch.zeros(8192, dtype=torch.int64, device=dev)
+_w, _ph, _mx = C.c_int(), C.c_int(), C.c_int()
+st = torch.zeros(eng.lib.prmf_debug_stamp_layout(C.byref(_w), C.byref(_ph), C.byref(_mx)), dtype=torch.int64, device=dev)
+WHERE = _w.value
 info = eng.sweep_info()
 
 
@@ -46,23 +48,23 @@ def collect(which):
     for rep in range(REPS):
         if which == "xv":
             st.zero_(); torch.cuda.synchronize()
-            eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()))
+            eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()), st.numel())
             eng.phase_u(); torch.cuda.synchronize()
-            eng.lib.prmf_debug_set_stamps(None)
+            eng.lib.prmf_debug_set_stamps(None, 0)
             a = st.cpu().numpy()
             eng.phase_q(); eng.phase_v(); eng.phase_post(); torch.cuda.synchronize()
         else:
             eng.phase_u(); torch.cuda.synchronize()
             st.zero_(); torch.cuda.synchronize()
-            eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()))
+            eng.lib.prmf_debug_set_stamps(C.c_void_p(st.data_ptr()), st.numel())
             eng.phase_q(); torch.cuda.synchronize()
-            eng.lib.prmf_debug_set_stamps(None)
+            eng.lib.prmf_debug_set_stamps(None, 0)
             a = st.cpu().numpy()
             eng.phase_v(); eng.phase_post(); torch.cuda.synchronize()
         g = info.grid_xv if which == "xv" else info.grid_xtu
         se = a[:2 * g].reshape(-1, 2)
         durs.append((se[:, 1] - se[:, 0]) / 100.0)
-        hw.append(a[6144:6144 + g].copy())
+        hw.append(a[WHERE:WHERE + g].copy())
     return np.array(durs), np.array(hw)
 
 
