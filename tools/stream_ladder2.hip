@@ -80,7 +80,8 @@ __global__ void __launch_bounds__(512) ladder(const u32x4* __restrict__ A, long 
         for (int i = 0; i < 4; ++i) acc += v[i][0] ^ v[i][1] ^ v[i][2] ^ v[i][3];
       }
     }
-    if ((MODE >= 5 && MODE <= 10) || MODE >= 13) {
+    if (((MODE >= 5 && MODE <= 10) || MODE >= 13) &&
+        !(MODE == 16 && u + (ce - cb) >= u1) && !(MODE == 17 && u + (ce - cb) < u1)) {      // 16: only the segments that are not the workgroup's last store; 17: only the last one
       // 5: distinct slab per segment | 6: same, non-temporal stores | 7: one slab per workgroup, overwritten
       // 8: every workgroup writes the same 64 KiB (no write traffic to speak of)
       // 9: as 5 but every store instruction writes 1 KiB contiguous ([q][lane] instead of [lane][q]) | 10: same, non-temporal
@@ -88,14 +89,21 @@ __global__ void __launch_bounds__(512) ladder(const u32x4* __restrict__ A, long 
       if (MODE >= 9) {      // (13: sc1, 14: sc0 sc1, 15: sc1 nt -- round 5)
         typedef float f4 __attribute__((ext_vector_type(4)));
         f4* o = reinterpret_cast<f4*>(slabs + slab * 16384) + (long)wave * 2 * 256 + lane;
+        unsigned long long t0 = 0;      // 19: how long until this wave's store burst is acknowledged (wave 0 of every workgroup)
+        if (MODE == 19) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t0 = wall_clock64(); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f4 x = {c0[4 * q], c0[4 * q + 1], c0[4 * q + 2], c0[4 * q + 3]}, y = {c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]};
-          if (MODE == 10) { __builtin_nontemporal_store(x, o + q * 64); __builtin_nontemporal_store(y, o + 256 + q * 64); }
+          if (MODE == 10 || MODE >= 16) { __builtin_nontemporal_store(x, o + q * 64); __builtin_nontemporal_store(y, o + 256 + q * 64); }
           else if (MODE == 13) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(o + q * 64), "v"(x) : "memory"); asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(o + 256 + q * 64), "v"(y) : "memory"); }
           else if (MODE == 14) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o + q * 64), "v"(x) : "memory"); asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o + 256 + q * 64), "v"(y) : "memory"); }
           else if (MODE == 15) { asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(o + q * 64), "v"(x) : "memory"); asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(o + 256 + q * 64), "v"(y) : "memory"); }
           else { o[q * 64] = x; o[256 + q * 64] = y; }
+        }
+        if (MODE == 19) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const unsigned long long t1 = wall_clock64();
+          if (lane == 0 && wave == 0) { const bool last = u + (ce - cb) >= u1; out[16 + blockIdx.x * 4 + (last ? 1 : 0)] = (unsigned)(t1 - t0); out[16 + blockIdx.x * 4 + 2 + (last ? 1 : 0)] = 1; }
         }
         seg ^= 1;
         u += ce - cb;
@@ -122,7 +130,7 @@ int main() {
   const long rows = 50176, rowbytes = 40192;
   const int panels = rows / 256, chunks = rowbytes / 128;
   u32x4 *A, *B; unsigned* out; float* slabs;
-  (void)hipMalloc(&A, rows * rowbytes); (void)hipMalloc(&B, (long)chunks * 16384); (void)hipMalloc(&out, 4);
+  (void)hipMalloc(&A, rows * rowbytes); (void)hipMalloc(&B, (long)chunks * 16384); (void)hipMalloc(&out, 65536); (void)hipMemset(out, 0, 65536);
   (void)hipMalloc(&slabs, 1024L * 16384 * 4);
   (void)hipMemset(A, 0, rows * rowbytes); (void)hipMemset(B, 0, (long)chunks * 16384);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -148,6 +156,9 @@ int main() {
         case 13: ladder<13><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
         case 14: ladder<14><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
         case 15: ladder<15><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
+        case 16: ladder<16><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
+        case 17: ladder<17><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
+        case 19: ladder<19><<<grid, 512>>>(A, rowbytes / 16, B, panels, chunks, slabs, out); break;
       }
       (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
       float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -156,7 +167,17 @@ int main() {
     const double bytes = (double)rows * rowbytes;
     printf("mode %d: best %.3f ms %.2f TB/s   mean %.3f ms %.2f TB/s\n", mode, best, bytes / best / 1e9, sum / 6, bytes / (sum / 6) / 1e9);
   };
-  for (int rep = 0; rep < 2; ++rep)
-    for (int mode : {0, 3, 4, 5, 7, 8, 9, 10, 13, 14, 15}) run(mode);
+  for (int rep = 0; rep < 3; ++rep)
+    for (int mode : {4, 10, 19}) run(mode);
+  {
+    static unsigned h[16384];
+    (void)hipMemcpy(h, out, 65536, hipMemcpyDeviceToHost);
+    double sm = 0, sl = 0, mxm = 0, mxl = 0; int nm = 0, nl = 0;
+    for (int b = 0; b < grid; ++b) {
+      if (h[16 + b * 4 + 2]) { const double t = h[16 + b * 4] / 100.0; sm += t; ++nm; if (t > mxm) mxm = t; }
+      if (h[16 + b * 4 + 3]) { const double t = h[16 + b * 4 + 1] / 100.0; sl += t; ++nl; if (t > mxl) mxl = t; }
+    }
+    printf("mode 19: store burst -> vmcnt(0): mid-stream %d bursts mean %.2f us max %.2f us | final %d bursts mean %.2f us max %.2f us\n", nm, nm ? sm / nm : 0, mxm, nl, nl ? sl / nl : 0, mxl);
+  }
   return 0;
 }
