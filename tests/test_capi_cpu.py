@@ -59,6 +59,20 @@ def test_error_paths_without_compute():
     assert lib.prmf_step(None, None, None, 1, 1.0, 1.0, -1.0, None, None, None) == _capi.PRMF_ERR_ARG
 
 
+def test_debug_stamp_buffer_length_is_checked():
+    """the sweep's debug stamps go to fixed, disjoint regions of the caller's buffer: a buffer shorter than the layout is refused"""
+    from prmf_amd import _capi
+    lib = _capi.load()
+    where, phase, wgs = C.c_int(), C.c_int(), C.c_int()
+    n = lib.prmf_debug_stamp_layout(C.byref(where), C.byref(phase), C.byref(wgs))
+    assert wgs.value >= 512 and where.value >= 2 * wgs.value and phase.value >= where.value + wgs.value
+    assert n >= phase.value + wgs.value * 8 * 8                  # 8 phase sums for each of 8 waves of every workgroup
+    fake = C.c_void_p(0x1000)                                    # never dereferenced: the call only records the pointer
+    assert lib.prmf_debug_set_stamps(fake, n - 1) == _capi.PRMF_ERR_ARG
+    assert lib.prmf_debug_set_stamps(fake, n) == 0
+    assert lib.prmf_debug_set_stamps(None, 0) == 0
+
+
 def test_missing_library_is_an_error(tmp_path):
     from prmf_amd import _capi
     with pytest.raises(_capi.PrmfLibraryError):

@@ -52,6 +52,41 @@ def test_failure_on_one_rank_reaches_the_caller():
         LocalRanks(4, timeout_s=30).run(body)
 
 
+def test_failed_group_is_spent_and_joins_share_one_deadline():
+    import time
+    g = LocalRanks(3, timeout_s=30)
+    with pytest.raises(ValueError):
+        g.run(lambda view: (_ for _ in ()).throw(ValueError("boom")) if view.rank == 1 else view.barrier())
+    with pytest.raises(RuntimeError, match="failed before"):
+        g.run(lambda view: view.rank)
+    # ONE deadline for the whole job: three ranks that never come back are reported after ~timeout_s, not 3 x timeout_s
+    stuck = LocalRanks(3, timeout_s=0.4)
+    t0 = time.monotonic()
+    with pytest.raises(RuntimeError, match="did not finish"):
+        stuck.run(lambda view: time.sleep(3.0))
+    assert time.monotonic() - t0 < 1.2
+
+
+def test_rank0_objects_arrive_as_per_rank_copies():
+    """what rank 0 hands out is a COPY on the other ranks (as between processes): rank 0 may go on writing to its own"""
+    def body(view):
+        d = view.from_rank0({"a": [1, 2]} if view.rank == 0 else None)
+        a = view.array_from_rank0(np.zeros(3) if view.rank == 0 else None, (3,))
+        view.barrier()
+        if view.rank == 0:
+            d["a"].append(3)
+            d["b"] = 1
+            a[:] = 7.0
+        view.barrier()
+        return d, a
+
+    res = LocalRanks(4).run(body)
+    assert res[0][0] == {"a": [1, 2, 3], "b": 1} and np.all(res[0][1] == 7.0)
+    for d, a in res[1:]:
+        assert d == {"a": [1, 2]} and np.all(a == 0.0)
+    assert len({id(d) for d, _a in res}) == 4 and len({id(a) for _d, a in res}) == 4
+
+
 def test_single_rank_group_is_inert():
     r = TorchRanks(None)
     assert not r.multi and r.from_rank0(3) == 3 and r.sum_float(1.5) == 1.5 and r.min_int(4) == 4
