@@ -383,8 +383,10 @@ int comm_fail(prmf_ctx* c, const char* what, const char* why) {
 // died leaves this rank's collective kernel spinning for ever, and a library call must not hang with it.  The bound is
 // c->comm_timeout_s PLUS an allowance per iteration the stream still carries (`pending_iters`: the batch prmf_end waits
 // for), so that a long healthy batch -- many steps, or eight thread ranks sharing one GPU through the test double -- is
-// not taken for a dead peer.  The poll spins briefly (a batch normally ends within it), then sleeps between queries with
-// a growing interval: N rank threads do not burn N cores while they wait.  One rank: the plain call.
+// not taken for a dead peer.  The poll spins for the first 2 ms (yielding now and then), after that it sleeps between
+// queries for 1 % of the time already waited (5 .. 200 us): N rank threads do not burn N cores on a long wait, and the
+// call returns at most 1 % after the stream has finished -- a timed multi-rank batch is not stretched by the polling.
+// One rank: the plain call.
 constexpr double SYNC_ALLOWANCE_PER_ITERATION_S = 2.0;
 int sync_stream(prmf_ctx* c, hipStream_t s, int pending_iters = 0) {
   if (c->nranks == 1 || !c->comm || !(c->comm_timeout_s > 0.0)) {
@@ -393,19 +395,20 @@ int sync_stream(prmf_ctx* c, hipStream_t s, int pending_iters = 0) {
   }
   const double limit_s = c->comm_timeout_s + SYNC_ALLOWANCE_PER_ITERATION_S * (pending_iters > 0 ? pending_iters : 0);
   const auto t0 = std::chrono::steady_clock::now();
-  unsigned nap_us = 10;
-  for (unsigned spins = 0;; ++spins) {
+  for (unsigned polls = 0;; ++polls) {
     const hipError_t e = hipStreamQuery(s);
     if (e == hipSuccess) return PRMF_OK;
     if (e != hipErrorNotReady) return fail(c, PRMF_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(e));
-    if (spins > 2000) {
-      std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
-      if (nap_us < 200) nap_us += 10;
-    } else if ((spins & 63) == 63) {
-      std::this_thread::yield();
-    }
-    if ((spins & 63) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
+    if ((polls & 15) != 15) continue;
+    const double waited_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (waited_s > limit_s)
       return comm_fail(c, "stream synchronisation", "timed out waiting for a collective -- a peer rank may have failed");
+    if (waited_s < 2e-3) {
+      std::this_thread::yield();
+    } else {
+      const double nap_us = waited_s * 1e4 < 5.0 ? 5.0 : (waited_s * 1e4 > 200.0 ? 200.0 : waited_s * 1e4);      // 1 % of the wait so far
+      std::this_thread::sleep_for(std::chrono::nanoseconds((long long)(nap_us * 1e3)));
+    }
   }
 }
 
