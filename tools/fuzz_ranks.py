@@ -1,0 +1,126 @@
+#!/usr/bin/env python
+"""Random shapes through the IN-LIBRARY multi-rank step: 2 .. 8 thread ranks sharing the GPU (prmf_amd.ranks.LocalRanks,
+collectives through the RCCL test double tests/native/mock_rccl.cpp), both V-update modes, with and without the tradeoff
+feedback -- sample counts below the rank count (ranks without rows), k below it (ranks without a latent column), ragged
+everything -- against the single-rank prmf_step on the whole matrix: U, V, every objective component within 1e-5 (the same
+arithmetic, another summation order), V / records / flags bit-identical across the ranks, a second run bit-identical.
+Not part of the test suite; a failure prints the case and exits non-zero.
+    SEED=1 CASES=40 python tools/fuzz_ranks.py"""
+import math
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+if "PRMF_RCCL_LIB" not in os.environ:      # build the double and re-run with it bound (the library binds its RCCL once per process)
+    so = os.path.join(tempfile.mkdtemp(prefix="mock_rccl_"), "libmock_rccl.so")
+    cc = subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                         os.path.join(ROOT, "tests", "native", "mock_rccl.cpp"), "-o", so, "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"],
+                        capture_output=True, text=True)
+    if cc.returncode != 0:
+        sys.exit("mock build failed:\n" + cc.stderr[-2000:])
+    sys.exit(subprocess.run([sys.executable] + sys.argv, env=dict(os.environ, PRMF_RCCL_LIB=so)).returncode)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import synth  # noqa: E402
+from prmf_amd import PathwayLibrary  # noqa: E402
+from prmf_amd.distributed import DistributedPrmf  # noqa: E402
+from prmf_amd.ranks import LocalRanks  # noqa: E402
+from prmf_amd.solver import PrmfEngine  # noqa: E402
+from prmf_amd.synthetic import shard_rows  # noqa: E402
+
+rs = np.random.RandomState(int(os.environ.get("SEED", 1)))
+ncases = int(os.environ.get("CASES", 40))
+KEYS = ("recon", "manifold", "ignore", "fro", "obj")
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def draw():
+    kind = rs.randint(4)
+    if kind == 0:
+        m, n = rs.randint(1, 20), rs.randint(4, 80)
+    elif kind == 1:
+        m, n = rs.randint(2, 200), rs.randint(300, 6000)
+    else:
+        m, n = rs.randint(20, 2500), rs.randint(20, 3000)
+    k = int(rs.choice([1, 2, 3, 5, 6, 7, 8, 13, 16, 31, 32, 33, 48, 64, 65, 96, 100, 128]))
+    return dict(m=int(m), n=int(n), k=k, P=int(rs.randint(1, 7)), order=int(min(max(2, n // 2), rs.randint(2, 150))),
+                x_dtype=str(rs.choice(["f32", "bf16"])), steps=int(rs.randint(2, 5)), seed=int(rs.randint(1 << 30)),
+                world=int(rs.randint(2, 9)), mode=str(rs.choice(["colshard", "replicated"])),
+                tradeoff=(0.5 if rs.rand() < 0.15 else None))
+
+
+t_start = time.time()
+worst = 0.0
+for ci in range(ncases):
+    c = draw()
+    case = synth.small_case(seed=c["seed"], m=c["m"], n=c["n"], k=c["k"], P=c["P"], order=c["order"], zero_genes=min(3, c["n"] // 4),
+                            isolated=min(2, max(0, c["order"] - 2)), bf16_x=(c["x_dtype"] == "bf16"))
+    m, n, k = c["m"], c["n"], c["k"]
+    lib = PathwayLibrary.from_edge_lists(n, case["pathways"])
+    active = list(np.arange(k) % len(case["pathways"]))
+
+    def solve(view):
+        world, rank = (view.world, view.rank) if view is not None else (1, 0)
+        lo, hi = shard_rows(m, world, rank)
+        eng = PrmfEngine(hi - lo, n, k, x_dtype=c["x_dtype"], device=0, nranks=world, rank=rank, dist_mode=c["mode"] if view is not None else None)
+        try:
+            Xd = eng.device_tensor(case["X"][lo:hi], eng.torch_x_dtype)
+            local = eng.local_norm_sq(Xd)
+            nsq = view.sum_float(local) if view is not None else local
+            eng.set_x(Xd, norm_x_sq=nsq)
+            eng.set_library(lib)
+            eng.set_active(active)
+            outs = []
+            stepper = DistributedPrmf(eng, group=view, native=True).step if view is not None else eng.step
+            for _rep in range(2):
+                U = eng.device_tensor(case["U0"][lo:hi], torch.float32)
+                V = eng.device_tensor(case["V0"], torch.float32)
+                eng.invalidate_factors()
+                try:
+                    objs, gd = stepper(U, V, c["steps"], case["gamma"], case["delta"], c["tradeoff"])
+                except FloatingPointError:
+                    return "numeric"
+                outs.append((U.cpu().numpy(), V.cpu().numpy(), objs, list(eng.last_flags), gd))
+            return outs
+        finally:
+            eng.close()
+
+    one = solve(None)
+    res = LocalRanks(c["world"], timeout_s=240).run(solve)
+    tag = " ".join("%s=%s" % kv for kv in c.items())
+    if one == "numeric" or any(r == "numeric" for r in res):
+        ok = one == "numeric" and all(r == "numeric" for r in res)
+        print("%3d %s  PRMF_ERR_NUMERIC on %s" % (ci, tag, "every rank and the single-rank run alike" if ok else "SOME runs only -> FAIL"), flush=True)
+        if not ok:
+            sys.exit(1)
+        continue
+    bad = []
+    U1, V1, objs1, flags1, gd1 = one[0]
+    Un = np.concatenate([r[0][0] for r in res]) if m else U1
+    errs = {"U": rel(Un, U1), "V": rel(res[0][0][1], V1)}
+    for key in KEYS:
+        errs[key] = max([abs(a[key] - b[key]) / max(abs(b[key]), 1e-12) for a, b, f in zip(res[0][0][2], objs1, flags1)
+                         if not ((f & 2) and key in ("recon", "obj"))] or [0.0])
+    bad += [key for key, e in errs.items() if not (e < 1e-5)]
+    if not all(np.array_equal(r[0][1], res[0][0][1]) and r[0][2] == res[0][0][2] and r[0][3] == res[0][0][3] for r in res[1:]):
+        bad.append("replicated state differs between ranks")
+    if not all(np.array_equal(r[0][0], r[1][0]) and np.array_equal(r[0][1], r[1][1]) and r[0][2] == r[1][2] for r in res):
+        bad.append("run-to-run difference")
+    if not (np.isfinite(Un).all() and np.isfinite(res[0][0][1]).all()):
+        bad.append("non-finite")
+    worst = max(worst, max(errs.values()))
+    print("%3d %s  %s%s" % (ci, tag, " ".join("%s %.1e" % kv for kv in errs.items()), ("   FAIL: " + ", ".join(bad)) if bad else ""), flush=True)
+    if bad:
+        sys.exit(1)
+print("all %d multi-rank cases within 1e-5 of the single-rank step, identical across ranks and runs (worst %.1e, %.0f s)" % (ncases, worst, time.time() - t_start))
