@@ -1,0 +1,30 @@
+"""Seeded random shapes (a bounded run of tools/fuzz_shapes.py and tools/fuzz_ranks.py, each in a process of its own):
+tiny and ragged matrices, k = 1 .. 128, both storages of X, the tradeoff feedback, candidate scores -- against the float64
+oracle at 1e-4 -- and the same kind of shapes through the in-library multi-rank step on 2 .. 8 thread ranks (RCCL test
+double; ranks without rows, ranks without a latent column) against the single-rank step at 1e-5, bit-identical across
+ranks and runs.  The long runs (hundreds of cases per seed) are in profiles/r05_fuzz_*.txt."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, seed, cases, timeout):
+    env = dict(os.environ, SEED=str(seed), CASES=str(cases))
+    env.pop("PRMF_RCCL_LIB", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)], env=env, capture_output=True, text=True, timeout=timeout)
+    tail = "\n".join((r.stdout + "\n" + r.stderr).strip().splitlines()[-12:])
+    assert r.returncode == 0, tail
+    assert ("all %d " % cases) in r.stdout, tail
+
+
+def test_random_shapes_vs_oracle():
+    _run("fuzz_shapes.py", seed=11, cases=60, timeout=600)
+
+
+def test_random_shapes_through_the_multi_rank_step():
+    _run("fuzz_ranks.py", seed=12, cases=40, timeout=600)
