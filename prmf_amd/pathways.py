@@ -169,5 +169,15 @@ class PathwayLibrary(object):
         a = self.local_adj[p]
         return float(vs.dot(self.degs[p] * vs - a.dot(vs)))
 
+    def laplacian_quadratics(self, p, V, cols):
+        """v^T L_p v for the columns `cols` of V (n x k): ONE sparse product per pathway instead of one per (latent, pathway)
+        pair -- force_distinct_lapls asks for 64 x 61 pairs at the 50000 x 20000, k = 64 shape (3904 SciPy calls, 44 ms of
+        a 0.33 s solve).  Per column the arithmetic is laplacian_quadratic's: the same row-wise accumulation in the sparse
+        product, the same contiguous dot at the end (columns are made contiguous), so the values are identical."""
+        s = self.supports[p]
+        Vs = np.asfortranarray(np.asarray(V, dtype=np.float64)[np.ix_(s, np.asarray(cols, dtype=np.int64))])      # support rows only
+        T = np.asfortranarray(self.degs[p][:, None] * Vs - self.local_adj[p].dot(Vs))
+        return [float(Vs[:, j].dot(T[:, j])) for j in range(Vs.shape[1])]
+
     def arrays(self):
         return (self.sup_ptr, self.sup_idx, self.sup_deg, self.sup_ldiag, self.row_ptr, self.col_local, self.w)

@@ -440,11 +440,23 @@ def restrict(scores_kP, latent_to_pathway_data, percentile=19.9):
     """prmf_runner.py:129-194 on a precomputed k x P score matrix (the GPU scores
     every pair; only the still-candidate ones are read here)."""
     rv = {}
+    # the percentile of every latent's candidate scores: ONE numpy call per list length (np.percentile along an axis
+    # gives each row the value the per-row call gives, bit for bit -- tested), not one per latent: the lists have the
+    # same length for all latents in the first rounds (64 calls of 35 us each per round at k = 64)
+    by_len = {}
+    for k, data in latent_to_pathway_data.items():
+        if len(data) > 1:
+            by_len.setdefault(len(data), []).append(k)
+    cut = {}
+    for _n, ks in by_len.items():
+        S = np.stack([scores_kP[k, [x[0] for x in latent_to_pathway_data[k]]] for k in ks])
+        for k, c in zip(ks, np.percentile(S, percentile, axis=1)):
+            cut[k] = c
     for k, data in latent_to_pathway_data.items():
         inds = [x[0] for x in data]
         if len(inds) > 1:
             scores = scores_kP[k, inds]
-            keep = np.where(scores > np.percentile(scores, percentile))[0]
+            keep = np.where(scores > cut[k])[0]
             if len(keep) == 0:
                 # :174-182 all scores tie: the reference asks np.random.choice for a
                 # negative sample size here and raises ValueError; so do we.
@@ -526,11 +538,20 @@ def force_distinct_lapls(V, library, latent_to_pathway_data, k_to_lapl, gamma, d
     (:233-235), so it is the last latent's value."""
     k_last = max(k_to_lapl.keys())
     ign = float(np.sum(1.0 / (V[library.supports[k_to_lapl[k_last]], k_last] + 1)))
+    # v_k^T L_p v_k for every remaining (latent, pathway) pair, one sparse product per pathway (PathwayLibrary.laplacian_quadratics)
+    by_pathway = {}
+    for k, data in latent_to_pathway_data.items():
+        for lapl, _score in data:
+            by_pathway.setdefault(lapl, []).append(k)
+    quad = {}
+    for lapl, ks in by_pathway.items():
+        for k, q in zip(ks, library.laplacian_quadratics(lapl, V, ks)):
+            quad[(k, lapl)] = q
     per_latent = []
     for k, data in latent_to_pathway_data.items():
         ws = []
         for lapl, _score in data:
-            denom = gamma * library.laplacian_quadratic(lapl, V[:, k]) + delta * ign
+            denom = gamma * quad[(k, lapl)] + delta * ign
             ws.append((lapl, 0 if denom == 0 else 1 / denom))
         per_latent.append((k, ws))
     for k, p in _max_weight_matching(per_latent):

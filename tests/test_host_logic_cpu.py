@@ -37,6 +37,10 @@ def test_library_from_edge_lists_matches_oracle_pathways():
         assert np.allclose(W, pw.W.toarray())
         v = np.random.RandomState(p).rand(n)
         assert abs(lib.laplacian_quadratic(p, v) - pw.L.dot(v).dot(v)) < 1e-9
+        # the batched form force_distinct_lapls uses (one sparse product per pathway): the same numbers, bit for bit
+        Vm = np.random.RandomState(100 + p).rand(n, 9)
+        cols = [7, 0, 3, 3, 8]
+        assert lib.laplacian_quadratics(p, Vm, cols) == [lib.laplacian_quadratic(p, Vm[:, c]) for c in cols]
 
 
 def test_library_from_graphs_and_from_sparse(tmp_path):
