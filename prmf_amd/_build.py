@@ -80,6 +80,43 @@ def build_variant(name, defines):
     return out
 
 
+def build_sanitized(outdir):
+    """libprmf_hip_san.so in `outdir`: the same sources with the HOST code under AddressSanitizer + UndefinedBehaviorSanitizer
+    (-fsanitize=address,undefined -fno-gpu-sanitize: device code is compiled as always -- GPU sanitizers are not available
+    on this pool).  Test infrastructure (tests/test_sanitize_cpu.py, tests/test_gpu_native.py); link the driver with the same
+    compiler and flags so that both share one sanitizer runtime."""
+    os.makedirs(outdir, exist_ok=True)
+    cc = hipcc()
+    san = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined"]
+    flags = [f for f in FLAGS if f != "-O3"] + ["-O1", "-g"] + san
+
+    def compile_one(src):
+        obj = os.path.join(outdir, src.replace(".hip", ".san.o"))
+        r = subprocess.run([cc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc (sanitized) failed for %s:\n%s" % (src, r.stderr))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    out = os.path.join(outdir, "libprmf_hip_san.so")
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + san[:2] + ["-o", out] + objs + ["-ldl"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link (sanitized) failed:\n%s" % r.stderr)
+    return out
+
+
+def build_sanitized_driver(src, exe, libdir, extra=()):
+    """a C++ driver against libprmf_hip_san.so, compiled by the same clang with the same sanitizers (one runtime for both)"""
+    cc = hipcc()
+    r = subprocess.run([cc, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        "-I", os.path.join(HERE, "..", "include"), "-I/opt/rocm/include", "-x", "c++", src, "-o", exe,
+                        "-L", libdir, "-lprmf_hip_san", "-Wl,-rpath," + libdir] + list(extra), capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("sanitized driver build failed:\n%s" % r.stderr)
+    return exe
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # python -m prmf_amd._build --variant NAME DEF1=1 DEF2=0 ...
         print(build_variant(sys.argv[2], sys.argv[3:]))

@@ -1,0 +1,83 @@
+// Host side of the C-ABI under AddressSanitizer + UndefinedBehaviorSanitizer ("host ASAN/UBSAN on the
+// C-ABI layer"; GPU sanitizers are not available on this pool).  Linked against a HOST-ONLY build of the library
+// (hipcc --cuda-host-only -fsanitize=address,undefined: every translation unit's host code, no device code), so it
+// runs without a GPU -- tests/test_sanitize_cpu.py builds both and runs this.  What it drives is the host arithmetic
+// that decides how kernels are launched: the sweep planner (balanced decomposition, slab masks: 64-bit shifts, vectors
+// sized by the plan) over a wide random range of shapes, and the argument / error paths that run before any device work.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include "prmf_hip.h"
+#include "prmf_hip_debug.h"
+
+static int failures = 0;
+#define CHECK(cond, ...)                         \
+  do {                                           \
+    if (!(cond)) {                               \
+      std::printf("FAILED %s: ", #cond);         \
+      std::printf(__VA_ARGS__);                  \
+      std::printf("\n");                         \
+      ++failures;                                \
+    }                                            \
+  } while (0)
+
+int main(int argc, char** argv) {
+  const long cases = argc > 1 ? std::atol(argv[1]) : 200000;
+  std::mt19937_64 rng(20261005);
+  auto uni = [&](long long lo, long long hi) { return (long long)(lo + (long long)(rng() % (unsigned long long)(hi - lo + 1))); };
+  long long checked = 0;
+  for (long i = 0; i < cases; ++i) {
+    const int xd = (int)(rng() & 1);
+    // log-uniform sizes: 1 .. 2^19 rows / depth, every k, CU counts of whole and harvested parts
+    const long long rows = uni(1, 1LL << uni(0, 19)), depth = uni(1, 1LL << uni(0, 19));
+    const int k = (int)uni(1, 128);
+    const int cus_list[] = {1, 7, 8, 64, 104, 228, 256, 304};
+    const int n_cus = cus_list[rng() % 8];
+    int out[8];
+    std::memset(out, 0xff, sizeof out);
+    const int rc = prmf_debug_plan_sweep(xd, rows, depth, k, n_cus, out);
+    CHECK(rc == PRMF_OK, "rc %d for x_dtype %d rows %lld depth %lld k %d cus %d", rc, xd, rows, depth, k, n_cus);
+    if (rc != PRMF_OK) continue;
+    const int waves = out[0], tiles = out[1], panel_rows = out[2], grid = out[3], slices = out[4], slabs = out[5], panels = out[7];
+    CHECK((waves == 4 || waves == 8) && (tiles == 1 || tiles == 2), "waves %d tiles %d", waves, tiles);
+    CHECK(panel_rows == waves * tiles * 32, "panel rows %d", panel_rows);
+    CHECK(panels == (int)((rows + panel_rows - 1) / panel_rows), "panels %d for %lld rows of %d", panels, rows, panel_rows);
+    CHECK(grid >= 1 && grid <= 2 * n_cus + 8, "grid %d for %d CUs", grid, n_cus);
+    CHECK(slices == 1 || slices == 2 || slices == 4 || slices == 8, "slices %d", slices);
+    CHECK(slabs >= 1 && slabs <= 64, "slabs per panel %d (64-bit panel mask)", slabs);
+    ++checked;
+  }
+  // argument and error paths that end before any device work (or at the first HIP call when there is no GPU)
+  prmf_ctx* ctx = nullptr;
+  CHECK(prmf_create(nullptr, 0, 10, 10, 4, 0, 1, 0, 0) == PRMF_ERR_ARG, "null out");
+  CHECK(prmf_create(&ctx, 0, 10, 0, 4, 0, 1, 0, 0) == PRMF_ERR_ARG && ctx == nullptr, "n = 0");
+  CHECK(std::strstr(prmf_last_error(nullptr), "bad shape") != nullptr, "message: %s", prmf_last_error(nullptr));
+  CHECK(prmf_create(&ctx, 0, -1, 10, 4, 0, 1, 0, 0) == PRMF_ERR_ARG, "m < 0");
+  CHECK(prmf_create(&ctx, 0, 10, 10, 4000, 0, 1, 0, 0) == PRMF_ERR_UNSUPPORTED, "k too large");
+  CHECK(prmf_create(&ctx, 0, 10, 10, 4, 7, 1, 0, 0) == PRMF_ERR_ARG, "x_dtype");
+  CHECK(prmf_create(&ctx, 0, 10, 10, 4, 0, 2, 2, 0) == PRMF_ERR_ARG, "rank >= nranks");
+  CHECK(prmf_create(&ctx, 0, 10, 10, 4, 0, 0, 0, 0) == PRMF_ERR_ARG, "nranks < 1");
+  {
+    const int rc = prmf_create(&ctx, 0, 64, 300, 6, 0, 1, 0, 0);      // a GPU box creates it; without one the first HIP call fails loudly
+    CHECK(rc == PRMF_OK || (rc == PRMF_ERR_HIP && ctx == nullptr), "create rc %d", rc);
+    if (rc == PRMF_OK) CHECK(prmf_destroy(ctx) == PRMF_OK, "destroy");
+    ctx = nullptr;
+  }
+  CHECK(prmf_destroy(nullptr) == PRMF_OK, "destroy(NULL)");
+  CHECK(prmf_step(nullptr, nullptr, nullptr, 1, 1.0, 1.0, -1.0, nullptr, nullptr, nullptr) == PRMF_ERR_ARG, "step(NULL)");
+  CHECK(prmf_step_dist(nullptr, nullptr, nullptr, 1, 1.0, 1.0, -1.0, nullptr, nullptr, nullptr) == PRMF_ERR_ARG, "step_dist(NULL)");
+  CHECK(prmf_set_comm_timeout(nullptr, 1.0) == PRMF_ERR_ARG && prmf_set_global_rows(nullptr, 1) == PRMF_ERR_ARG, "NULL ctx setters");
+  CHECK(prmf_comm_init(nullptr, nullptr) == PRMF_ERR_ARG, "comm_init(NULL)");
+  {
+    int w = 0, ph = 0, mx = 0;
+    const int n = prmf_debug_stamp_layout(&w, &ph, &mx);
+    CHECK(n > ph && ph > w && w >= 2 * mx, "stamp layout %d %d %d %d", n, w, ph, mx);
+    CHECK(prmf_debug_set_stamps((void*)0x1000, (size_t)n - 1) == PRMF_ERR_ARG, "short stamp buffer");
+    CHECK(prmf_debug_set_stamps((void*)0x1000, (size_t)n) == 0 && prmf_debug_set_stamps(nullptr, 0) == 0, "stamp buffer");
+  }
+  CHECK(prmf_abi_version() >= 2, "abi version %d", prmf_abi_version());
+  std::printf("%lld plans checked, %d failures\n", checked, failures);
+  return failures ? 1 : 0;
+}

@@ -53,3 +53,19 @@ def test_native_driver_matches_oracle(tmp_path):
         assert np.allclose(g, want, rtol=1e-4)
     sums = [l for l in lines if l and l[0] == "sumU"][0]
     assert abs(float(sums[1]) - Ur.sum()) < 1e-4 * Ur.sum() and abs(float(sums[3]) - Vr.sum()) < 1e-4 * Vr.sum()
+
+
+def test_native_driver_under_host_asan_ubsan(tmp_path):
+    """The same C++ driver against a build of the library whose HOST code runs under AddressSanitizer +
+    UndefinedBehaviorSanitizer (device code as always: GPU sanitizers are not available on this pool) -- context
+    creation, plans, the pathway library upload, three iterations, records, teardown: any report aborts the run."""
+    from prmf_amd import _build
+    libdir = str(tmp_path / "san")
+    _build.build_sanitized(libdir)
+    exe = _build.build_sanitized_driver(os.path.join(ROOT, "tests", "native", "capi_native.cpp"), str(tmp_path / "capi_native_san"), libdir,
+                                        extra=["-D__HIP_PLATFORM_AMD__", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:protect_shadow_gap=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "native OK" in r.stdout
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
