@@ -88,7 +88,12 @@ def build_sanitized(outdir):
     os.makedirs(outdir, exist_ok=True)
     cc = hipcc()
     san = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined"]
-    flags = [f for f in FLAGS if f != "-O3"] + ["-O1", "-g"] + san
+    # third-party headers are not ours to fix: rocPRIM's temporary-storage size query (segmented_radix_sort_keys with a null
+    # buffer, prep.hip) partitions offsets from a null base pointer -- "applying non-zero offset to null pointer"
+    ignore = os.path.join(outdir, "sanitize_ignorelist.txt")
+    with open(ignore, "w") as fh:
+        fh.write("src:*/include/rocprim/*\nsrc:*/include/hipcub/*\n")
+    flags = [f for f in FLAGS if f != "-O3"] + ["-O1", "-g"] + san + ["-fsanitize-ignorelist=" + ignore]
 
     def compile_one(src):
         obj = os.path.join(outdir, src.replace(".hip", ".san.o"))

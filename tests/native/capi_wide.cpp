@@ -1,0 +1,191 @@
+// The rest of the C-ABI from plain C++, for the host-sanitizer run (tests/test_gpu_native.py builds the library with
+// -fsanitize=address,undefined on its host code and this driver against it): several contexts of different plans
+// (f32 / bf16 X, k = 6 .. 128, 4- and 8-wave sweeps, sliced reductions, ragged sizes), prmf_step with and without the
+// tradeoff feedback and in the eager / direct-residual forms, the phase calls, candidate scores, held-out error, direct
+// residual, timing, introspection, the quantile transform, invalidation, error paths on a live context.  Values are only
+// checked for being finite and sane -- the parity tests own the numbers; what this run is for is every host-side buffer
+// the library sizes from a plan.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <unistd.h>
+
+#include "prmf_hip.h"
+
+static uint32_t lcg_state = 777u;
+static double lcg() {
+  lcg_state = lcg_state * 1664525u + 1013904223u;
+  return ((lcg_state >> 8) + 1) / 16777216.0;
+}
+#define CK(x) do { int _rc = (x); if (_rc != PRMF_OK) { std::fprintf(stderr, "line %d: %s -> %d: %s\n", __LINE__, #x, _rc, prmf_last_error(ctx)); return 2; } } while (0)
+#define HK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { std::fprintf(stderr, "line %d: %s: %s\n", __LINE__, #x, hipGetErrorString(_e)); return 3; } } while (0)
+#define REQUIRE(c) do { if (!(c)) { std::fprintf(stderr, "line %d: %s failed\n", __LINE__, #c); return 4; } } while (0)
+
+static uint16_t to_bf16(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+struct Library {
+  int P;
+  std::vector<int64_t> sup_ptr, row_ptr;
+  std::vector<int32_t> sup_idx, col_local;
+  std::vector<double> sup_deg, sup_ldiag, w;
+};
+// P chains of S genes each, pathway p on genes (p * stride + s) % n, weights 0.5 .. 1.5
+static Library chains(int64_t n, int P, int S) {
+  Library L;
+  L.P = P;
+  L.sup_ptr.resize(P + 1);
+  L.row_ptr.push_back(0);
+  const int64_t stride = n / P > S ? n / P : S;
+  for (int p = 0; p <= P; ++p) L.sup_ptr[p] = (int64_t)p * S;
+  for (int p = 0; p < P; ++p)
+    for (int s = 0; s < S; ++s) {
+      L.sup_idx.push_back((int32_t)(((int64_t)p * stride + s) % n));
+      double deg = 0;
+      if (s > 0) { L.col_local.push_back(s - 1); L.w.push_back(0.5 + (s % 3) * 0.5); deg += L.w.back(); }
+      if (s + 1 < S) { L.col_local.push_back(s + 1); L.w.push_back(0.5 + ((s + 1) % 3) * 0.5); deg += L.w.back(); }
+      L.sup_deg.push_back(deg);
+      L.sup_ldiag.push_back(deg);
+      L.row_ptr.push_back((int64_t)L.col_local.size());
+    }
+  return L;
+}
+
+static int run_case(int64_t m, int64_t n, int k, int x_dtype, unsigned flags, int P, int S, double tradeoff, int steps) {
+  prmf_ctx* ctx = nullptr;
+  std::vector<float> X((size_t)(m * n)), U((size_t)(m * k)), V((size_t)(n * k));
+  double nsq = 0.0;
+  for (auto& x : X) {
+    x = (float)lcg();
+    if (x_dtype == PRMF_X_BF16) { uint32_t u = (uint32_t)to_bf16(x) << 16; std::memcpy(&x, &u, 4); }
+    nsq += (double)x * x;
+  }
+  for (auto& u : U) u = (float)(3.0 * lcg());
+  for (auto& v : V) v = (float)(3.0 * lcg());
+  void* dX = nullptr;
+  float *dU = nullptr, *dV = nullptr;
+  if (x_dtype == PRMF_X_BF16) {
+    std::vector<uint16_t> Xh(X.size());
+    for (size_t i = 0; i < X.size(); ++i) Xh[i] = to_bf16(X[i]);
+    HK(hipMalloc(&dX, Xh.size() * 2));
+    HK(hipMemcpy(dX, Xh.data(), Xh.size() * 2, hipMemcpyHostToDevice));
+  } else {
+    HK(hipMalloc(&dX, X.size() * 4));
+    HK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice));
+  }
+  HK(hipMalloc(&dU, U.size() * 4 + 16));
+  HK(hipMalloc(&dV, V.size() * 4 + 16));
+  HK(hipMemcpy(dU, U.data(), U.size() * 4, hipMemcpyHostToDevice));
+  HK(hipMemcpy(dV, V.data(), V.size() * 4, hipMemcpyHostToDevice));
+  CK(prmf_create(&ctx, 0, m, n, k, x_dtype, 1, 0, flags));
+  CK(prmf_set_x(ctx, dX, n, nsq, nullptr));
+  const Library L = chains(n, P, S);
+  CK(prmf_set_pathway_library(ctx, L.P, L.sup_ptr.data(), L.sup_idx.data(), L.sup_deg.data(), L.sup_ldiag.data(), L.row_ptr.data(),
+                              L.col_local.data(), L.w.data(), nullptr));
+  std::vector<int32_t> active((size_t)k);
+  for (int i = 0; i < k; ++i) active[i] = i % P;
+  CK(prmf_set_active(ctx, active.data(), nullptr));
+  prmf_sweep_info info;
+  CK(prmf_get_sweep_info(ctx, &info));
+  REQUIRE(info.grid_xv >= 1 && info.grid_xtu >= 1 && info.splits_xv >= 1 && info.splits_xtu >= 1);
+  CK(prmf_set_timing(ctx, 1));
+  std::vector<double> obj((size_t)steps * PRMF_OBJ_STRIDE);
+  double gd[2] = {0, 0};
+  const double gamma = std::sqrt(nsq) / k, delta = 10.0 / std::sqrt(nsq);
+  CK(prmf_step(ctx, dU, dV, steps, gamma, delta, tradeoff, obj.data(), gd, nullptr));
+  for (int i = 0; i < steps; ++i) REQUIRE(std::isfinite(obj[(size_t)i * PRMF_OBJ_STRIDE + PRMF_OBJ_OBJ]) && obj[(size_t)i * PRMF_OBJ_STRIDE + PRMF_OBJ_RECON] >= 0.0);
+  double a = 0, b = 0, c = 0;
+  CK(prmf_get_timing(ctx, &a, &b, &c));
+  REQUIRE(a > 0 && b > 0);
+  CK(prmf_set_timing(ctx, 0));
+  // the phase calls (what a host that drives the collectives itself uses), two iterations
+  CK(prmf_begin(ctx, dU, dV, gamma, delta, -1.0, nullptr));
+  for (int it = 0; it < 2; ++it) {
+    CK(prmf_phase_u(ctx, nullptr));
+    CK(prmf_phase_q(ctx, nullptr));
+    CK(prmf_phase_v(ctx, nullptr));
+    CK(prmf_phase_post(ctx, nullptr));
+  }
+  double obj2[2 * PRMF_OBJ_STRIDE];
+  CK(prmf_end(ctx, 2, obj2, gd, nullptr));
+  REQUIRE(std::isfinite(obj2[PRMF_OBJ_STRIDE + PRMF_OBJ_OBJ]));
+  // candidate scores, direct residual, held-out error
+  std::vector<double> scores((size_t)k * P), err((size_t)m);
+  CK(prmf_score_candidates(ctx, dV, scores.data(), nullptr));
+  for (double s : scores) REQUIRE(std::isfinite(s));
+  double rsq = -1.0;
+  CK(prmf_residual_sq(ctx, dU, dV, &rsq, nullptr));
+  REQUIRE(rsq >= 0.0 && std::isfinite(rsq));
+  if (m <= 4000) {
+    CK(prmf_cv_error(ctx, dV, err.data(), nullptr));
+    for (double e : err) REQUIRE(e >= 0.0 && e <= 1.0 + 1e-9);
+  }
+  // the caller rewrites V: invalidate, step again; then error paths on the live context
+  HK(hipMemcpy(dV, V.data(), V.size() * 4, hipMemcpyHostToDevice));
+  CK(prmf_invalidate_factors(ctx));
+  CK(prmf_step(ctx, dU, dV, 1, gamma, delta, -1.0, obj.data(), gd, nullptr));
+  REQUIRE(prmf_step(ctx, nullptr, dV, 1, 1.0, 1.0, -1.0, obj.data(), gd, nullptr) == PRMF_ERR_ARG);
+  REQUIRE(prmf_step(ctx, dU, dV, -1, 1.0, 1.0, -1.0, obj.data(), gd, nullptr) == PRMF_ERR_ARG);
+  active[0] = P;      // out of range
+  REQUIRE(prmf_set_active(ctx, active.data(), nullptr) == PRMF_ERR_ARG);
+  REQUIRE(prmf_step_dist(ctx, dU, dV, 1, 1.0, 1.0, -1.0, obj.data(), gd, nullptr) == PRMF_ERR_STATE);      // no communicator
+  CK(prmf_destroy(ctx));
+  (void)hipFree(dX); (void)hipFree(dU); (void)hipFree(dV);
+  std::printf("case %lld x %lld k=%d %s flags %u tradeoff %.1f: ok (grid %d/%d, slabs %d/%d, sweeps %.3f/%.3f ms)\n", (long long)m, (long long)n, k,
+              x_dtype == PRMF_X_BF16 ? "bf16" : "f32", flags, tradeoff, info.grid_xv, info.grid_xtu, info.splits_xv, info.splits_xtu, a, b);
+  return 0;
+}
+
+int main() {
+  if (prmf_abi_version() != PRMF_ABI_VERSION) return 1;
+  int rc;
+  if ((rc = run_case(70, 150, 6, PRMF_X_F32, 0, 3, 12, -1.0, 3))) return rc;                     // the CLI's default k: element-wise factor loads
+  if ((rc = run_case(1, 37, 1, PRMF_X_BF16, 0, 1, 2, -1.0, 2))) return rc;                       // one sample, one latent column
+  if ((rc = run_case(333, 2500, 16, PRMF_X_F32, 0, 5, 40, 0.5, 3))) return rc;                   // tradeoff feedback: 7 launches + direct residual
+  if ((rc = run_case(900, 700, 47, PRMF_X_F32, PRMF_FLAG_EAGER_OBJECTIVE, 4, 30, -1.0, 3))) return rc;
+  if ((rc = run_case(1500, 9000, 64, PRMF_X_BF16, PRMF_FLAG_DIRECT_RESIDUAL, 8, 60, -1.0, 2))) return rc;
+  if ((rc = run_case(640, 70000, 64, PRMF_X_BF16, 0, 6, 50, -1.0, 2))) return rc;                // X V: 18 MB factor, 8-wave form, 2 row panels
+  if ((rc = run_case(40000, 700, 64, PRMF_X_BF16, 0, 3, 50, -1.0, 2))) return rc;                // X^T U: 10 MB factor over 2 panels
+  if ((rc = run_case(2100, 1300, 100, PRMF_X_F32, 0, 7, 35, -1.0, 2))) return rc;                // f32 X, k > 64: 32-row wave tiles, column-split epilogue
+  if ((rc = run_case(3000, 2600, 128, PRMF_X_BF16, 0, 9, 70, 0.3, 2))) return rc;                // k = 128 with the feedback
+  {
+    // the quantile transform (no context): 500 x 30 float64 with a NaN and a constant column
+    const int64_t m = 500, n = 30;
+    std::vector<double> A((size_t)(m * n));
+    for (auto& x : A) x = lcg();
+    for (int64_t i = 0; i < m; ++i) A[(size_t)(i * n + 5)] = 2.0;
+    A[7 * n + 3] = NAN;
+    double* dA = nullptr;
+    HK(hipMalloc(&dA, A.size() * 8));
+    HK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice));
+    prmf_ctx* ctx = nullptr;
+    CK(prmf_quantile_transform(0, dA, m, n, n, nullptr, 0, 1000, nullptr));
+    std::vector<int64_t> rows;
+    for (int64_t i = 0; i < m; i += 3) rows.push_back(i);
+    CK(prmf_quantile_transform(0, dA, m, n, n, rows.data(), (int64_t)rows.size(), 100, nullptr));
+    HK(hipMemcpy(A.data(), dA, A.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < m; ++i)
+      for (int64_t j = 0; j < n; ++j) {
+        const double v = A[(size_t)(i * n + j)];
+        if (i == 7 && j == 3) { REQUIRE(std::isnan(v)); } else { REQUIRE(v >= 0.0 && v <= 1.0); }
+      }
+    (void)hipFree(dA);
+  }
+  std::printf("wide OK\n");
+  std::fflush(stdout);
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+  // under the host sanitizers: leave without running the HIP / HSA runtimes' exit handlers -- AMD's ASan runtime aborts in its
+  // device allocator once the HSA runtime has unloaded ("dev_runtime_unloaded_" CHECK), after everything of ours has been torn down
+  _exit(0);
+#endif
+#endif
+  return 0;
+}

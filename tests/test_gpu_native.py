@@ -69,3 +69,11 @@ def test_native_driver_under_host_asan_ubsan(tmp_path):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "native OK" in r.stdout
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+    # the rest of the API (tests/native/capi_wide.cpp): nine contexts of different plans, tradeoff / eager / direct-residual
+    # forms, phase calls, scores, held-out error, direct residual, timing, quantile transform, error paths on a live context
+    wide = _build.build_sanitized_driver(os.path.join(ROOT, "tests", "native", "capi_wide.cpp"), str(tmp_path / "capi_wide_san"), libdir,
+                                         extra=["-D__HIP_PLATFORM_AMD__", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([wide], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "wide OK" in r.stdout and r.stdout.count(": ok (") == 9
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
