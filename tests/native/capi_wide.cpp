@@ -1,10 +1,9 @@
-// The rest of the C-ABI from plain C++, for the host-sanitizer run (tests/test_gpu_native.py builds the library with
-// -fsanitize=address,undefined on its host code and this driver against it): several contexts of different plans
+// The rest of the C-ABI from plain C++ (tests/test_gpu_native.py): several contexts of different plans
 // (f32 / bf16 X, k = 6 .. 128, 4- and 8-wave sweeps, sliced reductions, ragged sizes), prmf_step with and without the
 // tradeoff feedback and in the eager / direct-residual forms, the phase calls, candidate scores, held-out error, direct
 // residual, timing, introspection, the quantile transform, invalidation, error paths on a live context.  Values are only
-// checked for being finite and sane -- the parity tests own the numbers; what this run is for is every host-side buffer
-// the library sizes from a plan.
+// checked for being finite and sane -- the parity tests own the numbers; what this run is for is every entry point and
+// every host-side buffer the library sizes from a plan, from a caller that is not Python.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>

@@ -1,6 +1,6 @@
 // Host side of the C-ABI under AddressSanitizer + UndefinedBehaviorSanitizer ("host ASAN/UBSAN on the
 // C-ABI layer"; GPU sanitizers are not available on this pool).  Linked against a HOST-ONLY build of the library
-// (hipcc --cuda-host-only -fsanitize=address,undefined: every translation unit's host code, no device code), so it
+// (prmf_amd._build.build_sanitized: the host code of every translation unit instrumented, device code as always); it
 // runs without a GPU -- tests/test_sanitize_cpu.py builds both and runs this.  What it drives is the host arithmetic
 // that decides how kernels are launched: the sweep planner (balanced decomposition, slab masks: 64-bit shifts, vectors
 // sized by the plan) over a wide random range of shapes, and the argument / error paths that run before any device work.

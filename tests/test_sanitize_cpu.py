@@ -1,5 +1,5 @@
 """Host side of the C-ABI under AddressSanitizer + UndefinedBehaviorSanitizer (GPU sanitizers are
-not available on this pool): the library is rebuilt with -fsanitize=address,undefined on its HOST code (device code as
+not available on this pool): the library is rebuilt with both sanitizers on its HOST code only (prmf_amd._build.build_sanitized; device code as
 always) and tests/native/host_sanitize.cpp drives what runs without a GPU -- the sweep planner over 300 000 random
 shapes (decomposition, slab masks: 64-bit shifts, plan vectors) and the argument / error paths in front of any device
 work.  Any sanitizer report aborts the driver (-fno-sanitize-recover)."""
