@@ -912,7 +912,13 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
   // f32 X too (three-piece split; hook per 16-column tile): X^T U at the C3 shape 0.777 -> 0.745 ms, the N = 8 share of C5
   // 0.725 / 0.715 -> 0.711 / 0.705 ms -- unsliced; with the 4 slices of the 4-wave form it had measured equal.
   const bool pp_ok = PRMF_PP != 0 && (x_dtype == 1 || (PRMF_PP_F32 != 0 && NT == 2)) && NT >= PRMF_PP_MIN_NT && NT <= PRMF_PP_MAX_NT;
-  const double wide_from = (pp_ok && M >= PRMF_PP_WIDE_MIN_ROWS) ? PRMF_PP_WIDE_MB * 1024 * 1024 : SWEEP_WIDE_SMALL_FACTOR_BYTES;
+#ifndef PRMF_WIDE_F32_MB
+#define PRMF_WIDE_F32_MB 4.0      // f32 X, k = 33..64, >= PRMF_PP_WIDE_MIN_ROWS rows: the 8-wave form from this factor size (8 = the general rule)
+#endif
+  double wide_from = (pp_ok && M >= PRMF_PP_WIDE_MIN_ROWS) ? PRMF_PP_WIDE_MB * 1024 * 1024 : SWEEP_WIDE_SMALL_FACTOR_BYTES;
+  // f32 X at k = 33..64 too (round 5): X V of the 50000 x 20000 shape with the CLI's default storage (5.1 MB factor) 0.786 -> 0.756 ms in the
+  // 8-wave unsliced form, iteration -1.7 %, 5 of 5 interleaved rounds (profiles/r05_ab_f32_xv_8wave.txt); k > 64 not measured, not changed
+  if (x_dtype == 0 && NT == 2 && M >= PRMF_PP_WIDE_MIN_ROWS && PRMF_WIDE_F32_MB * 1024 * 1024 < wide_from) wide_from = PRMF_WIDE_F32_MB * 1024 * 1024;
   if (NT >= 2 && factor_bytes >= wide_from) {
     p.nw = SWEEP_NW_WIDE;
     p.bdb = true;

@@ -98,10 +98,12 @@ def test_sweep_plans_of_the_benchmark_shapes():
     xv, xtu = plan(BF16, 50000, 20000, 64), plan(BF16, 20000, 50000, 64)
     assert (xv["waves"], xv["panel_rows"], xv["grid"], xv["slices"], xv["panels"], xv["double_buffered"]) == (8, 512, 256, 1, 98, 3)
     assert (xtu["waves"], xtu["panel_rows"], xtu["grid"], xtu["slices"], xtu["panels"], xtu["double_buffered"]) == (8, 512, 256, 1, 40, 3)
-    # the same shape with f32 X: X V 4-wave, X^T U 8-wave, no ping-pong (64-row wave tiles at k = 33..64)
+    # the same shape with f32 X: both sweeps 8-wave (round 5: X V too, from a 4 MB factor on >= 16384 rows), no ping-pong
+    # (64-row wave tiles at k = 33..64); its four-rank share (12500 rows) keeps the 4-wave form for X V
     xv, xtu = plan(F32, 50000, 20000, 64), plan(F32, 20000, 50000, 64)
-    assert (xv["waves"], xv["tiles_per_wave"], xv["slices"], xv["double_buffered"]) == (4, 2, 1, 1)
+    assert (xv["waves"], xv["tiles_per_wave"], xv["slices"], xv["double_buffered"]) == (8, 2, 1, 1)
     assert (xtu["waves"], xtu["tiles_per_wave"], xtu["slices"], xtu["double_buffered"]) == (8, 2, 1, 1)
+    assert plan(F32, 12500, 20000, 64)["waves"] == 4 and plan(F32, 50000, 20000, 128)["waves"] == 8
     # the two- and four-rank shares of C3: 25000 rows take the ping-pong form for X V, 12500 rows (< 16384) keep the 4-wave one
     assert (plan(BF16, 25000, 20000, 64)["waves"], plan(BF16, 25000, 20000, 64)["double_buffered"]) == (8, 3)
     assert (plan(BF16, 12500, 20000, 64)["waves"], plan(BF16, 12500, 20000, 64)["double_buffered"]) == (4, 1)
