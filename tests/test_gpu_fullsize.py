@@ -192,3 +192,41 @@ def test_whole_round_vs_fp64_at_full_size(workload, x_dtype, steps):
         assert worst[key] < 1e-4, (key, worst)
     assert float(V.min()) >= EPS and bool(torch.isfinite(U).all())
     eng.close()
+
+
+@pytest.mark.parametrize("workload,x_dtype,rounds", [("c3", "bf16", 10), ("c3", "f32", 10), ("c5shard", "bf16", 10)])
+def test_hundred_iterations_vs_fp64_at_full_size(workload, x_dtype, rounds):
+    """A whole solve's worth of inner iterations at BASELINE.json's headline size: 10 rounds of 10 (prmf_runner.py:715-775)
+    with a NEW active pathway per latent column every round, as the outer loop re-samples them (:717-729), the float32
+    state carried across the rounds -- against the float64 restatement run next to it.  After rounds 1, 3 and 10 (10, 30,
+    100 iterations): U, V per array and per 32-row tile, and all five objective components of the round's last iteration,
+    at the 1e-4 bar north_star states.  SURVEY Appendix D measured this drift at 1000 x 4000 only (1e-6 after 200
+    iterations, saturating); this is the same measurement at 50000 x 20000, k = 64 (bf16 and f32 storage of X) and at one
+    rank's share of BASELINE configs[4] (25000 x 25000, k = 128)."""
+    import torch
+    from fp64_model import Fp64Model
+    eng, Xd, U, V, pathways, active, gamma, delta = _engine(torch, workload, x_dtype, 23)
+    P, k = len(pathways), V.shape[1]
+    U64, V64 = U.double(), V.double()
+    out = {}
+    for rnd in range(rounds):
+        active = [(kk + 7 * rnd) % P for kk in range(k)]
+        eng.set_active(active)
+        mdl = Fp64Model(torch, Xd, pathways, active, gamma, delta)
+        objs, _ = eng.step(U, V, 10, gamma, delta)
+        for _it in range(10):
+            _, U64, _, V64 = mdl.step(U64, V64)
+        if rnd + 1 in (1, 3, rounds):
+            od = mdl.objective(U64, V64)
+            res = {"rel_" + key: abs(objs[-1][key] - od[key]) / abs(od[key]) for key in OBJ_KEYS}
+            res.update(_tile_check(torch, "U", U, U64, 1e-3))
+            res.update(_tile_check(torch, "V", V, V64, 1e-3))
+            res["flags"] = int(max(eng.last_flags))
+            out[10 * (rnd + 1)] = res
+            report("hundred_iterations_vs_fp64[%s-%s]" % (workload, x_dtype), iterations=10 * (rnd + 1), **res)
+            assert res["rel_U"] < 1e-4 and res["rel_V"] < 1e-4, (rnd, res)
+            assert res["bad_tiles_U"] == 0 and res["bad_tiles_V"] == 0, (rnd, res)
+            for key in OBJ_KEYS:
+                assert res["rel_" + key] < 1e-4, (rnd, key, res)
+    assert float(V.min()) >= EPS and bool(torch.isfinite(U).all())
+    eng.close()
