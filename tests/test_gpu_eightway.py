@@ -134,15 +134,15 @@ def _share_worker(workload, variants, steps, q):
     q.put(result)
 
 
-@pytest.mark.parametrize("workload,variants", [
-    ("c3", [(8, "colshard"), (8, "replicated"), (4, "colshard")]),      # BASELINE configs[3]: 6250 x 20000 per rank, kc = 8
-    ("c5", [(8, "colshard"), (8, "replicated"), (4, "colshard")]),      # BASELINE configs[4]: 25000 x 25000 per rank, kc = 16
+@pytest.mark.parametrize("workload,variants,steps", [
+    ("c3", [(8, "colshard"), (8, "replicated"), (4, "colshard")], 3),      # BASELINE configs[3]: 6250 x 20000 per rank, kc = 8
+    ("c5", [(8, "colshard"), (8, "replicated"), (4, "colshard")], 3),      # BASELINE configs[4]: 25000 x 25000 per rank, kc = 16
+    ("c3", [(8, "colshard")], 30),                                         # three rounds' worth: the sharded run does not drift away
 ])
-def test_step_dist_four_and_eight_ranks_at_real_share_shapes(workload, variants, mock):
-    """prmf_step_dist on 8 (and 4) ranks, both V-update modes, 3 iterations, against the single-rank prmf_step on the
-    whole matrix (the same kernels summing in another order: float32, so 1e-5 as for two ranks); the replicated state --
-    V, every objective record, the flags -- must agree bit for bit across the ranks."""
-    steps = 3
+def test_step_dist_four_and_eight_ranks_at_real_share_shapes(workload, variants, steps, mock):
+    """prmf_step_dist on 8 (and 4) ranks, both V-update modes, 3 iterations (and 30 on 8 ranks), against the single-rank
+    prmf_step on the whole matrix (the same kernels summing in another order: float32, so 1e-5 as for two ranks); the
+    replicated state -- V, every objective record, the flags -- must agree bit for bit across the ranks."""
     out = _in_worker(_share_worker, (workload, variants, steps), {"PRMF_RCCL_LIB": mock}, deadline_s=1500)
     from prmf_amd import synthetic as syn
     m = syn.CONFIGS[workload][0]
