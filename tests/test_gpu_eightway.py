@@ -608,3 +608,43 @@ def test_host_driven_thread_ranks_on_the_gpu(world, k, mode, tradeoff):
     eo = max(relmax([o[key] for o in objs], [t[key] for t in tr]) for key in KEYS)
     report("host_driven_thread_ranks[%d-%d-%s]" % (world, k, mode), rel_U=eu, rel_V=ev, rel_obj=eo)
     assert eu < 1e-4 and ev < 1e-4 and eo < 1e-4
+
+
+def _medium_pathway_worker(world, mode, q):
+    from oracle import prmf_oracle as orc
+    from prmf_amd import PathwayLibrary
+    from prmf_amd.ranks import LocalRanks
+    from prmf_amd.solver import nmf_pathway
+    m, n, k, P = 700, 3000, 12, 40
+    case = synth.small_case(seed=31, m=m, n=n, k=k, P=P, order=60)
+    lib = PathwayLibrary.from_edge_lists(n, case["pathways"])
+    np.random.seed(5)                                    # rank 0's draws are the solve's
+
+    def body(view):
+        rounds, trace = [], []
+        U, V, od = nmf_pathway(case["X"], None, library=lib, gamma=1.0, k_latent=k, max_iter=300, round_log=rounds, trace=trace,
+                               dist_mode=mode, group=view)
+        l2p = od["latent_to_pathway_data"]
+        return U, V, [t["obj"] for t in trace], rounds, [[int(p) for p, _s in l2p[kk]] for kk in sorted(l2p)]
+
+    res = LocalRanks(world).run(body)
+    pws = [orc.pathway_from_edges(n, e, nodes, w) for (e, w, nodes) in case["pathways"]]
+    r_ref, t_ref = [], []
+    np.random.seed(5)
+    Ur, Vr, odr = orc.nmf_pathway(case["X"], pws, gamma=1.0, k_latent=k, max_iter=300, round_log=r_ref, trace=t_ref)
+    mr = odr["latent_to_pathway_data"]
+    q.put((res, Ur, Vr, [t["obj"] for t in t_ref], r_ref, [[int(p) for p, _s in mr[kk]] for kk in sorted(mr)]))
+
+
+def test_nmf_pathway_at_medium_size_on_five_ranks_vs_oracle(mock):
+    """The sharded outer solver where the goldens do not reach (700 x 3000, k = 12 on FIVE ranks: kc = 3, ranks 4 owns no
+    column; 40 candidate pathways, several `restrict` rounds, the matching): every rank returns the same result, and it is
+    the oracle's -- the same assignment in every round, the same 200 iterations, the same final map, trace / U / V at 1e-4."""
+    res, Ur, Vr, t_ref, r_ref, m_ref = _in_worker(_medium_pathway_worker, (5, "colshard"), {"PRMF_RCCL_LIB": mock}, deadline_s=900)
+    U0, V0, tr0, rounds0, map0 = res[0]
+    for U, V, tr, rounds, mp_ in res[1:]:
+        assert np.array_equal(U0, U) and np.array_equal(V0, V) and tr0 == tr and rounds0 == rounds and map0 == mp_
+    assert rounds0 == r_ref and len(tr0) == len(t_ref) and map0 == m_ref
+    e_tr, eu, ev = relmax(tr0, t_ref), rel(U0, Ur), rel(V0, Vr)
+    report("nmf_pathway_medium_five_ranks", iterations=len(tr0), rounds=len(rounds0), rel_trace=e_tr, rel_U=eu, rel_V=ev)
+    assert e_tr < 1e-4 and eu < 1e-4 and ev < 1e-4

@@ -417,3 +417,33 @@ def test_cli_library_cache(golden_dir, tmp_path):
     vals, mapping = _read_obj(str(tmp_path / "out1" / "obj.txt"))
     assert mapping == json.loads(str(g["mapping"]))
     assert max(obj_txt_errors(vals, json.loads(str(g["obj_txt"]))).values()) < TOL_OBJ
+
+
+@pytest.mark.parametrize("m,n,k,P,x_dtype", [(700, 3000, 12, 40, "f32"), (300, 9000, 20, 64, "bf16")])
+def test_outer_solver_at_medium_size_vs_oracle(m, n, k, P, x_dtype):
+    """The whole outer loop (prmf_runner.py:556-792: per-round pathway sampling, candidate scoring, `restrict`, the
+    matching, best iterate, stopping rule) at a size the reference's own goldens do not reach (they are 100 x 1000, k = 6,
+    6 pathways: one sweep workgroup): 40 / 64 candidate pathways per latent column, several `restrict` rounds -- against
+    the oracle's nmf_pathway (pinned to the reference by the goldens) consuming the same legacy RNG stream: the same
+    assignment in every round, the same number of iterations, the same final map; trace, U, V at the 1e-4 bar."""
+    from oracle import prmf_oracle as orc
+    from prmf_amd import PathwayLibrary
+    from prmf_amd.solver import nmf_pathway
+    case = synth.small_case(seed=31, m=m, n=n, k=k, P=P, order=60, bf16_x=(x_dtype == "bf16"))
+    X = case["X"]
+    pws = [orc.pathway_from_edges(n, e, nodes, w) for (e, w, nodes) in case["pathways"]]
+    lib = PathwayLibrary.from_edge_lists(n, case["pathways"])
+    r_ref, t_ref = [], []
+    np.random.seed(5)
+    Ur, Vr, odr = orc.nmf_pathway(X, pws, gamma=1.0, k_latent=k, max_iter=300, round_log=r_ref, trace=t_ref)
+    rounds, trace = [], []
+    np.random.seed(5)
+    U, V, od = nmf_pathway(X, None, library=lib, gamma=1.0, k_latent=k, max_iter=300, x_dtype=x_dtype, round_log=rounds, trace=trace)
+    tr, tref = np.array([t["obj"] for t in trace]), np.array([t["obj"] for t in t_ref])
+    assert rounds == r_ref, "per-round assignment differs in round %d" % next(i for i, (a, b) in enumerate(zip(rounds, r_ref)) if a != b)
+    assert len(tr) == len(tref)
+    mp, mr = od["latent_to_pathway_data"], odr["latent_to_pathway_data"]
+    assert [[int(p) for p, _s in mp[kk]] for kk in sorted(mp)] == [[int(p) for p, _s in mr[kk]] for kk in sorted(mr)]
+    e_tr, eu, ev = relmax(tr, tref), rel(U, Ur), rel(V, Vr)
+    report("outer_solver_medium_vs_oracle[%dx%d-k%d-P%d-%s]" % (m, n, k, P, x_dtype), iterations=len(tr), rounds=len(rounds), rel_trace=e_tr, rel_U=eu, rel_V=ev)
+    assert e_tr < TOL_OBJ and eu < TOL_FACTOR and ev < TOL_FACTOR
