@@ -1,0 +1,41 @@
+"""bench.py's ONE JSON line: the keys and relations the driver and the judge read (task contract: metric / value / unit /
+n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, plus the
+`roofline` and `cpu_baseline` objects) -- on the small BASELINE configs[1] workload with a short CPU-baseline budget, so
+that the check itself takes seconds.  The default invocation (C3, the headline) differs only in the workload."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2", "--steps", "6", "--warmup", "2", "--reps", "3",
+                        "--cpu-seconds", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "exactly one line on stdout: %r" % lines[:3]
+    d = json.loads(lines[0])
+    assert d["metric"] == "nmf_update_iterations_per_sec" and d["unit"] == "iterations/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["scaling"] in ("weak", "strong")
+    assert "5000x10000" in d["config"]["workload"] and d["config"]["k_latent"] == 16 and d["config"]["launches_per_iteration"] == 4
+    assert abs(d["value"] * d["ms_per_step"] / 1000.0 - 1.0) < 1e-6                      # value = iterations / second of the timed block
+    assert d["recon_err"] > 0 and d["objective"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.2 < rf["frac"] < 1.0
+    # achieved = algorithmic bytes per launch / average launch duration measured in this run (HIP events on the launch stream)
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    assert rf["algorithmic_bytes_per_launch"] == 5000 * 10000 * 4 + 4 * 10000 * 16 + 4 * 5000 * 16      # X once + factor once + product once
+    assert rf["traffic"] is None or rf["traffic"] > 0.9 * rf["algorithmic_bytes_per_launch"]
+    assert 0 < rf["frac_of_stream"] <= 1.05 and rf["stream_gbs"] > 1000
+    assert 2 * rf["avg_launch_ms"] < d["ms_per_step"] * 1.02                                 # the two sweeps fit inside the step
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "iterations/s" and cb["value"] > 0 and cb["cores"] >= 1 and "oracle/prmf_oracle.py" in cb["sample"]
+    assert cb["method"]["rebuild_laplacians"] is True and cb["lean_value"] >= cb["value"] * 0.5
+    assert d["update_only"]["value"] > 0 and d["outer_loop"]["iterations"] == 100
