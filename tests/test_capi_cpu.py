@@ -59,6 +59,18 @@ def test_error_paths_without_compute():
     assert lib.prmf_step(None, None, None, 1, 1.0, 1.0, -1.0, None, None, None) == _capi.PRMF_ERR_ARG
 
 
+def test_headers_are_plain_c_and_cxx(tmp_path):
+    """the boundary is a C ABI: both headers compile as strict C99 and as C++11, with nothing but <stddef.h> / <stdint.h> behind them"""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "prmf_hip.h"\n#include "prmf_hip_debug.h"\nint use(void) { return prmf_abi_version() + (int)sizeof(prmf_comm_sizes) + PRMF_OBJ_STRIDE; }\n')
+    inc = os.path.join(ROOT, "include")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)],
+                ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
 def test_debug_stamp_buffer_length_is_checked():
     """the sweep's debug stamps go to fixed, disjoint regions of the caller's buffer: a buffer shorter than the layout is refused"""
     from prmf_amd import _capi
