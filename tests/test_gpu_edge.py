@@ -121,3 +121,38 @@ def test_long_call_is_batched_like_short_calls():
         finally:
             eng2.end(1)
             eng2.close()
+
+
+@pytest.mark.parametrize("x_dtype", ["f32", "bf16"])
+def test_all_zero_matrix_matches_oracle(x_dtype):
+    """X = 0 with the caller's finite gamma / delta (the CLI would stop earlier: delta = 10 / ||X||, prmf_runner.py:645): P = X V = 0
+    drives U to exact zeros in one step (zeros are absorbing, :422), V follows the pathway terms alone -- finite, equal to
+    the oracle, recon exactly 0 (flagged as clamped or direct, never a NaN from sqrt of a negative identity value)."""
+    case = synth.small_case(seed=3, m=45, n=200, k=5, P=3, order=20, bf16_x=(x_dtype == "bf16"))
+    case["X"] = np.zeros_like(case["X"])
+    case["gamma"], case["delta"] = 0.7, 0.3
+    check(case, x_dtype, steps=4)
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_non_finite_input_is_an_error_not_a_silent_nan(bad):
+    """A NaN or an infinity in X: the reference would carry NaNs through every array without a word (np.seterr only raises
+    on divide); the library must never hand back non-finite factors silently (risk 4): PRMF_ERR_NUMERIC ->
+    FloatingPointError on the Python side."""
+    import torch
+    from prmf_amd import PathwayLibrary
+    from prmf_amd.solver import PrmfEngine
+    case = synth.small_case(seed=4, m=50, n=300, k=6, P=3, order=20)
+    X = case["X"].copy()
+    X[7, 11] = bad
+    eng = PrmfEngine(50, 300, 6, x_dtype="f32")
+    try:
+        eng.set_x(X, norm_x_sq=float(np.sum(case["X"] ** 2)))
+        eng.set_library(PathwayLibrary.from_edge_lists(300, case["pathways"]))
+        eng.set_active(np.arange(6) % 3)
+        U = eng.device_tensor(case["U0"], torch.float32)
+        V = eng.device_tensor(case["V0"], torch.float32)
+        with pytest.raises(FloatingPointError):
+            eng.step(U, V, 3, case["gamma"], case["delta"])
+    finally:
+        eng.close()
