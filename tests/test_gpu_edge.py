@@ -156,3 +156,14 @@ def test_non_finite_input_is_an_error_not_a_silent_nan(bad):
             eng.step(U, V, 3, case["gamma"], case["delta"])
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("gamma,delta", [(0.0, 0.0), (0.0, 0.5), (2.5, 0.0), (1e5, 1e-6), (1e-8, 1e4)])
+@pytest.mark.parametrize("x_dtype,k", [("f32", 6), ("bf16", 70)])
+def test_extreme_hyper_parameters(gamma, delta, x_dtype, k):
+    """gamma = 0 and / or delta = 0 (plain NMF: the pathway terms vanish from the update, not from the record), a gamma
+    that lets the Laplacian term dominate the V update, a delta that lets the ignore term dominate: the association
+    num = Q + (gamma W v + delta (v + 1)^-2) and the two clamps of prmf_runner.py:440-444 at both ends of the scale."""
+    case = synth.small_case(seed=8, m=90, n=260, k=k, P=4, order=30, bf16_x=(x_dtype == "bf16"))
+    case["gamma"], case["delta"] = gamma, delta
+    check(case, x_dtype, steps=4)
