@@ -167,3 +167,31 @@ def test_extreme_hyper_parameters(gamma, delta, x_dtype, k):
     case = synth.small_case(seed=8, m=90, n=260, k=k, P=4, order=30, bf16_x=(x_dtype == "bf16"))
     case["gamma"], case["delta"] = gamma, delta
     check(case, x_dtype, steps=4)
+
+
+@pytest.mark.parametrize("n,order,k,x_dtype", [(4000, 3000, 8, "f32"),       # support beyond the 1024 floats of LDS the k <= 32 epilogue can stage
+                                               (4000, 3000, 64, "bf16"),     # the same pathway within the 4096 floats of the k = 64 one
+                                               (7000, 6000, 64, "f32"),      # beyond them
+                                               (7000, 6900, 128, "bf16")])   # nearly every gene on one pathway, k = 128
+def test_pathways_larger_than_the_lds_staging(n, order, k, x_dtype):
+    """Pathways of thousands of genes (the reference's KEGG-sized graphs have ~300): the pathway terms stage a support's V
+    values in LDS when they fit and walk global memory when they do not (update.hip: graph_terms_body<true / false>); the
+    deferred objective and the candidate scorer have the same two paths."""
+    import torch
+    from oracle import prmf_oracle as orc
+    from prmf_amd import PathwayLibrary
+    from prmf_amd.solver import PrmfEngine
+    case = synth.small_case(seed=6, m=70, n=n, k=k, P=2, order=order, zero_genes=3, isolated=2, bf16_x=(x_dtype == "bf16"))
+    check(case, x_dtype, steps=3)
+    # the candidate scorer on the same library (restrict, prmf_runner.py:115-127)
+    eng = PrmfEngine(70, n, k, x_dtype=x_dtype)
+    try:
+        eng.set_x(case["X"])
+        eng.set_library(PathwayLibrary.from_edge_lists(n, case["pathways"]))
+        V = eng.device_tensor(case["V0"], torch.float32)
+        S = eng.score_candidates(V)
+    finally:
+        eng.close()
+    pws = [orc.pathway_from_edges(n, e, nodes, w) for (e, w, nodes) in case["pathways"]]
+    want = orc.score_matrix(case["V0"].astype(np.float32).astype(np.float64), pws)
+    assert np.max(np.abs(S - want) / np.maximum(np.abs(want), 1e-12)) < 1e-5
