@@ -195,3 +195,32 @@ def test_pathways_larger_than_the_lds_staging(n, order, k, x_dtype):
     pws = [orc.pathway_from_edges(n, e, nodes, w) for (e, w, nodes) in case["pathways"]]
     want = orc.score_matrix(case["V0"].astype(np.float32).astype(np.float64), pws)
     assert np.max(np.abs(S - want) / np.maximum(np.abs(want), 1e-12)) < 1e-5
+
+
+def test_self_loops_duplicate_edges_and_components():
+    """Graph oddities the library format has to carry: self-loops (on the diagonal of W once, so L_ii = deg - W_ii differs
+    from deg: normalize_laplacian reads L_ii, prmf_runner.py:60), duplicate edges (summed), two components, a hub, isolated
+    support nodes -- inner loop, objective and candidate scores against the oracle."""
+    import torch
+    from oracle import prmf_oracle as orc
+    from prmf_amd import PathwayLibrary
+    from prmf_amd.solver import PrmfEngine
+    case = synth.small_case(seed=12, m=40, n=120, k=4, P=1, order=10, zero_genes=2, isolated=0)
+    nodes0 = np.arange(5, 25)
+    e0 = [(5, 6), (6, 7), (7, 7), (5, 6), (8, 9), (9, 10), (10, 8), (12, 12), (5, 13), (5, 14), (5, 15), (5, 16), (20, 21)]      # 11, 17-19, 22-24: isolated
+    w0 = [1.0, 0.5, 2.0, 0.25, 1.0, 1.0, 3.0, 0.75, 1, 1, 1, 1, 0.125]
+    nodes1 = np.array([100, 3, 50, 51, 52])
+    e1 = [(100, 3), (3, 50), (50, 50), (51, 52)]
+    case["pathways"] = [(np.array(e0), np.array(w0), nodes0), (np.array(e1), np.ones(len(e1)), nodes1)]
+    check(case, "f32", steps=5)
+    check(dict(case, X=synth.round_to_bf16(case["X"])), "bf16", steps=3)      # (the oracle gets the X the GPU stores)
+    eng = PrmfEngine(40, 120, 4, x_dtype="f32")
+    try:
+        eng.set_x(case["X"])
+        eng.set_library(PathwayLibrary.from_edge_lists(120, case["pathways"]))
+        S = eng.score_candidates(eng.device_tensor(case["V0"], torch.float32))
+    finally:
+        eng.close()
+    pws = [orc.pathway_from_edges(120, e, nodes, w) for (e, w, nodes) in case["pathways"]]
+    want = orc.score_matrix(case["V0"].astype(np.float32).astype(np.float64), pws)
+    assert np.max(np.abs(S - want) / np.maximum(np.abs(want), 1e-12)) < 1e-5
