@@ -324,6 +324,12 @@ def gen_more_cli(ref):
         os.makedirs(wdir)
         wfps = synth.weighted_copies(c["manifolds"], wdir)
         runs["g12_weighted"] = ["--manifolds"] + wfps
+        # G13: the flags the reference parses but treats specially: --gamma reaches the solver, --delta and
+        # --tolerence do not (main passes neither to nmf_pathway, prmf_runner.py:1067), --m-samples sets n_rows and then reads
+        # with nrows=None (:933-942): the run is the --gamma 2 run of all samples with delta = 1 and tol = 1e-3
+        runs["g13_quirk_flags"] = ["--manifolds"] + c["manifolds"] + ["--gamma", "2.0", "--delta", "7.0", "--tolerence", "0.5", "--m-samples", "10"]
+        if ONLY:
+            runs = {k: v for k, v in runs.items() if k in ONLY}
         for tag, margs in runs.items():
             out = os.path.join(d, "out_" + tag)
             os.makedirs(out)
@@ -343,11 +349,17 @@ def gen_more_cli(ref):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]      # e.g. `python oracle/gen_golden.py g13_quirk_flags`: only that CLI fixture
+
+
 def main():
     if not ref_harness.reference_available():
         sys.exit("reference not mounted; golden vectors can only be generated in the build container")
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_harness.load_reference_runner()
+    if ONLY:
+        gen_more_cli(ref)
+        return
     gen_inner(ref)
     gen_restrict(ref)
     gen_solver_api(ref)

@@ -228,10 +228,11 @@ def test_cli_outputs_vs_reference(golden_dir, tmp_path, variant, tag, norm):
         assert np.allclose(V.to_numpy()[1000:], np.finfo(np.float32).eps)
 
 
-@pytest.mark.parametrize("tag", ["g10_init", "g11_fewer_pathways", "g12_weighted"])
+@pytest.mark.parametrize("tag", ["g10_init", "g11_fewer_pathways", "g12_weighted", "g13_quirk_flags"])
 def test_cli_more_variants_vs_reference(golden_dir, tmp_path, tag):
     """--manifolds-init (NNLS-based U/V start, init_pathways.txt), fewer pathways than latent factors,
-    weighted graphml edges: obj.txt, the latent->pathway mapping, U.csv and V.csv against reference runs."""
+    weighted graphml edges, the flags the reference parses but does not forward (--delta, --tolerence, --m-samples next
+    to a --gamma it does): obj.txt, the latent->pathway mapping, U.csv and V.csv against reference runs."""
     import pandas as pd
     g = np.load(os.path.join(golden_dir, tag + ".npz"))
     c = synth.cli_case(str(tmp_path), variant=1)
@@ -241,6 +242,10 @@ def test_cli_more_variants_vs_reference(golden_dir, tmp_path, tag):
         extra = ["--manifolds-init"] + [man[i] for i in (0, 1, 3, 2, 5, 4)]
     elif tag == "g11_fewer_pathways":
         man = man[:3]
+    elif tag == "g13_quirk_flags":
+        # parsed by the reference, but only --gamma reaches its solver: --delta and --tolerence are not passed on, --m-samples
+        # sets n_rows and then reads every row -- the drop-in CLI has to ignore them in the same way
+        extra = ["--gamma", "2.0", "--delta", "7.0", "--tolerence", "0.5", "--m-samples", "10"]
     else:
         wdir = str(tmp_path / "weighted")
         os.makedirs(wdir)
