@@ -452,3 +452,26 @@ def test_outer_solver_at_medium_size_vs_oracle(m, n, k, P, x_dtype):
     e_tr, eu, ev = relmax(tr, tref), rel(U, Ur), rel(V, Vr)
     report("outer_solver_medium_vs_oracle[%dx%d-k%d-P%d-%s]" % (m, n, k, P, x_dtype), iterations=len(tr), rounds=len(rounds), rel_trace=e_tr, rel_U=eu, rel_V=ev)
     assert e_tr < TOL_OBJ and eu < TOL_FACTOR and ev < TOL_FACTOR
+
+
+def test_cli_genes_by_samples_input_fails_where_the_reference_fails(golden_dir, tmp_path):
+    """--data stored genes x samples (1000 x 100): --high-dimensional (default True) turns the matrix so that the shorter
+    side is the samples (prmf_runner.py:945-952) and the solve runs -- its trace is the g6 run's -- but the sample labels
+    were taken BEFORE the turn (:943), so writing U.csv raises pandas' shape error.  The reference does exactly that
+    (tried with oracle/ref_harness.py while looking for a fixture: ValueError "Shape of passed values is (100, 6), indices
+    imply (1000, 6)"); a drop-in keeps the error behaviour, it does not guess a repair."""
+    import pandas as pd
+    g = np.load(os.path.join(golden_dir, "g6_nonorm.npz"))
+    c = synth.cli_case(str(tmp_path), variant=1)
+    data_t = str(tmp_path / "data_T.tsv")
+    pd.DataFrame(c["X"].T).to_csv(data_t, sep="\t", header=False, index=False)
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "script", "prmf_runner.py"), "--data", data_t, "--manifolds"] + c["manifolds"] +
+                       ["--node-attribute", "name", "--nodelist", c["nodelist"], "--outdir", out, "--delimiter", "\t", "--seed", "1", "--no-normalize"],
+                       cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode != 0
+    assert "Shape of passed values is (100, 6), indices imply (1000, 6)" in r.stderr
+    trace = _trace_of(r.stdout)
+    assert len(trace) == len(g["trace"]) and relmax(trace, g["trace"]) < TOL_OBJ      # the solve itself ran on the turned matrix
+    assert not os.path.exists(os.path.join(out, "U.csv"))
