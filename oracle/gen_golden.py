@@ -328,13 +328,17 @@ def gen_more_cli(ref):
         # --tolerence do not (main passes neither to nmf_pathway, prmf_runner.py:1067), --m-samples sets n_rows and then reads
         # with nrows=None (:933-942): the run is the --gamma 2 run of all samples with delta = 1 and tol = 1e-3
         runs["g13_quirk_flags"] = ["--manifolds"] + c["manifolds"] + ["--gamma", "2.0", "--delta", "7.0", "--tolerence", "0.5", "--m-samples", "10"]
+        # G15 / G16: other seeds -- other initial factors, other pathway draws per round, other `restrict` / matching decisions
+        runs["g15_seed7"] = ["--manifolds"] + c["manifolds"]
+        runs["g16_seed2024_k4"] = ["--manifolds"] + c["manifolds"] + ["-k", "4"]      # fewer latent factors than pathways
+        seeds = {"g15_seed7": "7", "g16_seed2024_k4": "2024"}
         if ONLY:
             runs = {k: v for k, v in runs.items() if k in ONLY}
         for tag, margs in runs.items():
             out = os.path.join(d, "out_" + tag)
             os.makedirs(out)
             argv = ["--data", c["data"]] + margs + ["--node-attribute", "name", "--nodelist", c["nodelist"],
-                                                    "--outdir", out, "--delimiter", "\t", "--seed", "1", "--no-normalize"]
+                                                    "--outdir", out, "--delimiter", "\t", "--seed", seeds.get(tag, "1"), "--no-normalize"]
             stdout = run_ref_cli(ref, argv, d)
             vals, mapping = read_obj_txt(os.path.join(out, "obj.txt"))
             U = pd.read_csv(os.path.join(out, "U.csv")).to_numpy()

@@ -228,7 +228,7 @@ def test_cli_outputs_vs_reference(golden_dir, tmp_path, variant, tag, norm):
         assert np.allclose(V.to_numpy()[1000:], np.finfo(np.float32).eps)
 
 
-@pytest.mark.parametrize("tag", ["g10_init", "g11_fewer_pathways", "g12_weighted", "g13_quirk_flags"])
+@pytest.mark.parametrize("tag", ["g10_init", "g11_fewer_pathways", "g12_weighted", "g13_quirk_flags", "g15_seed7", "g16_seed2024_k4"])
 def test_cli_more_variants_vs_reference(golden_dir, tmp_path, tag):
     """--manifolds-init (NNLS-based U/V start, init_pathways.txt), fewer pathways than latent factors,
     weighted graphml edges, the flags the reference parses but does not forward (--delta, --tolerence, --m-samples next
@@ -246,6 +246,10 @@ def test_cli_more_variants_vs_reference(golden_dir, tmp_path, tag):
         # parsed by the reference, but only --gamma reaches its solver: --delta and --tolerence are not passed on, --m-samples
         # sets n_rows and then reads every row -- the drop-in CLI has to ignore them in the same way
         extra = ["--gamma", "2.0", "--delta", "7.0", "--tolerence", "0.5", "--m-samples", "10"]
+    elif tag == "g15_seed7":
+        pass                                    # another seed: other initial factors, pathway draws, restrict / matching decisions
+    elif tag == "g16_seed2024_k4":
+        extra = ["-k", "4"]                     # fewer latent factors than pathways
     else:
         wdir = str(tmp_path / "weighted")
         os.makedirs(wdir)
@@ -254,7 +258,7 @@ def test_cli_more_variants_vs_reference(golden_dir, tmp_path, tag):
     os.makedirs(out)
     stdout = _cli(["--data", c["data"], "--manifolds"] + man + extra +
                   ["--node-attribute", "name", "--nodelist", c["nodelist"], "--outdir", out, "--delimiter", "\t",
-                   "--seed", "1", "--no-normalize"], str(tmp_path))
+                   "--seed", {"g15_seed7": "7", "g16_seed2024_k4": "2024"}.get(tag, "1"), "--no-normalize"], str(tmp_path))
     trace = _trace_of(stdout)
     ref_trace = g["trace"]
     vals, mapping = _read_obj(os.path.join(out, "obj.txt"))

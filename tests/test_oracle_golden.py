@@ -138,7 +138,7 @@ def test_outer_solver_trace_matches_reference(golden_dir, tmp_path, name, tradeo
     assert rel(U, g["U"]) < 1e-9 and rel(V, g["V"]) < 1e-9
 
 
-@pytest.mark.parametrize("tag", ["g11_fewer_pathways", "g12_weighted", "g13_quirk_flags"])
+@pytest.mark.parametrize("tag", ["g11_fewer_pathways", "g12_weighted", "g13_quirk_flags", "g15_seed7", "g16_seed2024_k4"])
 def test_outer_solver_cli_variants(golden_dir, tmp_path, tag):
     """Reference CLI runs (--seed 1 --no-normalize) with fewer pathways than latent factors (3 graphs,
     k = 6: prmf_runner.py:196-258 leaves the spare latents on a repeated pathway) and with weighted
@@ -156,11 +156,11 @@ def test_outer_solver_cli_variants(golden_dir, tmp_path, tag):
     if tag == "g12_weighted":
         assert any(np.any(np.abs(p.W.data - 1.0) > 1e-6) for p in pws)
     trace = []
-    np.random.seed(1)
+    np.random.seed({"g15_seed7": 7, "g16_seed2024_k4": 2024}.get(tag, 1))
     norm_x = np.linalg.norm(c["X"])
     # g13: the reference CLI run with --gamma 2 --delta 7 --tolerence 0.5 --m-samples 10: only --gamma reaches the solver
     # (SURVEY Appendix B-3), so the oracle called with gamma = 2 and everything else at its default reproduces it
-    U, V, od = orc.nmf_pathway(c["X"], pws, gamma=2.0 if tag == "g13_quirk_flags" else 1.0, k_latent=6, trace=trace)
+    U, V, od = orc.nmf_pathway(c["X"], pws, gamma=2.0 if tag == "g13_quirk_flags" else 1.0, k_latent=4 if tag == "g16_seed2024_k4" else 6, trace=trace)
     assert np.allclose([t["obj"] for t in trace], g["trace"], rtol=1e-9)
     l2p = od["latent_to_pathway_data"]
     names = [os.path.basename(c["manifolds"][int(l2p[k][0][0])]) for k in sorted(l2p)]
