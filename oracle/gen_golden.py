@@ -109,6 +109,23 @@ def save(name, **arrs):
     print("wrote", name, {k: getattr(v, "shape", None) for k, v in arrs.items()})
 
 
+WIDE_INNER = {      # G17 / G18 (round 5): the reference's inner loop at LARGER k -- the shapes that take the other GPU code paths (k = 100: three
+    # ... four 32-column tiles, 16x16x32 MFMA, column-split epilogues; k = 48 with f32 X: the three-piece split on 16x16x32)
+    "g17_k100_bf16": dict(seed=3, m=80, n=900, k=100, P=100, order=30, bf16_x=True),
+    "g18_k48": dict(seed=4, m=120, n=1200, k=48, P=48, order=40),
+}
+
+
+def gen_inner_wide(ref, only=None):
+    for name, kw in WIDE_INNER.items():
+        if only and name not in only:
+            continue
+        case = synth.small_case(**kw)
+        objs, sU, sV, _ = run_inner(ref, case, 6, [6])
+        save(name + ".npz", x_sha=np.array(synth.sha16(case["X"])), snap_steps=np.array([6]), obj=objs, U=sU, V=sV,
+             case_kwargs=np.array(json.dumps(kw)))
+
+
 def gen_inner(ref):
     snap = [1, 5, 10, 25]
     for name, kw in [("g2_inner25", {}), ("g3_zero_row", {"zero_row": True}),
@@ -362,9 +379,13 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_harness.load_reference_runner()
     if ONLY:
-        gen_more_cli(ref)
+        if any(t in WIDE_INNER for t in ONLY):
+            gen_inner_wide(ref, ONLY)
+        if any(t not in WIDE_INNER for t in ONLY):
+            gen_more_cli(ref)
         return
     gen_inner(ref)
+    gen_inner_wide(ref)
     gen_restrict(ref)
     gen_solver_api(ref)
     gen_cli(ref)

@@ -45,6 +45,11 @@ def make_engine(case, x_dtype):
     ("g3_zero_row.npz", {"zero_row": True}, "f32"),
     ("g9_bf16x.npz", {"bf16_x": True}, "bf16"),
     ("g9_bf16x.npz", {"bf16_x": True}, "f32"),
+    # round 5: reference runs at larger k -- bf16 X at k = 100 (four column tiles, 16x16x32 MFMA, column-split epilogues; also with
+    # f32 storage of the same rounded X: the three-piece split at k > 64) and f32 X at k = 48 (16x16x32, W16 packing in the fused epilogues)
+    ("g17_k100_bf16.npz", dict(seed=3, m=80, n=900, k=100, P=100, order=30, bf16_x=True), "bf16"),
+    ("g17_k100_bf16.npz", dict(seed=3, m=80, n=900, k=100, P=100, order=30, bf16_x=True), "f32"),
+    ("g18_k48.npz", dict(seed=4, m=120, n=1200, k=48, P=48, order=40), "f32"),
 ])
 def test_inner_loop_vs_reference_golden(torch_mod, golden_dir, name, kw, x_dtype):
     torch = torch_mod

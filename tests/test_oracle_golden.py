@@ -30,6 +30,9 @@ def rel(a, b):
     ("g2_inner25.npz", {}),
     ("g3_zero_row.npz", {"zero_row": True}),
     ("g9_bf16x.npz", {"bf16_x": True}),
+    # round 5, larger k (the shapes whose GPU code paths differ: 16x16x32 MFMA, column-split epilogues, three-piece split of f32 X)
+    ("g17_k100_bf16.npz", dict(seed=3, m=80, n=900, k=100, P=100, order=30, bf16_x=True)),
+    ("g18_k48.npz", dict(seed=4, m=120, n=1200, k=48, P=48, order=40)),
 ])
 def test_inner_loop_matches_reference(golden_dir, name, kw):
     g = load(golden_dir, name)
