@@ -146,10 +146,15 @@ def gen_inner(ref):
          obj=objs, U=sU, V=sV, final_gamma_delta=np.array(gd), tradeoff=np.array(0.7))
 
 
-def gen_restrict(ref):
-    """G5: scores for every (latent, pathway) pair and the kept sets of one
-    `restrict` call, on V after 10 inner steps of the small case with P=12."""
-    case = synth.small_case(seed=3, P=12)
+RESTRICT_CASES = {"g5_restrict": dict(seed=3, P=12),
+                  # G19 (round 5): the same at k = 40 latent columns x 60 candidate pathways of 50 genes on 1500 genes
+                  "g19_restrict_k40": dict(seed=5, m=60, n=1500, k=40, P=60, order=50)}
+
+
+def gen_restrict(ref, name="g5_restrict"):
+    """G5 / G19: scores for every (latent, pathway) pair and the kept sets of one
+    `restrict` call, on V after 10 inner steps of the small case (G5: P = 12)."""
+    case = synth.small_case(**RESTRICT_CASES[name])
     X, n, k = case["X"], case["X"].shape[1], case["k"]
     objs, sU, sV, _ = run_inner(ref, case, 10, [10])
     V = sV[0]
@@ -169,7 +174,7 @@ def gen_restrict(ref):
         for p, _s in lst:
             kept_mask[kk, p] = 1
     ref_harness.reset_reference_globals(ref)
-    save("g5_restrict.npz", x_sha=np.array(synth.sha16(X)), V=V, scores=scores, kept=kept_mask)
+    save(name + ".npz", x_sha=np.array(synth.sha16(X)), V=V, scores=scores, kept=kept_mask)
 
 
 def parse_trace(text):
@@ -381,11 +386,15 @@ def main():
     if ONLY:
         if any(t in WIDE_INNER for t in ONLY):
             gen_inner_wide(ref, ONLY)
-        if any(t not in WIDE_INNER for t in ONLY):
+        for t in ONLY:
+            if t in RESTRICT_CASES:
+                gen_restrict(ref, t)
+        if any(t not in WIDE_INNER and t not in RESTRICT_CASES for t in ONLY):
             gen_more_cli(ref)
         return
     gen_inner(ref)
     gen_inner_wide(ref)
+    gen_restrict(ref, "g19_restrict_k40")
     gen_restrict(ref)
     gen_solver_api(ref)
     gen_cli(ref)

@@ -86,10 +86,12 @@ def test_drop_in_inner_loop_function(golden_dir, capsys):
     assert [l.split()[0] for l in lines] == ["11", "12", "13", "14", "15"]     # "<iter> <obj>" trace
 
 
-def test_score_candidates_vs_reference(golden_dir):
+@pytest.mark.parametrize("name,kw", [("g5_restrict.npz", dict(seed=3, P=12)),
+                                     ("g19_restrict_k40.npz", dict(seed=5, m=60, n=1500, k=40, P=60, order=50))])      # round 5: 40 x 60 pairs
+def test_score_candidates_vs_reference(golden_dir, name, kw):
     import torch
-    g = np.load(os.path.join(golden_dir, "g5_restrict.npz"))
-    case = synth.small_case(seed=3, P=12)
+    g = np.load(os.path.join(golden_dir, name))
+    case = synth.small_case(**kw)
     eng = engine_for(case)
     V = eng.device_tensor(g["V"], torch.float32)
     S = eng.score_candidates(V)

@@ -65,8 +65,9 @@ def test_library_from_graphs_and_from_sparse(tmp_path):
         PathwayLibrary.from_sparse([bad.tocsr()], [pws[0].support])
 
 
-def test_restrict_matches_reference_kept_sets(golden_dir):
-    g = np.load(os.path.join(golden_dir, "g5_restrict.npz"))
+@pytest.mark.parametrize("name", ["g5_restrict.npz", "g19_restrict_k40.npz"])
+def test_restrict_matches_reference_kept_sets(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name))
     k, P = g["scores"].shape
     l2p = {kk: [(p, 1) for p in range(P)] for kk in range(k)}
     kept = solver.restrict(g["scores"], l2p)

@@ -98,9 +98,11 @@ def test_tradeoff_matches_reference(golden_dir):
     assert np.allclose([gam, dlt], g["final_gamma_delta"], rtol=1e-10)
 
 
-def test_restrict_scores_and_kept_sets(golden_dir):
-    g = load(golden_dir, "g5_restrict.npz")
-    case = synth.small_case(seed=3, P=12)
+@pytest.mark.parametrize("name,kw", [("g5_restrict.npz", dict(seed=3, P=12)),
+                                     ("g19_restrict_k40.npz", dict(seed=5, m=60, n=1500, k=40, P=60, order=50))])
+def test_restrict_scores_and_kept_sets(golden_dir, name, kw):
+    g = load(golden_dir, name)
+    case = synth.small_case(**kw)
     pws = oracle_pathways(case)
     V = g["V"]
     S = orc.score_matrix(V, pws)
