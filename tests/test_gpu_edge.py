@@ -224,3 +224,38 @@ def test_self_loops_duplicate_edges_and_components():
     pws = [orc.pathway_from_edges(120, e, nodes, w) for (e, w, nodes) in case["pathways"]]
     want = orc.score_matrix(case["V0"].astype(np.float32).astype(np.float64), pws)
     assert np.max(np.abs(S - want) / np.maximum(np.abs(want), 1e-12)) < 1e-5
+
+
+def test_contexts_release_their_device_memory():
+    """Thirty contexts in a row (create, X, library, a few iterations in three forms, scores, destroy), then several alive at
+    once: the free device memory comes back every time -- a CLI run is one context, a cross-validation or a server process many."""
+    import torch
+    from prmf_amd import PathwayLibrary
+    from prmf_amd.solver import PrmfEngine
+    case = synth.small_case(seed=2, m=300, n=2000, k=33, P=4, order=60)
+    lib = PathwayLibrary.from_edge_lists(2000, case["pathways"])
+
+    def one(flags):
+        eng = PrmfEngine(300, 2000, 33, x_dtype="f32", **flags)
+        eng.set_x(case["X"])
+        eng.set_library(lib)
+        eng.set_active(np.arange(33) % 4)
+        U = eng.device_tensor(case["U0"], torch.float32)
+        V = eng.device_tensor(case["V0"], torch.float32)
+        eng.step(U, V, 2, case["gamma"], case["delta"])
+        eng.score_candidates(V)
+        return eng
+
+    one({}).close()                                        # first use: module load, runtime pools
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    for i in range(30):
+        one([{}, {"eager_objective": True}, {"direct_residual": True}, {"timing": True}][i % 4]).close()
+    alive = [one({}) for _ in range(5)]
+    for e in alive:
+        e.close()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, "device memory not returned: %.1f MB" % ((free0 - free1) / 2**20)
