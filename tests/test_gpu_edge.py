@@ -259,3 +259,54 @@ def test_contexts_release_their_device_memory():
     torch.cuda.empty_cache()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, "device memory not returned: %.1f MB" % ((free0 - free1) / 2**20)
+
+
+def test_independent_contexts_on_concurrent_threads():
+    """Four unrelated problems (different shapes, storages, k) solved at the same time by four host threads, each with a
+    context and a stream of its own: no state is shared between contexts (include/prmf_hip.h), so every thread gets,
+    bit for bit, what the same problem gives when it runs alone."""
+    import threading
+    import torch
+    from prmf_amd import PathwayLibrary
+    from prmf_amd.solver import PrmfEngine
+    specs = [dict(seed=21, m=400, n=1500, k=16, P=4, order=50, x="f32"), dict(seed=22, m=90, n=5000, k=64, P=6, order=80, x="bf16"),
+             dict(seed=23, m=700, n=600, k=100, P=3, order=40, x="bf16"), dict(seed=24, m=33, n=257, k=6, P=2, order=12, x="f32")]
+    cases = [synth.small_case(seed=s["seed"], m=s["m"], n=s["n"], k=s["k"], P=s["P"], order=s["order"], bf16_x=(s["x"] == "bf16")) for s in specs]
+
+    def solve(i, out, stream=None):
+        s, case = specs[i], cases[i]
+        ctx = torch.cuda.stream(stream) if stream is not None else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            eng = PrmfEngine(s["m"], s["n"], s["k"], x_dtype=s["x"])
+            eng.set_x(case["X"])
+            eng.set_library(PathwayLibrary.from_edge_lists(s["n"], case["pathways"]))
+            eng.set_active(np.arange(s["k"]) % s["P"])
+            U = eng.device_tensor(case["U0"], torch.float32)
+            V = eng.device_tensor(case["V0"], torch.float32)
+            objs = []
+            for _ in range(6):                      # several calls, so that the threads interleave
+                o, _gd = eng.step(U, V, 3, case["gamma"], case["delta"])
+                objs += o
+            torch.cuda.current_stream().synchronize()
+            out[i] = (U.cpu().numpy(), V.cpu().numpy(), objs)
+            eng.close()
+        except BaseException as e:      # noqa: B902
+            out[i] = e
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+
+    alone, together = {}, {}
+    for i in range(4):
+        solve(i, alone)
+    threads = [threading.Thread(target=solve, args=(i, together, torch.cuda.Stream())) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    for i in range(4):
+        assert not isinstance(alone[i], BaseException), alone[i]
+        assert not isinstance(together.get(i), BaseException) and together.get(i) is not None, together.get(i)
+        assert np.array_equal(alone[i][0], together[i][0]) and np.array_equal(alone[i][1], together[i][1]) and alone[i][2] == together[i][2], i
