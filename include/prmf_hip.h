@@ -292,6 +292,40 @@ int prmf_quantile_transform(int device, double* dX, int64_t m, int64_t n, int64_
                             int64_t n_fit, int n_quantiles, void* stream);
 
 /*
+ * The numeric body of a delimited text matrix, parsed on the GPU: replaces the parse inside
+ * `pd.read_csv(args.data, sep=args.delimiter, header=..., index_col=...)` (script/prmf_runner.py:942) -- at the
+ * reference's typical size (500 x 20000, 187 MB of text) 1.7 s of a 2.0 s run.  pandas is a dependency of the reference
+ * (any pandas >= 1.2: float_precision "high", converter `precise_xstrtod`); every value produced here equals pandas' bit
+ * for bit because it is computed by the same float64 operations in the same order (prmf_amd/csrc/xstrtod.h).  What is
+ * parsed: the lines AFTER the header (the caller reads header and row names itself), every line `fields_per_line` fields
+ * separated by `delimiter`, ended by "\n" or "\r\n" (a missing final newline is supplied), every data field
+ *     [ \t]* [+-]? digits* ( . digits* )? ( [eE] [+-]? digits{1,4} )? [ \t]*      with at least one mantissa digit.
+ * Everything else is not interpreted but REPORTED in *flags_out, and the caller gives the file to pandas:
+ *     PRMF_TEXT_RAGGED       a line with another number of fields (blank lines, quoted separators, lone "\r" line ends)
+ *     PRMF_TEXT_QUOTED       a quote in a data field
+ *     PRMF_TEXT_NOT_NUMERIC  an empty field, NA / nan / inf, hex, an exponent beyond 4 digits, an overflowing value
+ *     PRMF_TEXT_WIDE_INT     an integer spelled with more than 15 digits (exact in pandas' int64, not in a double), or an
+ *                            integer part of 19 or more digits (pandas' int64 / uint64 probes overflow on it and the column's
+ *                            type then depends on what stood above that field)
+ * Calls: prmf_text_create(&t, device, nbytes) reserves device memory for the body; prmf_text_append copies the next piece
+ * of it from host memory (any piece size: a 64 MB read buffer keeps the host footprint flat); prmf_text_index finds the
+ * fields and checks the line structure (*rows_out lines); prmf_text_parse converts: out = rows x (fields_per_line -
+ * skip_first_field) float64, row-major, HOST memory; with skip_first_field the first field of every line is not parsed
+ * and name_spans[2 r], name_spans[2 r + 1] are the byte offsets [start, end) of row r's name within the appended text
+ * (host, 2 * rows); col_is_int[c] = 1 iff no field of data column c has a '.' or an exponent (pandas makes such a column
+ * int64).  *first_bad_offset_out (nullable): offset of the first refused field, -1 if none.  All four synchronise the
+ * device's null stream; no prmf_ctx is needed; errors are read with prmf_last_error(NULL).
+ */
+typedef struct prmf_text prmf_text;
+enum { PRMF_TEXT_RAGGED = 1, PRMF_TEXT_QUOTED = 2, PRMF_TEXT_NOT_NUMERIC = 4, PRMF_TEXT_WIDE_INT = 8 };
+int prmf_text_create(prmf_text** out, int device, int64_t nbytes);
+int prmf_text_append(prmf_text* text, const void* bytes, int64_t nbytes);
+int prmf_text_index(prmf_text* text, char delimiter, int64_t fields_per_line, int64_t* rows_out, int* flags_out);
+int prmf_text_parse(prmf_text* text, int skip_first_field, double* out, int64_t* name_spans, int32_t* col_is_int, int* flags_out,
+                    int64_t* first_bad_offset_out);
+int prmf_text_destroy(prmf_text* text);
+
+/*
  * Direct reconstruction error of this rank's rows: *out_local = sum_ij (X_g - U_g V^T)_ij^2 over the stored X
  * (float64 sum; X - U V^T formed on the bf16 MFMA with both factors split into three exact bf16 pieces, X exact), what the reference computes at
  * prmf_runner.py:337 before the square root.  One sweep over X; needs prmf_set_x only.  dU (m_local x k), dV (n x k):

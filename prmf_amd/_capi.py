@@ -21,6 +21,7 @@ PRMF_FLAG_EAGER_OBJECTIVE = 0x4
 PRMF_FLAG_DIRECT_RESIDUAL = 0x8
 PRMF_DIST_COLUMN_SHARDED, PRMF_DIST_REPLICATED = 0, 1
 PRMF_COMM_ID_BYTES = 128
+PRMF_TEXT_RAGGED, PRMF_TEXT_QUOTED, PRMF_TEXT_NOT_NUMERIC, PRMF_TEXT_WIDE_INT = 1, 2, 4, 8
 OBJ_KEYS = ("recon", "manifold", "ignore", "fro", "gamma", "delta", "obj")
 
 PRMF_OK = 0
@@ -73,6 +74,11 @@ SIGNATURES = {
     "prmf_cv_error": (_i, [_vp, _vp, _vp, _vp]),
     "prmf_residual_sq": (_i, [_vp, _vp, _vp, C.POINTER(_d), _vp]),
     "prmf_quantile_transform": (_i, [_i, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int64, _i, _vp]),
+    "prmf_text_create": (_i, [C.POINTER(_vp), _i, C.c_int64]),
+    "prmf_text_append": (_i, [_vp, _vp, C.c_int64]),
+    "prmf_text_index": (_i, [_vp, C.c_char, C.c_int64, C.POINTER(C.c_int64), C.POINTER(_i)]),
+    "prmf_text_parse": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(C.c_int64)]),
+    "prmf_text_destroy": (_i, [_vp]),
     "prmf_get_sweep_info": (_i, [_vp, C.POINTER(SweepInfo)]),
     "prmf_set_timing": (_i, [_vp, _i]),
     "prmf_get_timing": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)]),

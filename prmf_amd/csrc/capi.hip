@@ -26,6 +26,8 @@ constexpr int MAX_RECORDS = 256;   // objective records kept on the device betwe
 static_assert(PRMF_OBJ_STRIDE == REC_STRIDE && PRMF_OBJ_FLAGS == REC_FLAGS && PRMF_OBJ_RECON_SQ_IDENTITY == REC_RECON_SQ_IDENTITY &&
               PRMF_RECON_DIRECT == REC_FLAG_DIRECT && PRMF_RECON_IMPRECISE == REC_FLAG_IMPRECISE && PRMF_RECON_CLAMPED == REC_FLAG_CLAMPED,
               "record layout of the header and of the kernels");
+static_assert(PRMF_TEXT_RAGGED == TEXT_FLAG_RAGGED && PRMF_TEXT_QUOTED == TEXT_FLAG_QUOTED && PRMF_TEXT_NOT_NUMERIC == TEXT_FLAG_NOT_NUMERIC &&
+              PRMF_TEXT_WIDE_INT == TEXT_FLAG_WIDE_INT, "text flags of the header and of the kernels");
 }
 
 struct prmf_ctx {
@@ -1374,6 +1376,184 @@ int prmf_quantile_transform(int device, double* dX, int64_t m, int64_t n, int64_
   (void)hipFree(dref);
   (void)hipFree(drows);
   if (e != hipSuccess) return fail(nullptr, PRMF_ERR_HIP, "prmf_quantile_transform: %s", hipGetErrorString(e));
+  return PRMF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// delimited text -> float64 matrix (textio.hip)
+// ---------------------------------------------------------------------------
+struct prmf_text {
+  int device = 0;
+  unsigned char* text = nullptr;      // capacity + 1 bytes (room for a final '\n')
+  int64_t capacity = 0, filled = 0;
+  int last_byte = -1;                 // of the text appended so far
+  int64_t* sep_pos = nullptr;
+  int64_t fields_per_line = 0, rows = 0;
+  bool indexed = false;
+};
+
+namespace {
+int text_fail(prmf_text* t, int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_create_error, 512, fmt, ap);      // no context: prmf_last_error(NULL), as for prmf_create
+  va_end(ap);
+  (void)t;
+  return code;
+}
+#define TEXT_TRY(t, expr)                                                                                \
+  do {                                                                                                   \
+    hipError_t _e = (expr);                                                                              \
+    if (_e != hipSuccess) return text_fail(t, PRMF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));     \
+  } while (0)
+}  // namespace
+
+int prmf_text_create(prmf_text** out, int device, int64_t nbytes) {
+  if (!out) return PRMF_ERR_ARG;
+  *out = nullptr;
+  if (nbytes < 0 || nbytes > ((int64_t)1 << 40)) return text_fail(nullptr, PRMF_ERR_ARG, "prmf_text_create: nbytes=%lld outside [0, 2^40]", (long long)nbytes);
+  if (hipSetDevice(device) != hipSuccess) return text_fail(nullptr, PRMF_ERR_HIP, "hipSetDevice(%d) failed", device);
+  prmf_text* t = new (std::nothrow) prmf_text();
+  if (!t) return text_fail(nullptr, PRMF_ERR_HIP, "out of host memory");
+  t->device = device;
+  t->capacity = nbytes;
+  hipError_t e = hipMalloc((void**)&t->text, (size_t)nbytes + 16);
+  if (e != hipSuccess) {
+    delete t;
+    return text_fail(nullptr, PRMF_ERR_HIP, "hipMalloc(%lld bytes of text): %s", (long long)nbytes + 16, hipGetErrorString(e));
+  }
+  *out = t;
+  return PRMF_OK;
+}
+
+int prmf_text_append(prmf_text* t, const void* bytes, int64_t nbytes) {
+  if (!t || nbytes < 0 || (nbytes > 0 && !bytes)) return PRMF_ERR_ARG;
+  if (t->indexed) return text_fail(t, PRMF_ERR_STATE, "prmf_text_append after prmf_text_index");
+  if (t->filled + nbytes > t->capacity)
+    return text_fail(t, PRMF_ERR_ARG, "prmf_text_append: %lld + %lld bytes exceed the %lld the text was created for", (long long)t->filled,
+                     (long long)nbytes, (long long)t->capacity);
+  if (nbytes == 0) return PRMF_OK;
+  if (hipSetDevice(t->device) != hipSuccess) return text_fail(t, PRMF_ERR_HIP, "hipSetDevice(%d) failed", t->device);
+  TEXT_TRY(t, hipMemcpy(t->text + t->filled, bytes, (size_t)nbytes, hipMemcpyHostToDevice));
+  t->filled += nbytes;
+  t->last_byte = ((const unsigned char*)bytes)[nbytes - 1];
+  return PRMF_OK;
+}
+
+int prmf_text_index(prmf_text* t, char delimiter, int64_t fields_per_line, int64_t* rows_out, int* flags_out) {
+  if (!t || !rows_out || !flags_out) return PRMF_ERR_ARG;
+  const unsigned char d = (unsigned char)delimiter;
+  if (d == 0 || d > 127 || d == '\n' || d == '\r' || d == '"' || d == '.' || d == '+' || d == '-' || d == 'e' || d == 'E' ||
+      (d >= '0' && d <= '9'))
+    return text_fail(t, PRMF_ERR_ARG, "prmf_text_index: delimiter 0x%02x cannot separate decimal numbers", (unsigned)d);
+  if (fields_per_line < 1) return text_fail(t, PRMF_ERR_ARG, "prmf_text_index: fields_per_line < 1");
+  if (t->indexed) return text_fail(t, PRMF_ERR_STATE, "prmf_text_index called twice");
+  if (hipSetDevice(t->device) != hipSuccess) return text_fail(t, PRMF_ERR_HIP, "hipSetDevice(%d) failed", t->device);
+  *rows_out = 0;
+  *flags_out = 0;
+  t->fields_per_line = fields_per_line;
+  if (t->filled == 0) {
+    t->indexed = true;
+    return PRMF_OK;
+  }
+  if (t->last_byte != '\n') {                     // the last line ends like the others
+    const unsigned char nl = '\n';
+    TEXT_TRY(t, hipMemcpy(t->text + t->filled, &nl, 1, hipMemcpyHostToDevice));
+    t->filled += 1;
+    t->last_byte = '\n';
+  }
+  hipStream_t s = nullptr;
+  const int64_t nb = text_blocks(t->filled);
+  int64_t *counts = nullptr, *base = nullptr;
+  int* flags = nullptr;
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  hipError_t e = hipMalloc((void**)&counts, (size_t)(nb + 1) * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&base, (size_t)(nb + 1) * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&flags, sizeof(int));
+  if (e == hipSuccess) e = hipMemsetAsync(flags, 0, sizeof(int), s);
+  if (e == hipSuccess) e = hipMemsetAsync(counts + nb, 0, 8, s);       // one value more: its exclusive sum is the total
+  if (e == hipSuccess) e = text_count(t->text, t->filled, d, counts, s);
+  if (e == hipSuccess) e = text_scan(counts, base, nb + 1, nullptr, &tmp_bytes, s);
+  if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1);
+  if (e == hipSuccess) e = text_scan(counts, base, nb + 1, tmp, &tmp_bytes, s);
+  int64_t n_sep = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&n_sep, base + nb, 8, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  int host_flags = 0;
+  if (e == hipSuccess) {
+    if (n_sep % fields_per_line != 0) {
+      host_flags = PRMF_TEXT_RAGGED;
+    } else {
+      e = hipMalloc((void**)&t->sep_pos, (size_t)(n_sep ? n_sep : 1) * 8);
+      if (e == hipSuccess) e = text_positions(t->text, t->filled, d, base, fields_per_line, t->sep_pos, flags, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(&host_flags, flags, sizeof(int), hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+  }
+  (void)hipFree(counts);
+  (void)hipFree(base);
+  (void)hipFree(flags);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return text_fail(t, PRMF_ERR_HIP, "prmf_text_index: %s", hipGetErrorString(e));
+  t->indexed = true;
+  t->rows = host_flags ? 0 : n_sep / fields_per_line;
+  *rows_out = t->rows;
+  *flags_out = host_flags;
+  return PRMF_OK;
+}
+
+int prmf_text_parse(prmf_text* t, int skip_first_field, double* out, int64_t* name_spans, int32_t* col_is_int, int* flags_out,
+                    int64_t* first_bad_offset_out) {
+  if (!t || !flags_out) return PRMF_ERR_ARG;
+  if (!t->indexed) return text_fail(t, PRMF_ERR_STATE, "prmf_text_parse before prmf_text_index");
+  skip_first_field = skip_first_field ? 1 : 0;
+  const int64_t width = t->fields_per_line - skip_first_field, rows = t->rows;
+  if (width < 1) return text_fail(t, PRMF_ERR_ARG, "prmf_text_parse: no data column (fields_per_line=%lld, skip_first_field=%d)", (long long)t->fields_per_line, skip_first_field);
+  if (rows > 0 && (!out || !col_is_int || (skip_first_field && !name_spans))) return text_fail(t, PRMF_ERR_ARG, "prmf_text_parse: NULL output");
+  *flags_out = 0;
+  if (first_bad_offset_out) *first_bad_offset_out = -1;
+  if (rows == 0) return PRMF_OK;
+  if (hipSetDevice(t->device) != hipSuccess) return text_fail(t, PRMF_ERR_HIP, "hipSetDevice(%d) failed", t->device);
+  hipStream_t s = nullptr;
+  double* d_out = nullptr;
+  int64_t* d_spans = nullptr;
+  int* d_small = nullptr;              // [0] flags, [2..3] first bad offset (8-byte aligned), [4 .. 4 + width) col_not_int
+  hipError_t e = hipMalloc((void**)&d_out, (size_t)rows * width * 8);
+  if (e == hipSuccess && skip_first_field) e = hipMalloc((void**)&d_spans, (size_t)rows * 16);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_small, (size_t)(4 + width) * sizeof(int));
+  if (e == hipSuccess) e = hipMemsetAsync(d_small, 0, (size_t)(4 + width) * sizeof(int), s);
+  if (e == hipSuccess) e = hipMemsetAsync(d_small + 2, 0xff, 8, s);
+  if (e == hipSuccess)
+    e = text_parse(t->text, t->sep_pos, rows * t->fields_per_line, t->fields_per_line, skip_first_field, d_out, d_spans, d_small + 4,
+                   d_small, reinterpret_cast<unsigned long long*>(d_small + 2), s);
+  std::vector<int> small((size_t)(4 + width));
+  if (e == hipSuccess) e = hipMemcpyAsync(small.data(), d_small, small.size() * sizeof(int), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e == hipSuccess && small[0] == 0) {
+    e = hipMemcpy(out, d_out, (size_t)rows * width * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && skip_first_field) e = hipMemcpy(name_spans, d_spans, (size_t)rows * 16, hipMemcpyDeviceToHost);
+    for (int64_t c = 0; c < width; ++c) col_is_int[c] = small[(size_t)4 + c] ? 0 : 1;
+  }
+  (void)hipFree(d_out);
+  (void)hipFree(d_spans);
+  (void)hipFree(d_small);
+  if (e != hipSuccess) return text_fail(t, PRMF_ERR_HIP, "prmf_text_parse: %s", hipGetErrorString(e));
+  *flags_out = small[0];
+  if (small[0] && first_bad_offset_out) {
+    unsigned long long fb;
+    std::memcpy(&fb, &small[2], 8);
+    *first_bad_offset_out = (int64_t)fb;
+  }
+  return PRMF_OK;
+}
+
+int prmf_text_destroy(prmf_text* t) {
+  if (!t) return PRMF_OK;
+  (void)hipSetDevice(t->device);
+  (void)hipFree(t->text);
+  (void)hipFree(t->sep_pos);
+  delete t;
   return PRMF_OK;
 }
 

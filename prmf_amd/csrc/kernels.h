@@ -288,4 +288,24 @@ hipError_t launch_nnls(const double* G, const double* H, const double* xx, int64
 hipError_t quantile_transform_device(double* dX, int64_t m, int64_t n, int64_t ld, const int64_t* fit_rows_dev, int64_t n_fit,
                                      const double* refs, const double* qs, int nq, hipStream_t s);
 
+// ---------------------------------------------------------------------------
+// textio.hip: the numeric body of a delimited text matrix (pd.read_csv at script/prmf_runner.py:942)
+// ---------------------------------------------------------------------------
+constexpr int TEXT_FLAG_RAGGED = 1;        // = PRMF_TEXT_RAGGED ... (include/prmf_hip.h; checked by a static_assert in capi.hip)
+constexpr int TEXT_FLAG_QUOTED = 2;
+constexpr int TEXT_FLAG_NOT_NUMERIC = 4;
+constexpr int TEXT_FLAG_WIDE_INT = 8;
+int64_t text_blocks(int64_t nbytes);       // workgroups (= per-workgroup counts) for nbytes of text
+//   counts[text_blocks(nbytes)]: separators (delim or '\n') per 4 KiB of text
+hipError_t text_count(const unsigned char* text, int64_t nbytes, unsigned char delim, int64_t* counts, hipStream_t s);
+//   exclusive sum of n_values counts into `base` (tmp == nullptr: only *tmp_bytes is set)
+hipError_t text_scan(const int64_t* counts, int64_t* base, int64_t n_values, void* tmp, size_t* tmp_bytes, hipStream_t s);
+//   sep_pos[j] = byte offset of separator j; TEXT_FLAG_RAGGED unless separator j is '\n' exactly when (j + 1) % fields_per_line == 0
+hipError_t text_positions(const unsigned char* text, int64_t nbytes, unsigned char delim, const int64_t* block_base,
+                          int64_t fields_per_line, int64_t* sep_pos, int* flags, hipStream_t s);
+//   out[row][col - skip_first] of every field; name_spans[row] = [start, end) of field 0 when it is skipped;
+//   col_not_int[c] = 1 if some field of data column c has a '.' or an exponent; first_bad = lowest offset of a refused field
+hipError_t text_parse(const unsigned char* text, const int64_t* sep_pos, int64_t n_fields, int64_t fields_per_line, int skip_first,
+                      double* out, int64_t* name_spans, int* col_not_int, int* flags, unsigned long long* first_bad, hipStream_t s);
+
 }  // namespace prmf

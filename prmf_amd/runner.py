@@ -211,8 +211,20 @@ class DataMatrix(object):
         else:
             self.has_header = check_header(args.data, args.delimiter)                                   # :937-942
             self.has_row_names = check_row_names(args.data, args.delimiter, self.has_header)
-            frame = pd.read_csv(args.data, sep=args.delimiter, header='infer' if self.has_header else None, nrows=None,
-                                index_col=0 if self.has_row_names else None)
+            frame = None
+            from . import textio
+            if textio.wanted(args.data):
+                # the numeric body parsed on the GPU (prmf_text_*): the same frame, values bit for bit; a file that is not
+                # plain (quotes, missing values, ragged lines, ...) is left to pandas, which says what it means
+                import torch
+                why = []
+                frame = textio.read_frame(args.data, args.delimiter, self.has_header, self.has_row_names,
+                                          device=torch.cuda.current_device(), why=why, mixed_as_float=True)
+                if frame is None and getattr(args, "verbose", False):
+                    sys.stderr.write("--data is read by pandas: %s\n" % why[0])
+            if frame is None:
+                frame = pd.read_csv(args.data, sep=args.delimiter, header='infer' if self.has_header else None, nrows=None,
+                                    index_col=0 if self.has_row_names else None)
         self.samples = list(frame.index)                   # taken BEFORE the orientation step, as the reference does
         m, n = frame.shape                                  # :946-952: --high-dimensional wants m <= n
         if (m > n) if args.high_dimensional else (m < n):

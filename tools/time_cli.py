@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""End to end: the command line at the reference's typical size (samples << genes, delimited text in, U.csv / V.csv out),
+wall clock by stage.  Writes its inputs under $TMPDIR first (not timed).
+    M=500 N=20000 K=6 P=20 python tools/time_cli.py"""
+import cProfile
+import io
+import os
+import pstats
+import sys
+import tempfile
+import time
+
+t_start = time.perf_counter()
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np  # noqa: E402
+
+m, n, k, P = (int(os.environ.get(v, d)) for v, d in (("M", 500), ("N", 20000), ("K", 6), ("P", 20)))
+d = tempfile.mkdtemp(prefix="prmf_cli_")
+rs = np.random.RandomState(0)
+X = rs.gamma(5.0, size=(m, k)).dot(rs.gamma(5.0, size=(n, k)).T)
+genes = ["ENSP%d" % i for i in range(n)]
+t0 = time.perf_counter()
+with open(os.path.join(d, "data.csv"), "w") as fh:
+    fh.write("," + ",".join(genes) + "\n")
+    for i in range(m):
+        fh.write("s%d," % i + ",".join(map(repr, X[i].tolist())) + "\n")
+print("inputs: %d x %d matrix as text, %.0f MB, written in %.1f s" % (m, n, os.path.getsize(os.path.join(d, "data.csv")) / 1e6, time.perf_counter() - t0), flush=True)
+fps = []
+for p in range(P):
+    inds = rs.choice(n, 300, replace=False)
+    fp = os.path.join(d, "g%d.graphml" % p)
+    with open(fp, "w") as fh:
+        fh.write('<?xml version="1.0" encoding="utf-8"?><graphml xmlns="http://graphml.graphdrawing.org/xmlns"><key id="d0" for="node" attr.name="name" attr.type="string"/><graph edgedefault="undirected">\n')
+        for j, g in enumerate(inds):
+            fh.write('<node id="%d"><data key="d0">%s</data></node>\n' % (j, genes[g]))
+        for j in range(1, len(inds)):
+            fh.write('<edge source="%d" target="%d"/>\n' % (rs.randint(0, j), j))
+        fh.write('</graph></graphml>\n')
+    fps.append(fp)
+
+t_imp = time.perf_counter()
+from prmf_amd import runner  # noqa: E402
+import torch  # noqa: E402
+torch.cuda.init()
+print("imports (prmf_amd, torch, device init): %.2f s" % (time.perf_counter() - t_imp), flush=True)
+argv = ["--data", os.path.join(d, "data.csv"), "--manifolds"] + fps + ["--outdir", os.path.join(d, "out"), "-k", str(k), "--seed", "1"] + \
+    os.environ.get("EXTRA", "").split()
+os.makedirs(os.path.join(d, "out"), exist_ok=True)
+for rep in range(2):
+    out = io.StringIO()
+    pr = cProfile.Profile()
+    so, se = sys.stdout, sys.stderr
+    sys.stdout, sys.stderr = io.StringIO(), io.StringIO()
+    t0 = time.perf_counter()
+    try:
+        pr.enable()
+        runner.main(argv)
+        pr.disable()
+    finally:
+        lines = sys.stdout.getvalue().count("\n")
+        sys.stdout, sys.stderr = so, se
+    print("run %d: main() %.2f s (%d lines printed)" % (rep, time.perf_counter() - t0, lines), flush=True)
+pstats.Stats(pr, stream=out).sort_stats("cumulative").print_stats(int(os.environ.get("TOP", 40)))
+print(out.getvalue())
+import shutil  # noqa: E402
+shutil.rmtree(d, ignore_errors=True)
