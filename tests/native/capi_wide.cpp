@@ -1,7 +1,7 @@
 // The rest of the C-ABI from plain C++ (tests/test_gpu_native.py): several contexts of different plans
 // (f32 / bf16 X, k = 6 .. 128, 4- and 8-wave sweeps, sliced reductions, ragged sizes), prmf_step with and without the
 // tradeoff feedback and in the eager / direct-residual forms, the phase calls, candidate scores, held-out error, direct
-// residual, timing, introspection, the quantile transform, invalidation, error paths on a live context.  Values are only
+// residual, timing, introspection, the quantile transform, the text reader, invalidation, error paths on a live context.  Values are only
 // checked for being finite and sane -- the parity tests own the numbers; what this run is for is every entry point and
 // every host-side buffer the library sizes from a plan, from a caller that is not Python.
 #include <hip/hip_runtime.h>
@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <string>
 #include <vector>
 #include <unistd.h>
 
@@ -176,6 +178,45 @@ int main() {
         if (i == 7 && j == 3) { REQUIRE(std::isnan(v)); } else { REQUIRE(v >= 0.0 && v <= 1.0); }
       }
     (void)hipFree(dA);
+  }
+  {
+    // the text reader (no context): 40 lines of 1 name + 25 numbers, appended in pieces of 97 bytes, last line not terminated
+    prmf_ctx* ctx = nullptr;
+    std::string body;
+    std::vector<double> want;
+    char word[64];
+    for (int i = 0; i < 40; ++i) {
+      std::snprintf(word, sizeof word, "row %d", i);
+      body += word;
+      for (int j = 0; j < 25; ++j) {
+        const double v = (lcg() - 0.5) * std::pow(10.0, (double)((i + j) % 9 - 4));
+        std::snprintf(word, sizeof word, ";%.9g", v);
+        body += word;
+        want.push_back(std::strtod(word + 1, nullptr));          // <= 10 digits: pandas' conversion is the exact one there
+      }
+      if (i != 39) body += i % 2 ? "\r\n" : "\n";
+    }
+    prmf_text* t = nullptr;
+    CK(prmf_text_create(&t, 0, (int64_t)body.size()));
+    for (size_t off = 0; off < body.size(); off += 97) CK(prmf_text_append(t, body.data() + off, (int64_t)std::min<size_t>(97, body.size() - off)));
+    int64_t rows = 0, bad = 0;
+    int flags = -1;
+    CK(prmf_text_index(t, ';', 26, &rows, &flags));
+    REQUIRE(rows == 40 && flags == 0);
+    std::vector<double> out((size_t)(40 * 25));
+    std::vector<int64_t> spans(80);
+    std::vector<int32_t> is_int(25);
+    CK(prmf_text_parse(t, 1, out.data(), spans.data(), is_int.data(), &flags, &bad));
+    REQUIRE(flags == 0 && bad == -1);
+    for (size_t i = 0; i < out.size(); ++i) REQUIRE(out[i] == want[i]);
+    REQUIRE(body.substr((size_t)spans[2 * 17], (size_t)(spans[2 * 17 + 1] - spans[2 * 17])) == "row 17");
+    for (int j = 0; j < 25; ++j) REQUIRE(is_int[(size_t)j] == 0);
+    CK(prmf_text_destroy(t));
+    CK(prmf_text_create(&t, 0, 12));                              // a ragged body is reported, not parsed
+    CK(prmf_text_append(t, "1;2\n3;4;5\n6\n", 12));
+    CK(prmf_text_index(t, ';', 2, &rows, &flags));
+    REQUIRE(flags == PRMF_TEXT_RAGGED && rows == 0);
+    CK(prmf_text_destroy(t));
   }
   std::printf("wide OK\n");
   std::fflush(stdout);
