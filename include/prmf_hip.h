@@ -326,6 +326,19 @@ int prmf_text_parse(prmf_text* text, int skip_first_field, double* out, int64_t*
 int prmf_text_destroy(prmf_text* text);
 
 /*
+ * A float64 matrix as delimited text, byte for byte what `pd.DataFrame(U, index=..., columns=...).to_csv(path, sep=",",
+ * quoting=csv.QUOTE_NONNUMERIC)` writes for U.csv / V.csv (script/prmf_runner.py:1068-1071): every float as Python's
+ * repr() prints it (shortest digits that read back as the same double; positional when the decimal point falls in
+ * (-4, 16], else d[.ddd]e[+-]XX; "inf" / "-inf"; NaN as the quoted empty string), fields joined by `separator`, lines
+ * ended by "\n".  header_line (nullable): written first as it is (the caller quotes the labels and ends the line);
+ * row_prefixes / row_prefix_offsets (both or neither): the bytes that start row r -- its quoted label and the separator
+ * -- are row_prefixes[row_prefix_offsets[r] .. row_prefix_offsets[r + 1]).  values: rows x cols, leading dimension ld,
+ * HOST memory.  n_threads < 1: one per core, at most 16.  Host work only (no device, no context).
+ */
+int prmf_write_csv(const char* path, const char* header_line, const char* row_prefixes, const int64_t* row_prefix_offsets,
+                   const double* values, int64_t rows, int64_t cols, int64_t ld, char separator, int n_threads);
+
+/*
  * Direct reconstruction error of this rank's rows: *out_local = sum_ij (X_g - U_g V^T)_ij^2 over the stored X
  * (float64 sum; X - U V^T formed on the bf16 MFMA with both factors split into three exact bf16 pieces, X exact), what the reference computes at
  * prmf_runner.py:337 before the square root.  One sweep over X; needs prmf_set_x only.  dU (m_local x k), dV (n x k):

@@ -79,6 +79,7 @@ SIGNATURES = {
     "prmf_text_index": (_i, [_vp, C.c_char, C.c_int64, C.POINTER(C.c_int64), C.POINTER(_i)]),
     "prmf_text_parse": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(C.c_int64)]),
     "prmf_text_destroy": (_i, [_vp]),
+    "prmf_write_csv": (_i, [C.c_char_p, C.c_char_p, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_char, _i]),
     "prmf_get_sweep_info": (_i, [_vp, C.POINTER(SweepInfo)]),
     "prmf_set_timing": (_i, [_vp, _i]),
     "prmf_get_timing": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)]),

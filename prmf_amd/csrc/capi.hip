@@ -1548,6 +1548,20 @@ int prmf_text_parse(prmf_text* t, int skip_first_field, double* out, int64_t* na
   return PRMF_OK;
 }
 
+int prmf_write_csv(const char* path, const char* header_line, const char* row_prefixes, const int64_t* row_prefix_offsets,
+                   const double* values, int64_t rows, int64_t cols, int64_t ld, char separator, int n_threads) {
+  if (!path || rows < 0 || cols < 1 || ld < cols || (rows > 0 && !values) || ((row_prefixes == nullptr) != (row_prefix_offsets == nullptr)))
+    return text_fail(nullptr, PRMF_ERR_ARG, "prmf_write_csv: bad arguments");
+  if (n_threads < 1) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    n_threads = hw ? (int)(hw < 16 ? hw : 16) : 1;
+  }
+  if (rows * cols < 65536) n_threads = 1;
+  const int err = text_write_matrix(path, header_line, row_prefixes, row_prefix_offsets, values, rows, cols, ld, separator, n_threads);
+  if (err) return text_fail(nullptr, PRMF_ERR_ARG, "prmf_write_csv(%s): %s", path, err > 0 ? std::strerror(err) : "write failed");
+  return PRMF_OK;
+}
+
 int prmf_text_destroy(prmf_text* t) {
   if (!t) return PRMF_OK;
   (void)hipSetDevice(t->device);

@@ -307,5 +307,8 @@ hipError_t text_positions(const unsigned char* text, int64_t nbytes, unsigned ch
 //   col_not_int[c] = 1 if some field of data column c has a '.' or an exponent; first_bad = lowest offset of a refused field
 hipError_t text_parse(const unsigned char* text, const int64_t* sep_pos, int64_t n_fields, int64_t fields_per_line, int skip_first,
                       double* out, int64_t* name_spans, int* col_not_int, int* flags, unsigned long long* first_bad, hipStream_t s);
+//   host: a float64 matrix as DataFrame.to_csv(quoting=QUOTE_NONNUMERIC) writes it (repr floats); 0 or the errno of the failure
+int text_write_matrix(const char* path, const char* header, const char* prefixes, const int64_t* prefix_off, const double* values,
+                      int64_t rows, int64_t cols, int64_t ld, char sep, int n_threads);
 
 }  // namespace prmf

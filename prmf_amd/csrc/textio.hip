@@ -19,6 +19,15 @@
 // grammar, a quote outside the first column, a ragged line raise a flag and the caller gives the file to pandas.
 #include <hipcub/hipcub.hpp>
 
+#include <cerrno>
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
 #include "kernels.h"
 #include "xstrtod.h"
 
@@ -164,6 +173,135 @@ hipError_t text_parse(const unsigned char* text, const int64_t* sep_pos, int64_t
   text_parse_kernel<<<dim3((unsigned)nb), TEXT_TPB, 0, s>>>(text, sep_pos, n_fields, fields_per_line, skip_first, out, name_spans,
                                                              col_not_int, flags, first_bad);
   return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// float64 matrix -> delimited text, the way `DataFrame.to_csv(path, sep=",", quoting=csv.QUOTE_NONNUMERIC)` writes U.csv and
+// V.csv (script/prmf_runner.py:1068-1071): Python's csv module prints a float with repr() -- the shortest digit string that
+// reads back as the same double (std::to_chars gives the same digits), laid out by CPython's rule: positional notation when
+// the decimal point falls in (-4, 16], else d[.ddd]e[+-]XX; ".0" appended to positional integers; NaN is the quoted
+// empty string (na_rep under QUOTE_NONNUMERIC).  Host work (one thread per row range), here because this file is the text
+// I/O of the data matrix; 50000 x 64 + 20000 x 64: 3.0 s in pandas (profiles/r05_cli_end_to_end.txt).
+// ---------------------------------------------------------------------------
+namespace {
+
+// -> characters written (at most 26)
+inline int format_repr(double x, char* out) {
+  if (x != x) {
+    out[0] = '"';
+    out[1] = '"';
+    return 2;
+  }
+  char* o = out;
+  if (std::signbit(x)) {
+    *o++ = '-';
+    x = -x;
+  }
+  if (std::isinf(x)) {
+    std::memcpy(o, "inf", 3);
+    return (int)(o + 3 - out);
+  }
+  char sci[40];                                      // d[.ddd]e[+-]XX, shortest round-trip digits
+  const std::to_chars_result r = std::to_chars(sci, sci + sizeof sci, x, std::chars_format::scientific);
+  char digits[24];
+  int nd = 0;
+  const char* p = sci;
+  for (; p < r.ptr && *p != 'e'; ++p)
+    if (*p != '.') digits[nd++] = *p;
+  ++p;                                               // 'e'
+  const bool eneg = *p == '-';
+  ++p;
+  int e10 = 0;
+  for (; p < r.ptr; ++p) e10 = e10 * 10 + (*p - '0');
+  if (eneg) e10 = -e10;
+  const int decpt = e10 + 1;                         // digits are 0.d1d2... x 10^decpt
+  if (decpt > -4 && decpt <= 16) {
+    if (decpt <= 0) {
+      *o++ = '0';
+      *o++ = '.';
+      for (int i = 0; i < -decpt; ++i) *o++ = '0';
+      std::memcpy(o, digits, (size_t)nd);
+      o += nd;
+    } else if (decpt >= nd) {
+      std::memcpy(o, digits, (size_t)nd);
+      o += nd;
+      for (int i = nd; i < decpt; ++i) *o++ = '0';
+      *o++ = '.';
+      *o++ = '0';
+    } else {
+      std::memcpy(o, digits, (size_t)decpt);
+      o += decpt;
+      *o++ = '.';
+      std::memcpy(o, digits + decpt, (size_t)(nd - decpt));
+      o += nd - decpt;
+    }
+  } else {
+    *o++ = digits[0];
+    if (nd > 1) {
+      *o++ = '.';
+      std::memcpy(o, digits + 1, (size_t)(nd - 1));
+      o += nd - 1;
+    }
+    *o++ = 'e';
+    int e = decpt - 1;
+    *o++ = e < 0 ? '-' : '+';
+    if (e < 0) e = -e;
+    if (e >= 100) *o++ = (char)('0' + e / 100);
+    *o++ = (char)('0' + (e / 10) % 10);
+    *o++ = (char)('0' + e % 10);
+  }
+  return (int)(o - out);
+}
+
+}  // namespace
+
+// rows [r0, r1) of `values` as text lines appended to *out: prefix (nullable offsets), fields joined by `sep`, '\n'
+void text_format_rows(const double* values, int64_t ld, int64_t cols, int64_t r0, int64_t r1, const char* prefixes,
+                      const int64_t* prefix_off, char sep, std::string* out) {
+  char cell[32];
+  for (int64_t r = r0; r < r1; ++r) {
+    if (prefixes) out->append(prefixes + prefix_off[r], (size_t)(prefix_off[r + 1] - prefix_off[r]));
+    const double* row = values + r * ld;
+    for (int64_t c = 0; c < cols; ++c) {
+      if (c) out->push_back(sep);
+      out->append(cell, (size_t)format_repr(row[c], cell));
+    }
+    out->push_back('\n');
+  }
+}
+
+// 0 on success, else errno of the failing stdio call
+int text_write_matrix(const char* path, const char* header, const char* prefixes, const int64_t* prefix_off, const double* values,
+                      int64_t rows, int64_t cols, int64_t ld, char sep, int n_threads) {
+  std::FILE* fh = std::fopen(path, "wb");
+  if (!fh) return errno ? errno : -1;
+  int err = 0;
+  if (header && std::fputs(header, fh) < 0) err = errno ? errno : -1;
+  if (n_threads < 1) n_threads = 1;
+  const int64_t block = 4096 * (int64_t)n_threads;       // rows formatted between two writes
+  std::vector<std::string> parts((size_t)n_threads);
+  for (int64_t b0 = 0; b0 < rows && !err; b0 += block) {
+    const int64_t b1 = b0 + block < rows ? b0 + block : rows;
+    const int64_t per = (b1 - b0 + n_threads - 1) / n_threads;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; ++t) {
+      const int64_t r0 = b0 + t * per, r1 = r0 + per < b1 ? r0 + per : b1;
+      parts[(size_t)t].clear();
+      if (r0 >= r1) continue;
+      parts[(size_t)t].reserve((size_t)(r1 - r0) * (size_t)(cols * 26 + 64));      // once: clear() keeps it for the next block
+      if (n_threads == 1) {
+        text_format_rows(values, ld, cols, r0, r1, prefixes, prefix_off, sep, &parts[0]);
+      } else {
+        pool.emplace_back(text_format_rows, values, ld, cols, r0, r1, prefixes, prefix_off, sep, &parts[(size_t)t]);
+      }
+    }
+    for (auto& th : pool) th.join();
+    for (int t = 0; t < n_threads && !err; ++t)
+      if (!parts[(size_t)t].empty() && std::fwrite(parts[(size_t)t].data(), 1, parts[(size_t)t].size(), fh) != parts[(size_t)t].size())
+        err = errno ? errno : -1;
+  }
+  if (std::fclose(fh) != 0 && !err) err = errno ? errno : -1;
+  return err;
 }
 
 }  // namespace prmf

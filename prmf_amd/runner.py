@@ -344,10 +344,18 @@ def write_outputs(args, data, manifolds, samples, nodelist, U, V, obj_data):
     (`key = %.5f` lines, then `k -> manifold path`, :1081-1093)."""
     import pandas as pd
     cols = ["LV{}".format(x) for x in range(args.k_latent)]
-    pd.DataFrame(U, index=samples, columns=cols).to_csv(os.path.join(args.outdir, "U.csv"), sep=",",
-                                                        index=data.has_row_names, quoting=csv.QUOTE_NONNUMERIC)
-    pd.DataFrame(V, index=nodelist, columns=cols).to_csv(os.path.join(args.outdir, "V.csv"), sep=",", index=True,
-                                                         quoting=csv.QUOTE_NONNUMERIC)
+    from . import textio
+    # the two matrices: prmf_write_csv prints the same bytes (repr floats, QUOTE_NONNUMERIC labels) on all cores; labels that
+    # are not plain strings / integers go through pandas as before
+    # (the frame is built from ALL sample labels even when they are not written: labels that do not fit U raise pandas'
+    # shape error there, as in the reference -- tests/test_gpu_solver.py::test_cli_genes_by_samples_input_fails_...)
+    if len(samples) != np.shape(U)[0] or \
+            not textio.write_frame(os.path.join(args.outdir, "U.csv"), U, samples if data.has_row_names else None, cols):
+        pd.DataFrame(U, index=samples, columns=cols).to_csv(os.path.join(args.outdir, "U.csv"), sep=",",
+                                                            index=data.has_row_names, quoting=csv.QUOTE_NONNUMERIC)
+    if len(nodelist) != np.shape(V)[0] or not textio.write_frame(os.path.join(args.outdir, "V.csv"), V, nodelist, cols):
+        pd.DataFrame(V, index=nodelist, columns=cols).to_csv(os.path.join(args.outdir, "V.csv"), sep=",", index=True,
+                                                             quoting=csv.QUOTE_NONNUMERIC)
     with open(os.path.join(args.outdir, "obj.txt"), 'w') as fh:
         l2p = obj_data.pop('latent_to_pathway_data', {})
         for key, val in obj_data.items():

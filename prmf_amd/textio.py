@@ -166,3 +166,54 @@ def _read_frame(path, delimiter, has_header, has_row_names, device, mixed_as_flo
     else:
         index = pd.RangeIndex(m)
     return pd.DataFrame(body, index=index, columns=columns, copy=False)
+
+
+def write_frame(path, values, index, columns):
+    """pd.DataFrame(values, index=index, columns=columns).to_csv(path, sep=",", index=index is not None,
+    quoting=csv.QUOTE_NONNUMERIC) -- the call that writes U.csv / V.csv (script/prmf_runner.py:1068-1071) -- byte for byte,
+    with the floats formatted by `prmf_write_csv` (repr digits, on all cores) instead of one Python object per cell:
+    3.0 s -> 0.2 s for 50000 x 64 + 20000 x 64.  Takes the plain case only -- a 2-D float64 matrix, labels that are all
+    `str` or all `int` -- and returns False otherwise (the caller then writes with pandas)."""
+    a = np.asarray(values)
+    if a.dtype != np.float64 or a.ndim != 2 or a.shape[1] < 1:
+        return False
+    columns = list(columns)
+    if len(columns) != a.shape[1] or not all(type(c) is str for c in columns):
+        return False
+    buf = io.StringIO()
+    w = csv.writer(buf, delimiter=",", quoting=csv.QUOTE_NONNUMERIC, lineterminator="\n")
+    prefixes = offsets = None
+    keep = []
+    if index is not None:
+        index = list(index)
+        if len(index) != a.shape[0]:
+            return False
+        if all(type(x) is str for x in index):
+            pass
+        elif all(isinstance(x, (int, np.integer)) and not isinstance(x, (bool, np.bool_)) for x in index):
+            index = [int(x) for x in index]
+        else:
+            return False
+        w.writerow([""] + columns)                  # the index has no name: pandas writes the empty label, quoted
+        header = buf.getvalue().encode("utf-8")
+        buf = io.StringIO()
+        w = csv.writer(buf, delimiter=",", quoting=csv.QUOTE_NONNUMERIC, lineterminator="\n")
+        w.writerows([x] for x in index)
+        cells = buf.getvalue().encode("utf-8").split(b"\n")[:-1]
+        if len(cells) != len(index):                # a label with a line break inside: not plain
+            return False
+        blob = b",".join(cells) + b","
+        offsets = np.zeros(len(cells) + 1, dtype=np.int64)
+        np.cumsum([len(c) + 1 for c in cells], out=offsets[1:])
+        prefixes = blob
+        keep = [blob, offsets]
+    else:
+        w.writerow(columns)
+        header = buf.getvalue().encode("utf-8")
+    a = np.ascontiguousarray(a)
+    lib = _capi.load()
+    rc = lib.prmf_write_csv(os.fsencode(path), header, prefixes, offsets.ctypes.data_as(C.c_void_p) if offsets is not None else None,
+                            a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], a.shape[1], b",", 0)
+    del keep
+    _capi.check(lib, None, rc)
+    return True

@@ -106,3 +106,50 @@ def test_delimiters_that_cannot_separate_numbers_are_left_to_pandas(tmp_path, de
     f.write_text("1\n2\n")
     why = []
     assert textio.read_frame(str(f), delimiter, False, False, why=why) is None and why
+
+
+def _pandas_bytes(tmp_path, values, index, columns):
+    import csv
+    p = str(tmp_path / "want.csv")
+    pd.DataFrame(values, index=index, columns=columns).to_csv(p, sep=",", index=index is not None, quoting=csv.QUOTE_NONNUMERIC)
+    return open(p, "rb").read()
+
+
+def test_written_matrix_equals_pandas_byte_for_byte(tmp_path):
+    """prmf_write_csv (host code of the library: runs without a GPU) against DataFrame.to_csv(quoting=QUOTE_NONNUMERIC), the
+    call that writes U.csv / V.csv (prmf_runner.py:1068-1071): repr() of every float, quoted labels."""
+    rs = np.random.RandomState(8)
+    special = [0.0, -0.0, 1.0, -1.0, 0.1, 1e16, 1e15, 9999999999999998.0, 1e-4, 1e-5, 0.00012345, 123456789012345678.0, 5e-324, 2.2250738585072014e-308,
+               1.7976931348623157e308, float("inf"), float("-inf"), float("nan"), 1e22, 1e23, 1.5e300, 2.5e-300, 100.0, 1e100, 123456.789,
+               float(np.float32(0.3)), float(np.float32(1e-7)), float(np.finfo(np.float32).eps)]
+    a = np.concatenate([np.array(special), rs.rand(300), rs.gamma(2.0, size=300) * 10.0 ** rs.randint(-30, 30, 300),
+                        rs.rand(300).astype(np.float32).astype(np.float64), np.frombuffer(rs.bytes(8 * 372), dtype=np.float64)])
+    a = a[:1300].reshape(100, 13)
+    cols = ["LV%d" % i for i in range(13)]
+    cases = [(None, "no index"), (["s%d" % i for i in range(100)], "strings"), (list(range(100, 200)), "integers"),
+             (['he said "x"', "a,b", "naïve", "", " lead"] + ["r%d" % i for i in range(95)], "awkward strings"),
+             (list(np.arange(100, dtype=np.int64)), "numpy integers")]
+    for index, what in cases:
+        out = str(tmp_path / "got.csv")
+        assert textio.write_frame(out, a, index, cols), what
+        assert open(out, "rb").read() == _pandas_bytes(tmp_path, a, index, cols), what
+    # the threaded path (>= 65536 cells), a matrix as the solver returns it (float32 values held in float64)
+    big = (3 * rs.rand(3000, 64)).astype(np.float32).astype(np.float64)
+    out = str(tmp_path / "big.csv")
+    assert textio.write_frame(out, big, ["g%d" % i for i in range(3000)], ["LV%d" % i for i in range(64)])
+    assert open(out, "rb").read() == _pandas_bytes(tmp_path, big, ["g%d" % i for i in range(3000)], ["LV%d" % i for i in range(64)])
+
+
+def test_writer_leaves_what_is_not_plain_to_pandas(tmp_path):
+    a = np.ones((3, 2))
+    out = str(tmp_path / "x.csv")
+    assert not textio.write_frame(out, a.astype(np.float32), None, ["a", "b"])
+    assert not textio.write_frame(out, a, [1.5, 2.5, 3.5], ["a", "b"])
+    assert not textio.write_frame(out, a, ["a", 1, "c"], ["a", "b"])
+    assert not textio.write_frame(out, a, ["a", "line\nbreak", "c"], ["a", "b"])
+    assert not textio.write_frame(out, a, [True, False, True], ["a", "b"])
+    assert not textio.write_frame(out, a, None, ["a", 2])
+    assert not os.path.exists(out)
+    from prmf_amd import _capi
+    with pytest.raises(_capi.PrmfError):
+        textio.write_frame(str(tmp_path / "no" / "such" / "dir.csv"), a, None, ["a", "b"])
