@@ -101,9 +101,10 @@ def relabel_nodes(G, node_attribute):
 
 
 def parse_pathways(manifold_fps, node_attribute="name"):
-    """prmf_runner.py:833-868."""
-    import networkx as nx
-    return [(relabel_nodes(nx.read_graphml(fp).to_undirected(), node_attribute), fp) for fp in manifold_fps]
+    """prmf_runner.py:833-868: `relabel_nodes(nx.read_graphml(fp).to_undirected(), node_attribute)` per file -- built in one
+    pass by prmf_amd.graphml.read_pathway (the same networkx.Graph; files that are not plain go through networkx itself)."""
+    from .graphml import read_pathway
+    return [(read_pathway(fp, node_attribute), fp) for fp in manifold_fps]
 
 
 def parse_nodelist(fh):

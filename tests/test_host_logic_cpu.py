@@ -195,3 +195,109 @@ def test_fast_matching_equals_networkx():
                 G.add_edge("k%d" % k, "l%d" % p, weight=w)
         want = sorted((int(a[1:]), int(b[1:])) if a[0] == "k" else (int(b[1:]), int(a[1:])) for a, b in nx.max_weight_matching(G))
         assert sorted(solver._max_weight_matching(per_latent)) == want, trial
+
+
+def _same_graph(a, b):
+    assert type(a) is type(b)
+    assert list(a.nodes()) == list(b.nodes())
+    assert dict(a.nodes(data=True)) == dict(b.nodes(data=True))
+    assert a.graph == b.graph
+    for u in a.nodes():
+        assert list(a.adj[u]) == list(b.adj[u]), u            # adjacency ORDER too
+        for v in a.adj[u]:
+            assert a.adj[u][v] == b.adj[u][v] and {k: type(x) for k, x in a.adj[u][v].items()} == {k: type(x) for k, x in b.adj[u][v].items()}
+    assert list(a.edges(data=True)) == list(b.edges(data=True))
+
+
+def test_fast_graphml_equals_networkx(tmp_path):
+    """prmf_amd.graphml.read_pathway against the reference's three steps (prmf_runner.py:863-866): class, node order, node
+    and edge attributes with their types, adjacency order, graph attributes -- for plain files built directly and for
+    every kind of file that is handed to networkx instead."""
+    import networkx as nx
+    from prmf_amd import graphml
+    from prmf_amd.runner import relabel_nodes
+    rs = np.random.RandomState(4)
+
+    def slow(fp, attr="name"):
+        return relabel_nodes(nx.read_graphml(fp).to_undirected(), attr)
+
+    fast_taken = 0
+    files = []
+    for case in range(12):
+        n = int(rs.randint(1, 60))
+        G = nx.Graph()
+        order = rs.permutation(n)
+        for i in order:
+            attrs = {}
+            if case % 4 != 3 or rs.rand() < 0.7:
+                attrs["name"] = "ENSP%d" % (1000 + i)            # case 3, 7, 11: some nodes keep their id
+            if case % 3 == 0:
+                attrs["score"] = float(rs.rand())
+                attrs["rank"] = int(rs.randint(100))
+                attrs["flag"] = bool(rs.rand() < 0.5)
+            G.add_node(int(i), **attrs)
+        for _ in range(int(rs.randint(0, 3 * n + 1))):
+            u, v = int(rs.randint(n)), int(rs.randint(n))
+            if case % 5 == 4 or u != v:                           # case 4, 9: self loops too
+                w = {}
+                if case % 2:
+                    w["weight"] = float(rs.rand()) if case % 4 == 1 else int(rs.randint(1, 9))
+                G.add_edge(u, v, **w)
+        fp = str(tmp_path / ("g%d.graphml" % case))
+        nx.write_graphml(G, fp, named_key_ids=bool(case % 2))
+        files.append(fp)
+    # hand-written, like the reference's docstring example (:838-848), edges with ids, an empty <data/>, another attribute name
+    fp = str(tmp_path / "hand.graphml")
+    with open(fp, "w") as fh:
+        fh.write('<?xml version="1.0"?>\n<graphml xmlns="http://graphml.graphdrawing.org/xmlns">\n'
+                 '<key attr.name="name" attr.type="string" for="node" id="d1"/><key attr.name="weight" attr.type="double" for="edge" id="d2"/>'
+                 '<key attr.name="note" attr.type="string" for="edge" id="d3"/>\n<graph edgedefault="undirected">\n'
+                 '<node id="11485"><data key="d1">ENSG11486</data></node><node id="7"><data key="d1">ENSG7</data></node><node id="9"/>\n'
+                 '<edge id="e0" source="7" target="11485"><data key="d2">0.25</data></edge><edge source="9" target="7"><data key="d3"/></edge>'
+                 '<edge id="e2" source="9" target="9"/>\n</graph></graphml>\n')
+    files.append(fp)
+    real_fast = graphml._fast
+    for fp in files:
+        for attr in ("name", None, "rank"):
+            _same_graph(graphml.read_pathway(fp, attr), slow(fp, attr))
+            try:
+                real_fast(fp, attr)
+                fast_taken += 1
+            except graphml._NotPlain:
+                pass
+    assert fast_taken >= 30                                   # the plain files did take the direct path
+    # not plain: each must come out as networkx makes it (or raise what networkx raises)
+    head = '<?xml version="1.0"?>\n<graphml xmlns="http://graphml.graphdrawing.org/xmlns">\n<key attr.name="name" attr.type="string" for="node" id="d1"/>\n'
+    odd = {
+        "directed": head + '<graph edgedefault="directed"><node id="a"/><node id="b"/><edge source="a" target="b"/><edge source="b" target="a"/></graph></graphml>',
+        "parallel edges": head + '<graph edgedefault="undirected"><node id="a"/><node id="b"/><edge source="a" target="b"/><edge source="b" target="a"/></graph></graphml>',
+        "undeclared endpoint": head + '<graph edgedefault="undirected"><node id="a"/><edge source="a" target="zz"/></graph></graphml>',
+        "two nodes, one name": head + '<graph edgedefault="undirected"><node id="a"><data key="d1">X</data></node><node id="b"><data key="d1">X</data></node>'
+                                      '<node id="c"/><edge source="a" target="c"/><edge source="b" target="c"/></graph></graphml>',
+        "name equal to another id": head + '<graph edgedefault="undirected"><node id="a"><data key="d1">b</data></node><node id="b"/><edge source="a" target="b"/></graph></graphml>',
+        "default value": head.replace('id="d1"/>', 'id="d1"><default>none</default></key>') + '<graph edgedefault="undirected"><node id="a"/></graph></graphml>',
+        "duplicate node id": head + '<graph edgedefault="undirected"><node id="a"><data key="d1">X</data></node><node id="a"/></graph></graphml>',
+        "graph data": head + '<key attr.name="title" attr.type="string" for="graph" id="d9"/><graph edgedefault="undirected"><data key="d9">t</data><node id="a"/></graph></graphml>',
+        "two graphs": head + '<graph edgedefault="undirected"><node id="a"/></graph><graph edgedefault="undirected"><node id="b"/></graph></graphml>',
+        "untyped key": head.replace(' attr.type="string"', '') + '<graph edgedefault="undirected"><node id="a"><data key="d1">A</data></node></graph></graphml>',
+    }
+    for what, text in odd.items():
+        fp = str(tmp_path / "odd.graphml")
+        with open(fp, "w") as fh:
+            fh.write(text)
+        with pytest.raises(graphml._NotPlain):
+            graphml._fast(fp, "name")
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _same_graph(graphml.read_pathway(fp, "name"), slow(fp, "name"))
+    # what networkx refuses is refused in its words
+    for text in ("not xml at all", head + '<graph edgedefault="undirected"><node id="a"><data key="nokey">1</data></node></graph></graphml>'):
+        fp = str(tmp_path / "bad.graphml")
+        with open(fp, "w") as fh:
+            fh.write(text)
+        with pytest.raises(Exception) as mine:
+            graphml.read_pathway(fp, "name")
+        with pytest.raises(Exception) as theirs:
+            slow(fp)
+        assert type(mine.value) is type(theirs.value) and str(mine.value) == str(theirs.value)

@@ -20,11 +20,18 @@ rs = np.random.RandomState(0)
 X = rs.gamma(5.0, size=(m, k)).dot(rs.gamma(5.0, size=(n, k)).T)
 genes = ["ENSP%d" % i for i in range(n)]
 t0 = time.perf_counter()
-with open(os.path.join(d, "data.csv"), "w") as fh:
-    fh.write("," + ",".join(genes) + "\n")
-    for i in range(m):
-        fh.write("s%d," % i + ",".join(map(repr, X[i].tolist())) + "\n")
-print("inputs: %d x %d matrix as text, %.0f MB, written in %.1f s" % (m, n, os.path.getsize(os.path.join(d, "data.csv")) / 1e6, time.perf_counter() - t0), flush=True)
+as_npy = os.environ.get("FORMAT", "text") == "npy"          # FORMAT=npy: the binary input of large runs (+ --nodelist)
+data_fp = os.path.join(d, "data.npy" if as_npy else "data.csv")
+if as_npy:
+    np.save(data_fp, X.astype(np.float32))
+    with open(os.path.join(d, "nodelist.txt"), "w") as fh:
+        fh.write("\n".join(genes))
+else:
+    with open(data_fp, "w") as fh:
+        fh.write("," + ",".join(genes) + "\n")
+        for i in range(m):
+            fh.write("s%d," % i + ",".join(map(repr, X[i].tolist())) + "\n")
+print("inputs: %d x %d matrix as %s, %.0f MB, written in %.1f s" % (m, n, "float32 .npy" if as_npy else "text", os.path.getsize(data_fp) / 1e6, time.perf_counter() - t0), flush=True)
 fps = []
 for p in range(P):
     inds = rs.choice(n, 300, replace=False)
@@ -43,8 +50,8 @@ from prmf_amd import runner  # noqa: E402
 import torch  # noqa: E402
 torch.cuda.init()
 print("imports (prmf_amd, torch, device init): %.2f s" % (time.perf_counter() - t_imp), flush=True)
-argv = ["--data", os.path.join(d, "data.csv"), "--manifolds"] + fps + ["--outdir", os.path.join(d, "out"), "-k", str(k), "--seed", "1"] + \
-    os.environ.get("EXTRA", "").split()
+argv = ["--data", data_fp, "--manifolds"] + fps + ["--outdir", os.path.join(d, "out"), "-k", str(k), "--seed", "1"] + \
+    (["--nodelist", os.path.join(d, "nodelist.txt")] if as_npy else []) + os.environ.get("EXTRA", "").split()
 os.makedirs(os.path.join(d, "out"), exist_ok=True)
 for rep in range(2):
     out = io.StringIO()
