@@ -47,28 +47,52 @@ def quantile_transform_block(Xb, fit_rows=None, n_quantiles=1000, device=0):
     return Xd.cpu().numpy()
 
 
-def quantile_transform(X, n_quantiles=1000, random_state=None, device=0, copy=True):
-    """Drop-in for sklearn.preprocessing.quantile_transform(X) (uniform output, axis 0): numpy in, numpy out."""
+def _to_device_f64(torch, X, device):
+    """A host matrix of any real dtype -> float64 on the device: uploaded in its OWN dtype in row chunks and widened there
+    (float32 input: half the PCIe bytes and no float64 copy on the host; integers and float32 widen exactly)."""
+    dev = "cuda:%d" % device
+    if X.dtype == np.float64 or X.dtype.kind not in "fiu" or X.nbytes < (32 << 20):
+        return torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(dev)
+    if X.dtype.kind in "iu" and X.dtype.itemsize == 8:
+        return torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(dev)      # 64-bit integers: numpy's own rounding
+    out = torch.empty(X.shape, dtype=torch.float64, device=dev)
+    rows = max(1, (160 << 20) // max(1, X.shape[1] * X.dtype.itemsize))
+    for r0 in range(0, X.shape[0], rows):
+        out[r0:r0 + rows] = torch.from_numpy(np.ascontiguousarray(X[r0:r0 + rows])).to(dev)
+    return out
+
+
+def quantile_transform(X, n_quantiles=1000, random_state=None, device=0, copy=True, on_device=False):
+    """Drop-in for sklearn.preprocessing.quantile_transform(X) (uniform output, axis 0): numpy in, numpy out.
+    on_device=True: the result stays where it was computed -- a float64 torch tensor on the GPU, which nmf_pathway takes
+    as X -- instead of travelling to the host and back (the command line's single-GPU path)."""
     import torch
     if not torch.cuda.is_available():
         raise RuntimeError("prmf_amd.preprocess.quantile_transform needs a ROCm GPU; there is no CPU path here")
     lib = _capi.load()
-    X = np.asarray(X, dtype=np.float64)
+    X = np.asarray(X)
+    if X.dtype.kind not in "fiu":
+        X = np.asarray(X, dtype=np.float64)
     if X.ndim != 2:
         raise ValueError("X must be 2-D (samples x genes)")
     m, n = X.shape
     if m == 0 or n == 0:
+        X = np.asarray(X, dtype=np.float64)
+        if on_device:
+            return torch.from_numpy(np.ascontiguousarray(X)).to("cuda:%d" % device)
         return X.copy() if copy else X
     rows = _subsample_rows(m, random_state) if m > SUBSAMPLE else None
-    Xd = torch.from_numpy(np.ascontiguousarray(X)).to("cuda:%d" % device)
+    Xd = _to_device_f64(torch, X, device)
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     rc = lib.prmf_quantile_transform(int(device), C.c_void_p(Xd.data_ptr()), m, n, n,
                                      rows.ctypes.data_as(C.c_void_p) if rows is not None else None,
                                      len(rows) if rows is not None else m, int(n_quantiles), stream)
     if rc != _capi.PRMF_OK:
         raise _capi.PrmfError(rc, lib.prmf_last_error(None).decode())
+    if on_device:
+        return Xd
     out = Xd.cpu().numpy()
-    if not copy:
+    if not copy and X.dtype == np.float64:
         X[...] = out
         return X
     return out

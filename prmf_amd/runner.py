@@ -479,7 +479,14 @@ def _run(args, rank, world, local_ranks=0):
             X, X_test, samples = hold_out(X, samples, args.cross_validation)
         if not args.no_normalize:                              # :1019-1020, on the GPU (prmf_quantile_transform)
             from .preprocess import quantile_transform
-            X = quantile_transform(X)
+            # one process, one GPU, nothing else that reads X on the host (--manifolds-init does): the normalised matrix
+            # stays on the device and nmf_pathway takes it from there
+            stay = world == 1 and not local_ranks and args.manifolds_init is None
+            if stay:
+                import torch
+                X = quantile_transform(X, device=torch.cuda.current_device(), on_device=True)
+            else:
+                X = quantile_transform(X)
     U_init = V_init = None
     if args.manifolds_init is not None:
         U_init, V_init = initial_factors(args, X, manifolds, nodelist, write=rank == 0)

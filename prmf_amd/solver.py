@@ -101,6 +101,12 @@ class PrmfEngine(object):
         (50000 x 20000 f32 -> bf16: 0.45 s, f64 -> f32: 0.91 s; chunked: 0.07 s = 54 GB/s, profiles/r03_outer_solver.txt)."""
         torch = self.torch
         dev = "cuda:%d" % self.device
+        if isinstance(a, torch.Tensor) and a.is_cuda and a.ndim == 2 and a.numel() * a.element_size() > (32 << 20) and dtype not in (None, a.dtype):
+            out = torch.empty(a.shape, dtype=dtype, device=dev)          # a device matrix: narrowed in row chunks, no whole-size temporary
+            rows = max(1, (160 << 20) // max(1, a.shape[1] * a.element_size()))
+            for r0 in range(0, a.shape[0], rows):
+                out[r0:r0 + rows] = a[r0:r0 + rows].to(device=dev)
+            return out
         if isinstance(a, np.ndarray) and a.ndim == 2 and a.nbytes > (32 << 20) and a.dtype in (np.float32, np.float64):
             a = np.ascontiguousarray(a)
             out = torch.empty(a.shape, dtype=dtype or torch.from_numpy(a[:0]).dtype, device=dev)
@@ -580,7 +586,10 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
     from .ranks import as_ranks
     ranks = as_ranks(group)
     say = print if ranks.rank == 0 else (lambda *a, **kw: None)
-    X = np.asarray(X) if not hasattr(X, "rows") else X        # RowSource (rank-local input): .shape, .rows(lo, hi)
+    # X: the reference's ndarray; a RowSource (rank-local input: .shape, .rows(lo, hi)); or a 2-D tensor already on the GPU
+    # (prmf_amd.preprocess.quantile_transform(on_device=True): the normalised matrix never visits the host)
+    on_gpu = hasattr(X, "is_cuda") and X.is_cuda
+    X = X if (hasattr(X, "rows") or on_gpu) else np.asarray(X)
     m, n = X.shape
     lo, hi = 0, m
     if ranks.multi:

@@ -60,3 +60,42 @@ def test_row_subsample_matches_sklearn():
     np.random.seed(11)
     quantile_transform(X)
     assert np.random.rand() == a
+
+
+def test_result_left_on_the_device_and_narrow_inputs():
+    """on_device=True returns the same float64 values as a tensor on the GPU; a float32 / integer host matrix is widened on
+    the device (uploaded in its own dtype, in row chunks once it is large) to the same float64 values numpy would give."""
+    import torch
+    from prmf_amd.preprocess import quantile_transform
+    rs = np.random.RandomState(2)
+    X32 = (rs.gamma(2.0, size=(3000, 3100)) * 50).astype(np.float32)          # 37 MB: crosses the chunked-upload threshold
+    want = quantile_transform(X32.astype(np.float64))
+    got = quantile_transform(X32)
+    assert got.dtype == np.float64 and np.array_equal(got, want)
+    dev = quantile_transform(X32, on_device=True)
+    assert isinstance(dev, torch.Tensor) and dev.is_cuda and dev.dtype == torch.float64 and np.array_equal(dev.cpu().numpy(), want)
+    counts = rs.randint(0, 1000, size=(400, 30))
+    assert np.array_equal(quantile_transform(counts), sk(counts.astype(np.float64)))
+    assert np.array_equal(quantile_transform(counts.astype(np.int16)), sk(counts.astype(np.float64)))
+
+
+def test_solver_takes_the_normalised_matrix_from_the_device():
+    """nmf_pathway(X) with X a float64 tensor on the GPU (what the command line hands over after the normalisation) gives, bit
+    for bit, what it gives for the same values as a host array -- both storages of X."""
+    import synth
+    from prmf_amd import PathwayLibrary
+    from prmf_amd.preprocess import quantile_transform
+    from prmf_amd.solver import nmf_pathway
+    rs = np.random.RandomState(9)
+    m, n, k = 90, 700, 5
+    raw = rs.gamma(2.0, size=(m, n)) * 10
+    lib = PathwayLibrary.from_edge_lists(n, synth.tree_pathways(n, 8, 40, 3))
+    host = quantile_transform(raw)
+    dev = quantile_transform(raw, on_device=True)
+    for xd in ("f32", "bf16"):
+        out = []
+        for X in (host, dev):
+            np.random.seed(4)
+            out.append(nmf_pathway(X, None, library=lib, k_latent=k, max_iter=40, x_dtype=xd))
+        (U0, V0, o0), (U1, V1, o1) = out
+        assert np.array_equal(U0, U1) and np.array_equal(V0, V1) and o0["obj"] == o1["obj"]
