@@ -6,6 +6,7 @@ import cProfile
 import io
 import os
 import pstats
+import shlex
 import sys
 import tempfile
 import time
@@ -51,7 +52,7 @@ import torch  # noqa: E402
 torch.cuda.init()
 print("imports (prmf_amd, torch, device init): %.2f s" % (time.perf_counter() - t_imp), flush=True)
 argv = ["--data", data_fp, "--manifolds"] + fps + ["--outdir", os.path.join(d, "out"), "-k", str(k), "--seed", "1"] + \
-    (["--nodelist", os.path.join(d, "nodelist.txt")] if as_npy else []) + os.environ.get("EXTRA", "").split()
+    (["--nodelist", os.path.join(d, "nodelist.txt")] if as_npy else []) + shlex.split(os.environ.get("EXTRA", ""))
 os.makedirs(os.path.join(d, "out"), exist_ok=True)
 # wall clock of the stages (no profiler in the way): wrappers around the runner's own stage functions
 stage = {}
