@@ -931,7 +931,16 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
   // one workgroup per resident slot (a multiple of 8: one share per XCD), but at least 8 chunks each
   int64_t G = (int64_t)n_cus * (p.nw == SWEEP_NW_WIDE ? 1 : SWEEP_WGS_PER_CU);
   const int64_t total_units = (int64_t)p.panels * p.ngroups;
-  if (G > total_units * UNIT / 8) G = total_units * UNIT / 8;
+  // A matrix too small to give every slot work: down to 4 chunks per workgroup while that still fills one workgroup per CU,
+  // down to 2 below that (but then at most one workgroup per CU).  Round 5 (profiles/r05_small_matrix_grid.txt; the rule was
+  // "at least 8 chunks each"): 500 x 20000 f32 k = 6 -- the reference's typical size -- iteration 78.6 -> 73.7 us (X V 23.3 ->
+  // 18.9 us on 256 instead of 156 workgroups); 100 x 2000 k = 30 / 128: 92 -> 53 / 197 -> 91 us; no shape of the scan slower.
+  // A short sweep is bounded by loads in flight (workgroups x 32 KiB), not by bytes.
+  {
+    const int64_t chunks = total_units * UNIT;
+    const int64_t cap = chunks / 4 >= n_cus ? chunks / 4 : (chunks / 2 < n_cus ? chunks / 2 : (int64_t)n_cus);
+    if (G > cap) G = cap;
+  }
   G = G / 8 * 8;
   p.nx = 1;
   if (G >= 8 && p.ngroups * UNIT >= 16) {

@@ -134,9 +134,12 @@ def test_sweep_plans_of_the_benchmark_shapes():
         assert (p["waves"], p["tiles_per_wave"], p["panel_rows"], p["slices"], p["double_buffered"]) == (4, 1, 128, 1, 1)
     # the N = 8 share of C3 (6250 x 20000): X V's 5.1 MB factor takes two slices there, X^T U (1.6 MB) none
     assert plan(BF16, 6250, 20000, 64)["slices"] == 2 and plan(BF16, 20000, 6250, 64)["slices"] == 1
-    # a tiny matrix launches few workgroups (at least 8 chunks each) and never more slabs than the 64-bit mask holds
+    # a tiny matrix launches few workgroups (round 5: at least 2 chunks each and then at most one per CU; at least 4 where that
+    # still fills one per CU) and never more slabs than the 64-bit mask holds
     tiny = plan(F32, 100, 2000, 6)
-    assert tiny["grid"] <= 16 and tiny["max_slabs"] <= 64
+    assert tiny["grid"] == 32 and tiny["max_slabs"] <= 64
+    assert plan(F32, 2000, 2000, 6)["grid"] == 256 and plan(F32, 500, 2000, 6)["grid"] == 128
+    assert plan(F32, 500, 20000, 6)["grid"] == 256 and plan(F32, 20000, 500, 6)["grid"] == 512      # the reference's typical size
     # bad arguments
     out = (C.c_int * 8)()
     assert lib.prmf_debug_plan_sweep(BF16, 10, 0, 4, 256, out) == _capi.PRMF_ERR_ARG
