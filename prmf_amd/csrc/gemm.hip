@@ -1010,9 +1010,10 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
       p.max_seg = p.nx * p.pmax;
       break;
     }
-    // too many segments per panel for the 64-bit mask: drop the slices, then workgroups
+    // too many segments per panel for the 64-bit mask: drop the slices, then workgroups -- eight at a time (round 5; it was
+    // "halve": a two-panel X V got 64 workgroups where 120 fit, profiles/r05_small_matrix_grid.txt)
     if (p.nx > 1) p.nx = 1;
-    else G = G > 16 ? G / 2 : 1;
+    else G = G > 16 ? G - 8 : 1;
   }
   // Slabs leave as non-temporal full-line stores (see the sweep's epilogue) -- except when a launch writes only a few
   // MB of them (5000 x 10000, k = 16: 9 MB): plain stores are then 2% faster on the iteration; from 34 MB up (k = 64 at
