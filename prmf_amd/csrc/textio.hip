@@ -128,11 +128,12 @@ text_parse_kernel(const unsigned char* __restrict__ text, const int64_t* __restr
     name_spans[2 * row + 1] = end;
     return;
   }
-  const ParsedField r = parse_decimal(text + start, text + end);
+  // no number is 4 KiB long: such a field (a file with the wrong delimiter is ONE field per line) is refused unread
+  const ParsedField r = end - start <= 4096 ? parse_decimal(text + start, text + end) : ParsedField{0.0, false, false, false};
   if (!r.ok || r.wide_int) {
     int why = r.ok ? TEXT_FLAG_WIDE_INT : TEXT_FLAG_NOT_NUMERIC;
-    if (!r.ok)
-      for (int64_t p = start; p < end; ++p)
+    if (!r.ok)                                           // (a look at its first 4 KiB: a refused field can be a whole malformed file)
+      for (int64_t p = start; p < end && p < start + 4096; ++p)
         if (text[p] == '"') why = TEXT_FLAG_QUOTED;
     atomicOr(flags, why);
     atomicMin(first_bad, (unsigned long long)start);

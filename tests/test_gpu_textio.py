@@ -143,6 +143,7 @@ NOT_PLAIN = {
     "thousands": 'a,b,c\n1,"2,000",3\n4,5,6\n',
     "header only": "a,b,c\n",
     "one line without end": "1,2,3",
+    "a field of 5000 digits": "a,b,c\n1,%s,3\n4,5,6\n" % ("7" * 5000),
 }
 
 
