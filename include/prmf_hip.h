@@ -278,6 +278,14 @@ int prmf_score_candidates(prmf_ctx* ctx, const float* dV, double* scores_out, vo
 int prmf_cv_error(prmf_ctx* ctx, const float* dV, double* err_out, void* stream);
 
 /*
+ * *out = sum of squares of a device matrix (m x n, leading dimension ld, x_dtype PRMF_X_F32 or PRMF_X_BF16) in float64:
+ * ||X||_F^2 of the values the sweeps will read, what `norm_X = np.linalg.norm(X)` (script/prmf_runner.py:640) squares to
+ * and what prmf_set_x takes as norm_x_sq (a rank of a multi-GPU run passes its rows and adds the ranks' results).
+ * Deterministic (fixed summation tree).  No context needed; synchronises `stream`.
+ */
+int prmf_sum_squares(int device, const void* dX, int x_dtype, int64_t m, int64_t n, int64_t ld, double* out, void* stream);
+
+/*
  * Per-gene quantile normalisation, replaces `X = quantile_transform(X)` (script/prmf_runner.py:1019-1020;
  * sklearn.preprocessing.quantile_transform with its defaults: n_quantiles = 1000, uniform output, axis 0).
  * dX: m x n float64 row-major device buffer (leading dimension ld >= n), transformed IN PLACE.  The quantiles of

@@ -1346,6 +1346,27 @@ int prmf_debug_recon_terms(prmf_ctx* c, int it, double* cross, double* gu, doubl
   return PRMF_OK;
 }
 
+int prmf_sum_squares(int device, const void* dX, int x_dtype, int64_t m, int64_t n, int64_t ld, double* out, void* stream) {
+  if (!out || m < 0 || n < 0 || ld < n || (m > 0 && n > 0 && !dX) || (x_dtype != PRMF_X_F32 && x_dtype != PRMF_X_BF16))
+    return fail(nullptr, PRMF_ERR_ARG, "prmf_sum_squares: bad arguments");
+  *out = 0.0;
+  if (m == 0 || n == 0) return PRMF_OK;
+  if (hipSetDevice(device) != hipSuccess) return fail(nullptr, PRMF_ERR_HIP, "hipSetDevice(%d) failed", device);
+  hipStream_t s = (hipStream_t)stream;
+  double* partial = nullptr;
+  std::vector<double> host((size_t)SUM_SQUARES_BLOCKS);
+  hipError_t e = hipMalloc((void**)&partial, host.size() * sizeof(double));
+  if (e == hipSuccess) e = launch_sum_squares(x_dtype, dX, ld, m, n, partial, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(host.data(), partial, host.size() * sizeof(double), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(partial);
+  if (e != hipSuccess) return fail(nullptr, PRMF_ERR_HIP, "prmf_sum_squares: %s", hipGetErrorString(e));
+  double total = 0.0;
+  for (double v : host) total += v;          // index order: the same bits on every run
+  *out = total;
+  return PRMF_OK;
+}
+
 int prmf_quantile_transform(int device, double* dX, int64_t m, int64_t n, int64_t ld, const int64_t* fit_rows,
                             int64_t n_fit, int n_quantiles, void* stream) {
   if (m < 0 || n < 0 || (m > 0 && n > 0 && !dX) || ld < n || n_quantiles < 1)

@@ -1173,6 +1173,46 @@ hipError_t launch_stream_read(const void* p, size_t bytes, int n_cus, void* sink
 }
 
 // ---------------------------------------------------------------------------
+// ||X||_F^2 of the stored matrix in float64 (np.linalg.norm(X) at prmf_runner.py:640, before the root): every value widened,
+// squared and summed in double -- per lane over its columns, per workgroup in a fixed tree, the workgroups' partials added in
+// index order by the caller: the same bits on every run.  (It was a chain of torch ops on the host side -- .double() ** 2 .sum()
+// per row chunk --, 8 ms at 50000 x 20000 and 0.13 s for the first call of a process, which loads torch's pow kernel.)
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ double widen(T v);
+template <>
+__device__ __forceinline__ double widen<float>(float v) { return (double)v; }
+template <>
+__device__ __forceinline__ double widen<uint16_t>(uint16_t v) { return (double)__uint_as_float((uint32_t)v << 16); }      // bf16
+
+template <typename T>
+__global__ void __launch_bounds__(256) sum_squares_kernel(const T* __restrict__ X, int64_t ld, int64_t rows, int64_t cols,
+                                                          double* __restrict__ partial) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    const T* row = X + r * ld;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) {
+      const double v = widen<T>(row[c]);
+      acc += v * v;
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+hipError_t launch_sum_squares(int x_dtype, const void* X, int64_t ld, int64_t rows, int64_t cols, double* partial, hipStream_t s) {
+  if (x_dtype == 0) sum_squares_kernel<float><<<SUM_SQUARES_BLOCKS, 256, 0, s>>>((const float*)X, ld, rows, cols, partial);
+  else sum_squares_kernel<uint16_t><<<SUM_SQUARES_BLOCKS, 256, 0, s>>>((const uint16_t*)X, ld, rows, cols, partial);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // one-time layout kernels (prmf_set_x): padded copy and padded transpose
 // ---------------------------------------------------------------------------
 template <typename T>

@@ -147,6 +147,9 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
                        bool split = false /* f32 X as three bf16 pieces, packedB in the bf16 hi/lo layout */,
                        const SweepPrologue* prologue = nullptr /* runs inside the sweep when its jobs fit the grid, else as a launch of its own */,
                        bool attr_only = false /* launch nothing: raise the kernel's dynamic-LDS limit on the current device (prmf_create) */);
+//   partial[SUM_SQUARES_BLOCKS] (device): per-workgroup sums of squares of a rows x cols f32 (x_dtype 0) / bf16 (1) matrix, float64
+constexpr int SUM_SQUARES_BLOCKS = 1024;
+hipError_t launch_sum_squares(int x_dtype, const void* X, int64_t ld, int64_t rows, int64_t cols, double* partial, hipStream_t s);
 hipError_t launch_stream_read(const void* p, size_t bytes, int n_cus, void* sink /* >= 2 n_cus ints, never written */, hipStream_t s);
 // Pathway terms of the V update as extra workgroups of the U epilogue launch (they depend on the OLD V and gamma / delta
 // only; the epilogue leaves a quarter of the chip's slots idle and runs longer than the terms' dependent-load chain, so

@@ -137,12 +137,15 @@ class PrmfEngine(object):
         return self.norm_x_sq
 
     def local_norm_sq(self, Xd):
-        """sum of squares of the rounded local X in float64 (chunked)."""
-        total = 0.0
-        rows = max(1, (1 << 24) // max(1, Xd.shape[1]))
-        for r0 in range(0, Xd.shape[0], rows):
-            total += float((Xd[r0:r0 + rows].double() ** 2).sum().item())
-        return total
+        """sum of squares of the rounded local X (a contiguous device tensor in the engine's dtype) in float64
+        (`prmf_sum_squares`: one kernel, fixed summation order)."""
+        torch = self.torch
+        if not (isinstance(Xd, torch.Tensor) and Xd.is_cuda and Xd.dtype == self.torch_x_dtype and Xd.ndim == 2 and Xd.is_contiguous()):
+            raise ValueError("local_norm_sq takes a contiguous 2-D device tensor of the engine's x dtype")
+        out = C.c_double()
+        self._check(self.lib.prmf_sum_squares(self.device, C.c_void_p(Xd.data_ptr()), self.x_dtype, Xd.shape[0], Xd.shape[1], Xd.shape[1],
+                                              C.byref(out), self._stream()))
+        return out.value
 
     def set_library(self, library):
         if library.n != self.n:
@@ -565,6 +568,19 @@ def force_distinct_lapls(V, library, latent_to_pathway_data, k_to_lapl, gamma, d
     return latent_to_pathway_data
 
 
+def multinomial_one(p):
+    """`scipy.stats.multinomial.rvs(1, p)` (the draw at prmf_runner.py:723) on the legacy global stream WITHOUT importing
+    scipy.stats, which costs 0.26 s of a command-line run that takes 0.9 s.  What scipy (1.15: `_process_parameters`, then
+    `random_state.multinomial`) does with it: the last probability becomes 1 - sum(p[:-1]) unless that differs from 1 by no
+    more than 1e-15, and numpy's legacy global RandomState draws -- the same two steps here, so the same stream positions and
+    the same one-hot vector (tests/test_host_logic_cpu.py::test_multinomial_draw_equals_scipy compares them draw by draw)."""
+    p = np.array(p, dtype=np.float64, copy=True)
+    adjusted = 1.0 - p[:-1].sum(axis=-1)
+    if np.abs(adjusted) > 1e-15:
+        p[-1] = adjusted
+    return np.random.mtrand._rand.multinomial(1, p)
+
+
 def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3, max_iter=1000, nodelist=None,
                 modulus=10, U_init=None, V_init=None, verbose=False, x_dtype="f32", library=None, round_log=None,
                 trace=None, group=None, dist_mode=None):
@@ -582,7 +598,6 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
     U on its GPU, V is replicated, each iteration exchanges the k x k Gram U^T U and the n x k product X^T U over RCCL
     (prmf_amd.distributed; dist_mode "colshard" (default) or "replicated").  Rank 0's RNG stream is the solve's: its
     draws are broadcast.  Every rank returns the same (U, V, obj_data) -- U gathered to all m rows; only rank 0 prints."""
-    from scipy.stats import multinomial
     from .ranks import as_ranks
     ranks = as_ranks(group)
     say = print if ranks.rank == 0 else (lambda *a, **kw: None)
@@ -648,7 +663,7 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
                 for k in range(k_latent):                          # :717-729
                     inds = [x[0] for x in l2p[k]]
                     scores = np.array([x[1] for x in l2p[k]])
-                    sample = multinomial.rvs(1, scores / np.sum(scores))
+                    sample = multinomial_one(scores / np.sum(scores))
                     k_to_lapl[k] = inds[np.where(sample != 0)[0][0]]
             k_to_lapl = ranks.from_rank0(k_to_lapl)
             if round_log is not None:

@@ -310,3 +310,32 @@ def test_independent_contexts_on_concurrent_threads():
         assert not isinstance(alone[i], BaseException), alone[i]
         assert not isinstance(together.get(i), BaseException) and together.get(i) is not None, together.get(i)
         assert np.array_equal(alone[i][0], together[i][0]) and np.array_equal(alone[i][1], together[i][1]) and alone[i][2] == together[i][2], i
+
+
+def test_sum_squares_kernel_vs_float64():
+    """prmf_sum_squares (||X||_F^2 of the stored values, prmf_runner.py:640) against numpy in float64: both storages, a leading
+    dimension wider than the row, one row, no rows, 3 x 10^7 values; the same bits on a second call."""
+    import ctypes as C
+    import torch
+    from prmf_amd import _capi
+    lib = _capi.load()
+    rs = np.random.RandomState(6)
+
+    def ss(t, m, n, ld, xd):
+        out = C.c_double(-1.0)
+        rc = lib.prmf_sum_squares(0, C.c_void_p(t.data_ptr()), xd, m, n, ld, C.byref(out), None)
+        assert rc == _capi.PRMF_OK, lib.prmf_last_error(None)
+        return out.value
+
+    for m, n, ld in ((1, 1, 1), (1, 5000, 5000), (257, 33, 40), (3000, 10000, 10000), (0, 7, 7)):
+        a = (rs.gamma(2.0, size=(m, ld)) * 3).astype(np.float32)
+        for xd, tdt in ((_capi.PRMF_X_F32, torch.float32), (_capi.PRMF_X_BF16, torch.bfloat16)):
+            t = torch.from_numpy(a).to("cuda:0").to(tdt).contiguous()
+            want = float((t[:, :n].double().cpu().numpy() ** 2).sum())
+            got = ss(t, m, n, ld, xd)
+            assert got == ss(t, m, n, ld, xd)
+            assert abs(got - want) <= 1e-13 * max(want, 1.0), (m, n, ld, xd, got, want)
+    out = C.c_double()
+    assert lib.prmf_sum_squares(0, None, _capi.PRMF_X_F32, 3, 3, 3, C.byref(out), None) == _capi.PRMF_ERR_ARG
+    assert lib.prmf_sum_squares(0, None, 7, 0, 0, 0, C.byref(out), None) == _capi.PRMF_ERR_ARG
+    assert lib.prmf_sum_squares(0, None, _capi.PRMF_X_F32, 2, 5, 4, C.byref(out), None) == _capi.PRMF_ERR_ARG

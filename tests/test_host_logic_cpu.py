@@ -301,3 +301,31 @@ def test_fast_graphml_equals_networkx(tmp_path):
         with pytest.raises(Exception) as theirs:
             slow(fp)
         assert type(mine.value) is type(theirs.value) and str(mine.value) == str(theirs.value)
+
+
+def test_multinomial_draw_equals_scipy():
+    """solver.multinomial_one against scipy.stats.multinomial.rvs(1, p) -- the reference's draw (prmf_runner.py:723) -- on the
+    same legacy stream: the same one-hot vectors, draw by draw, and the same stream position afterwards; probabilities as the
+    outer loop makes them (scores / sum), with zeros, a single candidate, sums that are off by rounding."""
+    from scipy.stats import multinomial
+    from prmf_amd.solver import multinomial_one
+    rs = np.random.RandomState(3)
+    cases = []
+    for _ in range(400):
+        n = int(rs.randint(1, 40))
+        scores = rs.rand(n) * 10.0 ** rs.randint(-3, 4)
+        if rs.rand() < 0.3:
+            scores[rs.randint(n)] = 0.0
+        if scores.sum() == 0:
+            scores[0] = 1.0
+        cases.append(scores / np.sum(scores))
+    cases += [np.array([1.0]), np.array([0.5, 0.5]), np.array([0.1] * 10), np.array([1 / 3.0] * 3), np.array([1.0, 0.0, 0.0]),
+              np.array([0.0, 0.0, 1.0]), np.array([0.2, 0.3, 0.5 + 1e-16]), np.array([0.25, 0.25, 0.25, 0.25 - 1e-12])]
+    np.random.seed(17)
+    want = [multinomial.rvs(1, p) for p in cases]
+    after_want = np.random.rand()
+    np.random.seed(17)
+    got = [multinomial_one(p) for p in cases]
+    after_got = np.random.rand()
+    assert all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(got, want))
+    assert after_got == after_want

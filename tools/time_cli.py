@@ -95,7 +95,7 @@ if os.environ.get("PROFILE", "1") == "0":
     import shutil  # noqa: E402
     shutil.rmtree(d, ignore_errors=True)
     sys.exit(0)
-for rep in range(2):
+for rep in range(1 if os.environ.get("FIRST") else 2):          # FIRST=1: profile the first run of the process (what a user's run is)
     out = io.StringIO()
     pr = cProfile.Profile()
     so, se = sys.stdout, sys.stderr
