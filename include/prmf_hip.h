@@ -278,6 +278,21 @@ int prmf_score_candidates(prmf_ctx* ctx, const float* dV, double* scores_out, vo
 int prmf_cv_error(prmf_ctx* ctx, const float* dV, double* err_out, void* stream);
 
 /*
+ * Non-negative least squares against the data matrix: x = argmin_{x >= 0} || A x - b ||_2 with A = X (transposed = 0:
+ * rows equations, cols unknowns) or A = X^T (transposed = 1: cols equations, rows unknowns), X a float64 row-major DEVICE
+ * matrix (rows x cols, leading dimension ld) that is neither copied nor transposed.  Replaces `scipy.optimize.nnls(X, u)`
+ * and `scipy.optimize.nnls(X.transpose(), v)` of `--manifolds-init` (script/prmf_runner.py:308-334: nmf_init_u / nmf_init_v)
+ * -- the Lawson-Hanson active-set method as there; gradient, column inner products and residual on the device, the
+ * passive-set factor on the host, one refinement step per solve.  b (equations) and x (unknowns) are HOST arrays;
+ * *rnorm_out (nullable) = || A x - b ||_2, *iterations_out (nullable) = active-set steps taken; max_iter <= 0: 3 x the
+ * number of unknowns (scipy's default); PRMF_ERR_NUMERIC when it is exceeded ("maximum number of iterations reached").
+ * Both problems have a unique minimiser for data in general position, so the result equals scipy's up to rounding
+ * (tests/test_gpu_nnls_matrix.py: 1e-9).  Synchronises `stream`; no context needed.
+ */
+int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t ld, int transposed, const double* b, double* x,
+              double* rnorm_out, int* iterations_out, int max_iter, void* stream);
+
+/*
  * *out = sum of squares of a device matrix (m x n, leading dimension ld, x_dtype PRMF_X_F32 or PRMF_X_BF16) in float64:
  * ||X||_F^2 of the values the sweeps will read, what `norm_X = np.linalg.norm(X)` (script/prmf_runner.py:640) squares to
  * and what prmf_set_x takes as norm_x_sq (a rank of a multi-GPU run passes its rows and adds the ranks' results).

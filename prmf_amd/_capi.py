@@ -73,6 +73,7 @@ SIGNATURES = {
     "prmf_score_candidates": (_i, [_vp, _vp, _vp, _vp]),
     "prmf_cv_error": (_i, [_vp, _vp, _vp, _vp]),
     "prmf_residual_sq": (_i, [_vp, _vp, _vp, C.POINTER(_d), _vp]),
+    "prmf_nnls": (_i, [_i, _vp, C.c_int64, C.c_int64, C.c_int64, _i, _vp, _vp, C.POINTER(_d), C.POINTER(_i), _i, _vp]),
     "prmf_sum_squares": (_i, [_i, _vp, _i, C.c_int64, C.c_int64, C.c_int64, C.POINTER(_d), _vp]),
     "prmf_quantile_transform": (_i, [_i, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int64, _i, _vp]),
     "prmf_text_create": (_i, [C.POINTER(_vp), _i, C.c_int64]),

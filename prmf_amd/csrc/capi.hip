@@ -1346,6 +1346,234 @@ int prmf_debug_recon_terms(prmf_ctx* c, int it, double* cross, double* gu, doubl
   return PRMF_OK;
 }
 
+// ---------------------------------------------------------------------------
+// NNLS against the data matrix (nnls_matrix.hip): Lawson-Hanson, passive-set algebra on the host
+// ---------------------------------------------------------------------------
+namespace {
+struct NnlsDev {
+  double *b = nullptr, *r = nullptr, *q = nullptr, *w = nullptr, *s = nullptr, *out = nullptr;
+  unsigned char* state = nullptr;
+  long long *P = nullptr, *arg = nullptr;
+  ~NnlsDev() {
+    (void)hipFree(b); (void)hipFree(r); (void)hipFree(q); (void)hipFree(w); (void)hipFree(s); (void)hipFree(out);
+    (void)hipFree(state); (void)hipFree(P); (void)hipFree(arg);
+  }
+};
+
+// lower Cholesky factor of the leading np x np block of G (row-major, leading dimension cap) into L; false if not positive definite
+bool chol_factor(const std::vector<double>& G, std::vector<double>& L, int np, int cap) {
+  for (int i = 0; i < np; ++i) {
+    for (int j = 0; j <= i; ++j) {
+      double v = G[(size_t)i * cap + j];
+      for (int t = 0; t < j; ++t) v -= L[(size_t)i * cap + t] * L[(size_t)j * cap + t];
+      if (i == j) {
+        if (!(v > 1e-13 * G[(size_t)i * cap + i])) return false;
+        L[(size_t)i * cap + i] = std::sqrt(v);
+      } else {
+        L[(size_t)i * cap + j] = v / L[(size_t)j * cap + j];
+      }
+    }
+  }
+  return true;
+}
+
+// row np of the factor from row np of G (the others are unchanged); false if the new column is numerically dependent
+bool chol_append_row(const std::vector<double>& G, std::vector<double>& L, int np, int cap) {
+  const int i = np;
+  double ss = 0.0;
+  for (int j = 0; j < i; ++j) {
+    double v = G[(size_t)i * cap + j];
+    for (int t = 0; t < j; ++t) v -= L[(size_t)i * cap + t] * L[(size_t)j * cap + t];
+    v /= L[(size_t)j * cap + j];
+    L[(size_t)i * cap + j] = v;
+    ss += v * v;
+  }
+  const double d2 = G[(size_t)i * cap + i] - ss;
+  if (!(d2 > 1e-13 * G[(size_t)i * cap + i])) return false;
+  L[(size_t)i * cap + i] = std::sqrt(d2);
+  return true;
+}
+
+void chol_solve(const std::vector<double>& L, int np, int cap, const double* rhs, double* sol) {
+  for (int i = 0; i < np; ++i) {
+    double v = rhs[i];
+    for (int t = 0; t < i; ++t) v -= L[(size_t)i * cap + t] * sol[t];
+    sol[i] = v / L[(size_t)i * cap + i];
+  }
+  for (int i = np - 1; i >= 0; --i) {
+    double v = sol[i];
+    for (int t = i + 1; t < np; ++t) v -= L[(size_t)t * cap + i] * sol[t];
+    sol[i] = v / L[(size_t)i * cap + i];
+  }
+}
+}  // namespace
+
+int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t ld, int transposed, const double* b, double* x,
+              double* rnorm_out, int* iterations_out, int max_iter, void* stream) {
+  if (rows < 1 || cols < 1 || ld < cols || !dX || !b || !x) return fail(nullptr, PRMF_ERR_ARG, "prmf_nnls: bad arguments");
+  transposed = transposed ? 1 : 0;
+  const int64_t nvec = transposed ? rows : cols, len = transposed ? cols : rows;
+  const int64_t st_t = transposed ? 1 : ld, st_j = transposed ? ld : 1;
+  if (nvec > ((int64_t)1 << 30) || len > ((int64_t)1 << 30)) return fail(nullptr, PRMF_ERR_UNSUPPORTED, "prmf_nnls: more than 2^30 unknowns or equations");
+  const int cap = (int)((nvec < len ? nvec : len) + 1);          // a passive set holds linearly independent columns
+  if ((double)cap * cap * 16.0 > 8e9) return fail(nullptr, PRMF_ERR_UNSUPPORTED, "prmf_nnls: min(unknowns, equations) = %d is beyond the host-side factor", cap - 1);
+  if (max_iter <= 0) max_iter = (int)(3 * nvec < 2000000000 ? 3 * nvec : 2000000000);      // scipy's default
+  if (hipSetDevice(device) != hipSuccess) return fail(nullptr, PRMF_ERR_HIP, "hipSetDevice(%d) failed", device);
+  hipStream_t s = (hipStream_t)stream;
+  for (int64_t j = 0; j < nvec; ++j) x[j] = 0.0;
+  if (iterations_out) *iterations_out = 0;
+  NnlsDev d;
+#define NN_TRY(expr)                                                                                       \
+  do {                                                                                                     \
+    hipError_t _e = (expr);                                                                                \
+    if (_e != hipSuccess) return fail(nullptr, PRMF_ERR_HIP, "prmf_nnls: %s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+  NN_TRY(hipMalloc((void**)&d.b, (size_t)len * 8));
+  NN_TRY(hipMalloc((void**)&d.r, (size_t)len * 8));
+  NN_TRY(hipMalloc((void**)&d.q, (size_t)len * 8));
+  NN_TRY(hipMalloc((void**)&d.w, (size_t)nvec * 8));
+  NN_TRY(hipMalloc((void**)&d.state, (size_t)nvec));
+  NN_TRY(hipMalloc((void**)&d.s, (size_t)cap * 8));
+  NN_TRY(hipMalloc((void**)&d.out, (size_t)cap * 8));
+  NN_TRY(hipMalloc((void**)&d.P, (size_t)cap * 8));
+  NN_TRY(hipMalloc((void**)&d.arg, 16));
+  NN_TRY(hipMemcpyAsync(d.b, b, (size_t)len * 8, hipMemcpyHostToDevice, s));
+  NN_TRY(hipMemcpyAsync(d.r, b, (size_t)len * 8, hipMemcpyHostToDevice, s));          // x = 0: r = b
+  NN_TRY(hipMemsetAsync(d.state, 0, (size_t)nvec, s));
+  std::vector<double> G((size_t)cap * cap, 0.0), L((size_t)cap * cap, 0.0);
+  std::vector<double> c((size_t)cap), sv((size_t)cap), xs((size_t)cap, 0.0), tmp((size_t)cap), corr((size_t)cap);
+  std::vector<long long> P;                 // passive list, in order of entry
+  std::vector<long long> rejected;          // refused in this round (state 2)
+  int np = 0, iters = 0;
+  double tol = -1.0;
+
+  // s = argmin || A_P s - b || on the current list: Cholesky solve + one refinement step with the residual from A itself
+  auto solve_passive = [&]() -> int {
+    chol_solve(L, np, cap, c.data(), sv.data());
+    NN_TRY(hipMemcpyAsync(d.s, sv.data(), (size_t)np * 8, hipMemcpyHostToDevice, s));
+    NN_TRY(nnlsm_residual(dX, st_t, st_j, len, d.P, np, d.s, d.b, d.q, s));
+    NN_TRY(nnlsm_dots(dX, st_t, st_j, len, d.P, np, d.q, d.out, s));
+    NN_TRY(hipMemcpyAsync(tmp.data(), d.out, (size_t)np * 8, hipMemcpyDeviceToHost, s));
+    NN_TRY(hipStreamSynchronize(s));
+    chol_solve(L, np, cap, tmp.data(), corr.data());
+    for (int a = 0; a < np; ++a) sv[(size_t)a] += corr[(size_t)a];
+    return PRMF_OK;
+  };
+  auto upload_list = [&]() -> int {
+    if (np) NN_TRY(hipMemcpyAsync(d.P, P.data(), (size_t)np * 8, hipMemcpyHostToDevice, s));
+    return PRMF_OK;
+  };
+  auto set_state = [&](long long j, unsigned char v) -> int {
+    NN_TRY(hipMemcpyAsync(d.state + j, &v, 1, hipMemcpyHostToDevice, s));
+    NN_TRY(hipStreamSynchronize(s));          // v is a stack byte
+    return PRMF_OK;
+  };
+  int rc;
+  bool need_gradient = true;
+  for (;;) {
+    if (need_gradient) {
+      NN_TRY(nnlsm_gradient(dX, ld, rows, cols, transposed != 0, d.r, d.w, s));
+      need_gradient = false;
+    }
+    NN_TRY(nnlsm_argmax(d.w, d.state, nvec, d.arg, s));
+    long long arg[2];
+    NN_TRY(hipMemcpyAsync(arg, d.arg, 16, hipMemcpyDeviceToHost, s));
+    NN_TRY(hipStreamSynchronize(s));
+    double wj;
+    std::memcpy(&wj, &arg[1], 8);
+    const long long j = arg[0];
+    if (tol < 0.0) tol = 1e-12 * (j >= 0 && wj > 0.0 ? wj : 0.0);       // relative to the largest component of A^T b
+    if (j < 0 || !(wj > tol) || np >= cap - 1) break;
+    if (++iters > max_iter) return fail(nullptr, PRMF_ERR_NUMERIC, "prmf_nnls: maximum number of iterations reached");
+    // column j joins the list: its inner products with the list (one row of A_P^T A_P) and with b
+    NN_TRY(nnlsm_column(dX, st_t, st_j, len, j, d.q, s));
+    P.push_back(j);
+    ++np;
+    if ((rc = upload_list())) return rc;
+    NN_TRY(nnlsm_dots(dX, st_t, st_j, len, d.P, np, d.q, d.out, s));
+    NN_TRY(hipMemcpyAsync(tmp.data(), d.out, (size_t)np * 8, hipMemcpyDeviceToHost, s));
+    NN_TRY(nnlsm_dots(dX, st_t, st_j, len, d.P + (np - 1), 1, d.b, d.out + cap - 1, s));
+    NN_TRY(hipMemcpyAsync(&c[(size_t)np - 1], d.out + cap - 1, 8, hipMemcpyDeviceToHost, s));
+    NN_TRY(hipStreamSynchronize(s));
+    for (int a = 0; a < np; ++a) {
+      G[(size_t)(np - 1) * cap + a] = tmp[(size_t)a];
+      G[(size_t)a * cap + (np - 1)] = tmp[(size_t)a];
+    }
+    bool ok = chol_append_row(G, L, np - 1, cap);
+    if (ok) {
+      xs[(size_t)np - 1] = 0.0;
+      if ((rc = solve_passive())) return rc;
+      ok = sv[(size_t)np - 1] > 0.0;                  // Lawson-Hanson: the entering unknown must come out positive
+    }
+    if (!ok) {                                        // refuse it for this round and look at the next largest gradient
+      P.pop_back();
+      --np;
+      rejected.push_back(j);
+      if ((rc = set_state(j, 2))) return rc;
+      if ((rc = upload_list())) return rc;
+      continue;
+    }
+    if ((rc = set_state(j, 1))) return rc;
+    // feasibility: walk from the current point towards the unconstrained solution until the first unknown reaches zero
+    for (;;) {
+      int worst = -1;
+      double alpha = 2.0;
+      for (int a = 0; a < np; ++a)
+        if (sv[(size_t)a] <= 0.0) {
+          const double t = xs[(size_t)a] / (xs[(size_t)a] - sv[(size_t)a]);
+          if (t < alpha) {
+            alpha = t;
+            worst = a;
+          }
+        }
+      if (worst < 0) break;
+      if (++iters > max_iter) return fail(nullptr, PRMF_ERR_NUMERIC, "prmf_nnls: maximum number of iterations reached");
+      for (int a = 0; a < np; ++a) xs[(size_t)a] += alpha * (sv[(size_t)a] - xs[(size_t)a]);
+      xs[(size_t)worst] = 0.0;
+      // every unknown that reached zero leaves the list; the Gram block, c and the point are compacted in list order
+      // (sources lie at or after their targets in both coordinates, so the in-place copy is safe)
+      std::vector<int> keep;
+      for (int a = 0; a < np; ++a) {
+        if (xs[(size_t)a] > 0.0) keep.push_back(a);
+        else if ((rc = set_state(P[(size_t)a], 0))) return rc;
+      }
+      const int kept = (int)keep.size();
+      for (int a = 0; a < kept; ++a) {
+        for (int t = 0; t < kept; ++t) G[(size_t)a * cap + t] = G[(size_t)keep[(size_t)a] * cap + keep[(size_t)t]];
+        P[(size_t)a] = P[(size_t)keep[(size_t)a]];
+        xs[(size_t)a] = xs[(size_t)keep[(size_t)a]];
+        c[(size_t)a] = c[(size_t)keep[(size_t)a]];
+      }
+      P.resize((size_t)kept);
+      np = kept;
+      if ((rc = upload_list())) return rc;
+      if (np == 0) break;
+      if (!chol_factor(G, L, np, cap)) return fail(nullptr, PRMF_ERR_NUMERIC, "prmf_nnls: passive columns became dependent");
+      if ((rc = solve_passive())) return rc;
+    }
+    for (int a = 0; a < np; ++a) xs[(size_t)a] = sv[(size_t)a];
+    // the new point: its residual, and a fresh gradient; refusals of this round are forgotten
+    if (np) NN_TRY(hipMemcpyAsync(d.s, xs.data(), (size_t)np * 8, hipMemcpyHostToDevice, s));
+    NN_TRY(nnlsm_residual(dX, st_t, st_j, len, d.P, np, d.s, d.b, d.r, s));
+    for (long long rj : rejected)
+      if ((rc = set_state(rj, 0))) return rc;
+    rejected.clear();
+    need_gradient = true;
+  }
+  for (int a = 0; a < np; ++a) x[P[(size_t)a]] = xs[(size_t)a];
+  if (rnorm_out) {
+    std::vector<double> r((size_t)len);
+    NN_TRY(hipMemcpyAsync(r.data(), d.r, (size_t)len * 8, hipMemcpyDeviceToHost, s));
+    NN_TRY(hipStreamSynchronize(s));
+    double ss = 0.0;
+    for (double v : r) ss += v * v;
+    *rnorm_out = std::sqrt(ss);
+  }
+  if (iterations_out) *iterations_out = iters;
+#undef NN_TRY
+  return PRMF_OK;
+}
+
 int prmf_sum_squares(int device, const void* dX, int x_dtype, int64_t m, int64_t n, int64_t ld, double* out, void* stream) {
   if (!out || m < 0 || n < 0 || ld < n || (m > 0 && n > 0 && !dX) || (x_dtype != PRMF_X_F32 && x_dtype != PRMF_X_BF16))
     return fail(nullptr, PRMF_ERR_ARG, "prmf_sum_squares: bad arguments");

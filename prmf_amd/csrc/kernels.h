@@ -292,6 +292,19 @@ hipError_t quantile_transform_device(double* dX, int64_t m, int64_t n, int64_t l
                                      const double* refs, const double* qs, int nq, hipStream_t s);
 
 // ---------------------------------------------------------------------------
+// nnls_matrix.hip: the device steps of Lawson-Hanson NNLS on A = X or X^T (float64 row-major X, never copied).
+// Element t of column j of A is X[t * st_t + j * st_j]  (A = X: st_t = ld, st_j = 1;  A = X^T: st_t = 1, st_j = ld).
+// ---------------------------------------------------------------------------
+hipError_t nnlsm_gradient(const double* X, int64_t ld, int64_t rows, int64_t cols, bool transposed, const double* r, double* w,
+                          hipStream_t s);                                        // w = A^T r, all unknowns
+hipError_t nnlsm_argmax(const double* w, const unsigned char* state, int64_t n, long long* out /* index, bits of w */, hipStream_t s);
+hipError_t nnlsm_column(const double* X, int64_t st_t, int64_t st_j, int64_t len, int64_t j, double* q, hipStream_t s);
+hipError_t nnlsm_dots(const double* X, int64_t st_t, int64_t st_j, int64_t len, const long long* P, int np, const double* q,
+                      double* out, hipStream_t s);                               // out[a] = A(:, P[a]) . q
+hipError_t nnlsm_residual(const double* X, int64_t st_t, int64_t st_j, int64_t len, const long long* P, int np, const double* sv,
+                          const double* b, double* r, hipStream_t s);            // r = b - A_P s
+
+// ---------------------------------------------------------------------------
 // textio.hip: the numeric body of a delimited text matrix (pd.read_csv at script/prmf_runner.py:942)
 // ---------------------------------------------------------------------------
 constexpr int TEXT_FLAG_RAGGED = 1;        // = PRMF_TEXT_RAGGED ... (include/prmf_hip.h; checked by a static_assert in capi.hip)

@@ -96,3 +96,41 @@ def quantile_transform(X, n_quantiles=1000, random_state=None, device=0, copy=Tr
         X[...] = out
         return X
     return out
+
+
+class DeviceNnls(object):
+    """scipy.optimize.nnls(X, b) / nnls(X.T, b) for ONE data matrix and many right-hand sides, on the GPU (`prmf_nnls`,
+    prmf_amd/csrc/nnls_matrix.hip): X is uploaded once as float64 and never copied or transposed again.  The two solves per
+    latent factor of --manifolds-init (script/prmf_runner.py:308-334)."""
+
+    def __init__(self, X, device=0):
+        import torch
+        self.lib = _capi.load()
+        X = np.asarray(X)
+        if X.ndim != 2 or X.shape[0] < 1 or X.shape[1] < 1:
+            raise ValueError("X must be a non-empty 2-D matrix")
+        self.device = int(device)
+        self.shape = X.shape
+        self.Xd = _to_device_f64(torch, X, self.device).contiguous()
+        self._torch = torch
+
+    def nnls(self, b, transposed=False):
+        """-> (x, rnorm) like scipy.optimize.nnls(X.T if transposed else X, b)."""
+        m, n = self.shape
+        b = np.ascontiguousarray(np.asarray(b, dtype=np.float64).ravel())
+        unknowns, equations = (m, n) if transposed else (n, m)
+        if b.shape[0] != equations:
+            raise ValueError("Expected a 1D array of length %d for the right-hand side, got %d" % (equations, b.shape[0]))
+        if not np.all(np.isfinite(b)):
+            raise ValueError("array must not contain infs or NaNs")
+        x = np.zeros(unknowns, dtype=np.float64)
+        rnorm, iters = C.c_double(), C.c_int()
+        stream = C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self.lib.prmf_nnls(self.device, C.c_void_p(self.Xd.data_ptr()), m, n, n, 1 if transposed else 0,
+                                b.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.byref(rnorm), C.byref(iters), 0, stream)
+        if rc == _capi.PRMF_ERR_NUMERIC:
+            raise RuntimeError("Maximum number of iterations reached.")          # scipy's words
+        if rc != _capi.PRMF_OK:
+            raise _capi.PrmfError(rc, self.lib.prmf_last_error(None).decode())
+        self.last_iterations = iters.value
+        return x, rnorm.value

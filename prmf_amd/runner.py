@@ -140,18 +140,25 @@ def pathway_to_vec(X, G, nodelist, rel_weight=5):
     return v / np.linalg.norm(v), on
 
 
-def nmf_init_u(X, v):
-    """prmf_runner.py:308-317."""
-    import scipy.optimize
-    u, res = scipy.optimize.nnls(X.transpose(), v.flatten())
+def nmf_init_u(X, v, solver=None):
+    """prmf_runner.py:308-317: u = nnls(X^T, v), scaled.  solver: a prmf_amd.preprocess.DeviceNnls holding X (the GPU's
+    Lawson-Hanson); None: scipy's on the host, as the reference calls it."""
+    if solver is not None:
+        u, res = solver.nnls(v.flatten(), transposed=True)
+    else:
+        import scipy.optimize
+        u, res = scipy.optimize.nnls(X.transpose(), v.flatten())
     u = u / np.linalg.norm(u) ** 2
     return u.reshape((X.shape[0], 1)), res
 
 
-def nmf_init_v(X, u):
-    """prmf_runner.py:319-334."""
-    import scipy.optimize
-    v, res = scipy.optimize.nnls(X, u.flatten())
+def nmf_init_v(X, u, solver=None):
+    """prmf_runner.py:319-334: v = nnls(X, u), scaled."""
+    if solver is not None:
+        v, res = solver.nnls(u.flatten(), transposed=False)
+    else:
+        import scipy.optimize
+        v, res = scipy.optimize.nnls(X, u.flatten())
     v = v / np.linalg.norm(v) ** 2
     return v.reshape(X.shape[1], 1), res
 
@@ -325,11 +332,15 @@ def initial_factors(args, X, manifolds, nodelist, write=True):
     elif len(chosen) > args.k_latent:
         chosen = [chosen[i] for i in np.random.choice(len(chosen), args.k_latent)]
     us, vs = [], []
+    # the 2 k NNLS solves against X run on the GPU (prmf_nnls): 14.4 s -> 0.3 s at 500 x 20000, k = 6
+    import torch
+    from .preprocess import DeviceNnls
+    solver = DeviceNnls(X, device=torch.cuda.current_device())
     for fp in chosen:
         v, on = pathway_to_vec(X, manifolds.by_path[fp], nodelist)
         signal = v[on]
-        u, _res = nmf_init_u(X, v)
-        v_new, _res = nmf_init_v(X, u)
+        u, _res = nmf_init_u(X, v, solver)
+        v_new, _res = nmf_init_v(X, u, solver)
         v_new[on] = signal
         us.append(u)
         vs.append(v_new)

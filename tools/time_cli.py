@@ -52,7 +52,8 @@ import torch  # noqa: E402
 torch.cuda.init()
 print("imports (prmf_amd, torch, device init): %.2f s" % (time.perf_counter() - t_imp), flush=True)
 argv = ["--data", data_fp, "--manifolds"] + fps + ["--outdir", os.path.join(d, "out"), "-k", str(k), "--seed", "1"] + \
-    (["--nodelist", os.path.join(d, "nodelist.txt")] if as_npy else []) + shlex.split(os.environ.get("EXTRA", ""))
+    (["--nodelist", os.path.join(d, "nodelist.txt")] if as_npy else []) + shlex.split(os.environ.get("EXTRA", "")) + \
+    (["--manifolds-init"] + fps[:k] if os.environ.get("INIT") else [])          # INIT=1: one initial pathway per latent factor
 os.makedirs(os.path.join(d, "out"), exist_ok=True)
 # wall clock of the stages (no profiler in the way): wrappers around the runner's own stage functions
 stage = {}
@@ -79,8 +80,9 @@ _wrap(runner.ManifoldSet, "coverage", "coverage")
 _wrap(_pp, "quantile_transform", "quantile normalisation")
 _wrap(_sv, "nmf_pathway", "nmf_pathway")
 _wrap(runner, "write_outputs", "outputs")
+_wrap(runner, "initial_factors", "--manifolds-init")
 if os.environ.get("PROFILE", "1") == "0":
-    for rep in range(3):
+    for rep in range(int(os.environ.get("REPS", 3))):
         stage.clear()
         so, se = sys.stdout, sys.stderr
         sys.stdout, sys.stderr = io.StringIO(), io.StringIO()
