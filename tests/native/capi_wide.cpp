@@ -1,7 +1,7 @@
 // The rest of the C-ABI from plain C++ (tests/test_gpu_native.py): several contexts of different plans
 // (f32 / bf16 X, k = 6 .. 128, 4- and 8-wave sweeps, sliced reductions, ragged sizes), prmf_step with and without the
 // tradeoff feedback and in the eager / direct-residual forms, the phase calls, candidate scores, held-out error, direct
-// residual, timing, introspection, the quantile transform, the text reader, invalidation, error paths on a live context.  Values are only
+// residual, timing, introspection, the quantile transform, the text reader and writer, the matrix NNLS, invalidation, error paths on a live context.  Values are only
 // checked for being finite and sane -- the parity tests own the numbers; what this run is for is every entry point and
 // every host-side buffer the library sizes from a plan, from a caller that is not Python.
 #include <hip/hip_runtime.h>
@@ -217,6 +217,68 @@ int main() {
     CK(prmf_text_index(t, ';', 2, &rows, &flags));
     REQUIRE(flags == PRMF_TEXT_RAGGED && rows == 0);
     CK(prmf_text_destroy(t));
+  }
+  {
+    // sum of squares, NNLS against a device matrix (both orientations; checked through its optimality conditions), CSV writer
+    prmf_ctx* ctx = nullptr;
+    const int64_t m = 30, n = 50;
+    std::vector<double> A((size_t)(m * n));
+    std::vector<float> Af(A.size());
+    double want_ss = 0.0;
+    for (size_t i = 0; i < A.size(); ++i) {
+      Af[i] = (float)lcg();
+      A[i] = (double)Af[i];
+      want_ss += A[i] * A[i];
+    }
+    double* dA = nullptr;
+    float* dAf = nullptr;
+    HK(hipMalloc(&dA, A.size() * 8));
+    HK(hipMalloc(&dAf, A.size() * 4));
+    HK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dAf, Af.data(), A.size() * 4, hipMemcpyHostToDevice));
+    double ss = -1.0;
+    CK(prmf_sum_squares(0, dAf, PRMF_X_F32, m, n, n, &ss, nullptr));
+    REQUIRE(std::fabs(ss - want_ss) <= 1e-12 * want_ss);
+    for (int transposed = 0; transposed < 2; ++transposed) {
+      const int64_t eq = transposed ? n : m, un = transposed ? m : n;
+      std::vector<double> b((size_t)eq), x((size_t)un, -1.0);
+      for (auto& v : b) v = lcg();
+      double rnorm = -1.0;
+      int iters = -1;
+      CK(prmf_nnls(0, dA, m, n, n, transposed, b.data(), x.data(), &rnorm, &iters, 0, nullptr));
+      REQUIRE(iters > 0 && rnorm >= 0.0);
+      std::vector<double> r(b);                      // r = b - A x, then the gradient A^T r: <= 0 where x = 0, = 0 where x > 0
+      for (int64_t t = 0; t < eq; ++t)
+        for (int64_t j = 0; j < un; ++j) r[(size_t)t] -= (transposed ? A[(size_t)(j * n + t)] : A[(size_t)(t * n + j)]) * x[(size_t)j];
+      double rr = 0.0;
+      for (double v : r) rr += v * v;
+      REQUIRE(std::fabs(std::sqrt(rr) - rnorm) <= 1e-10);
+      for (int64_t j = 0; j < un; ++j) {
+        double g = 0.0;
+        for (int64_t t = 0; t < eq; ++t) g += (transposed ? A[(size_t)(j * n + t)] : A[(size_t)(t * n + j)]) * r[(size_t)t];
+        REQUIRE(x[(size_t)j] >= 0.0);
+        if (x[(size_t)j] > 0.0) REQUIRE(std::fabs(g) <= 1e-9); else REQUIRE(g <= 1e-9);
+      }
+    }
+    REQUIRE(prmf_nnls(0, dA, m, n, n - 1, 0, A.data(), A.data(), nullptr, nullptr, 0, nullptr) == PRMF_ERR_ARG);
+    char path[] = "/tmp/prmf_capi_wide_XXXXXX";
+    const int fd = mkstemp(path);
+    REQUIRE(fd >= 0);
+    close(fd);
+    const char prefixes[] = "\"a\",\"b\",";
+    const int64_t offs[3] = {0, 4, 8};
+    const double vals[4] = {0.1, 1e16, -0.0, 5e-324};
+    CK(prmf_write_csv(path, "\"\",\"LV0\",\"LV1\"\n", prefixes, offs, vals, 2, 2, 2, ',', 1));
+    std::FILE* fh = std::fopen(path, "rb");
+    REQUIRE(fh != nullptr);
+    char text[256];
+    const size_t got = std::fread(text, 1, sizeof text - 1, fh);
+    std::fclose(fh);
+    unlink(path);
+    text[got] = 0;
+    REQUIRE(std::string(text) == "\"\",\"LV0\",\"LV1\"\n\"a\",0.1,1e+16\n\"b\",-0.0,5e-324\n");
+    (void)hipFree(dA);
+    (void)hipFree(dAf);
   }
   std::printf("wide OK\n");
   std::fflush(stdout);
