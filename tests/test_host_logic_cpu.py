@@ -329,3 +329,23 @@ def test_multinomial_draw_equals_scipy():
     after_got = np.random.rand()
     assert all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(got, want))
     assert after_got == after_want
+
+
+def test_hold_out_equals_scikit_learn_kfold():
+    """runner.hold_out (the --cross-validation split, prmf_runner.py:1002-1013) against KFold(n_splits=round(1/f)) itself."""
+    from sklearn.model_selection import KFold
+    from prmf_amd.runner import hold_out
+    for n in (2, 3, 7, 10, 99, 100, 101, 1000):
+        X = np.arange(n * 3, dtype=float).reshape(n, 3)
+        samples = ["s%d" % i for i in range(n)]
+        for f in (0.5, 0.34, 0.2, 0.1, 0.05, 0.013):
+            k = round(1 / f)
+            if k > n:
+                with pytest.raises(ValueError):
+                    hold_out(X, samples, f)
+                continue
+            train, test = next(KFold(n_splits=k).split(X))
+            a, b, c = hold_out(X, samples, f)
+            assert np.array_equal(a, X[train]) and np.array_equal(b, X[test]) and c == [samples[i] for i in train]
+    with pytest.raises(ValueError):
+        hold_out(np.zeros((10, 2)), list(range(10)), 0.9)          # one fold: scikit-learn refuses
