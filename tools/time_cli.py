@@ -46,6 +46,30 @@ for p in range(P):
         fh.write('</graph></graphml>\n')
     fps.append(fp)
 
+if os.environ.get("SUBPROCESS"):          # the whole process as a user starts it: interpreter, imports, device, main()
+    import subprocess
+    argv = ["--data", data_fp, "--manifolds"] + fps + ["--outdir", os.path.join(d, "out"), "-k", str(k), "--seed", "1"] + \
+        (["--nodelist", os.path.join(d, "nodelist.txt")] if as_npy else []) + shlex.split(os.environ.get("EXTRA", ""))
+    os.makedirs(os.path.join(d, "out"), exist_ok=True)
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "script", "prmf_runner.py")
+    for rep in range(3):
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, script] + argv, capture_output=True, text=True)
+        print("process %d: %.2f s wall clock (exit %d, %d lines printed)" % (rep, time.perf_counter() - t0, r.returncode, r.stdout.count("\n")), flush=True)
+    r = subprocess.run([sys.executable, "-X", "importtime", "-c", "import sys; sys.path.insert(0, %r); import prmf_amd.runner, torch, pandas, networkx" %
+                        os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")], capture_output=True, text=True)
+    tops = []
+    for line in r.stderr.splitlines():
+        parts = line.split("|")
+        if len(parts) == 3 and not parts[2].startswith("   "):          # top-level imports only
+            try:
+                tops.append((int(parts[1]), parts[2].strip()))
+            except ValueError:
+                pass
+    print("imports (cumulative ms): " + ", ".join("%s %.0f" % (nm, us / 1e3) for us, nm in sorted(tops, reverse=True)[:8]), flush=True)
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+    sys.exit(0)
 t_imp = time.perf_counter()
 from prmf_amd import runner  # noqa: E402
 import torch  # noqa: E402
