@@ -1360,50 +1360,37 @@ struct NnlsDev {
   }
 };
 
-// lower Cholesky factor of the leading np x np block of G (row-major, leading dimension cap) into L; false if not positive definite
-bool chol_factor(const std::vector<double>& G, std::vector<double>& L, int np, int cap) {
-  for (int i = 0; i < np; ++i) {
-    for (int j = 0; j <= i; ++j) {
-      double v = G[(size_t)i * cap + j];
-      for (int t = 0; t < j; ++t) v -= L[(size_t)i * cap + t] * L[(size_t)j * cap + t];
-      if (i == j) {
-        if (!(v > 1e-13 * G[(size_t)i * cap + i])) return false;
-        L[(size_t)i * cap + i] = std::sqrt(v);
-      } else {
-        L[(size_t)i * cap + j] = v / L[(size_t)j * cap + j];
-      }
-    }
-  }
-  return true;
-}
+// G and its Cholesky factor L as lower triangles, one row per passive unknown (row i holds i + 1 entries): storage follows the
+// passive set, not the number of unknowns
+typedef std::vector<std::vector<double>> Tri;
 
-// row np of the factor from row np of G (the others are unchanged); false if the new column is numerically dependent
-bool chol_append_row(const std::vector<double>& G, std::vector<double>& L, int np, int cap) {
-  const int i = np;
+// row i of the factor from row i of G (rows before i are final); false if column i is numerically dependent on them
+bool chol_row(const Tri& G, Tri& L, int i) {
+  L[(size_t)i].assign((size_t)i + 1, 0.0);
   double ss = 0.0;
   for (int j = 0; j < i; ++j) {
-    double v = G[(size_t)i * cap + j];
-    for (int t = 0; t < j; ++t) v -= L[(size_t)i * cap + t] * L[(size_t)j * cap + t];
-    v /= L[(size_t)j * cap + j];
-    L[(size_t)i * cap + j] = v;
+    double v = G[(size_t)i][(size_t)j];
+    for (int t = 0; t < j; ++t) v -= L[(size_t)i][(size_t)t] * L[(size_t)j][(size_t)t];
+    v /= L[(size_t)j][(size_t)j];
+    L[(size_t)i][(size_t)j] = v;
     ss += v * v;
   }
-  const double d2 = G[(size_t)i * cap + i] - ss;
-  if (!(d2 > 1e-13 * G[(size_t)i * cap + i])) return false;
-  L[(size_t)i * cap + i] = std::sqrt(d2);
+  const double d2 = G[(size_t)i][(size_t)i] - ss;
+  if (!(d2 > 1e-13 * G[(size_t)i][(size_t)i])) return false;
+  L[(size_t)i][(size_t)i] = std::sqrt(d2);
   return true;
 }
 
-void chol_solve(const std::vector<double>& L, int np, int cap, const double* rhs, double* sol) {
+void chol_solve(const Tri& L, int np, const double* rhs, double* sol) {
   for (int i = 0; i < np; ++i) {
     double v = rhs[i];
-    for (int t = 0; t < i; ++t) v -= L[(size_t)i * cap + t] * sol[t];
-    sol[i] = v / L[(size_t)i * cap + i];
+    for (int t = 0; t < i; ++t) v -= L[(size_t)i][(size_t)t] * sol[t];
+    sol[i] = v / L[(size_t)i][(size_t)i];
   }
   for (int i = np - 1; i >= 0; --i) {
     double v = sol[i];
-    for (int t = i + 1; t < np; ++t) v -= L[(size_t)t * cap + i] * sol[t];
-    sol[i] = v / L[(size_t)i * cap + i];
+    for (int t = i + 1; t < np; ++t) v -= L[(size_t)t][(size_t)i] * sol[t];
+    sol[i] = v / L[(size_t)i][(size_t)i];
   }
 }
 }  // namespace
@@ -1416,7 +1403,6 @@ int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t 
   const int64_t st_t = transposed ? 1 : ld, st_j = transposed ? ld : 1;
   if (nvec > ((int64_t)1 << 30) || len > ((int64_t)1 << 30)) return fail(nullptr, PRMF_ERR_UNSUPPORTED, "prmf_nnls: more than 2^30 unknowns or equations");
   const int cap = (int)((nvec < len ? nvec : len) + 1);          // a passive set holds linearly independent columns
-  if ((double)cap * cap * 16.0 > 8e9) return fail(nullptr, PRMF_ERR_UNSUPPORTED, "prmf_nnls: min(unknowns, equations) = %d is beyond the host-side factor", cap - 1);
   if (max_iter <= 0) max_iter = (int)(3 * nvec < 2000000000 ? 3 * nvec : 2000000000);      // scipy's default
   if (hipSetDevice(device) != hipSuccess) return fail(nullptr, PRMF_ERR_HIP, "hipSetDevice(%d) failed", device);
   hipStream_t s = (hipStream_t)stream;
@@ -1440,7 +1426,7 @@ int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t 
   NN_TRY(hipMemcpyAsync(d.b, b, (size_t)len * 8, hipMemcpyHostToDevice, s));
   NN_TRY(hipMemcpyAsync(d.r, b, (size_t)len * 8, hipMemcpyHostToDevice, s));          // x = 0: r = b
   NN_TRY(hipMemsetAsync(d.state, 0, (size_t)nvec, s));
-  std::vector<double> G((size_t)cap * cap, 0.0), L((size_t)cap * cap, 0.0);
+  Tri G, L;                                 // lower triangles of A_P^T A_P and of its Cholesky factor, in list order
   std::vector<double> c((size_t)cap), sv((size_t)cap), xs((size_t)cap, 0.0), tmp((size_t)cap), corr((size_t)cap);
   std::vector<long long> P;                 // passive list, in order of entry
   std::vector<long long> rejected;          // refused in this round (state 2)
@@ -1449,13 +1435,13 @@ int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t 
 
   // s = argmin || A_P s - b || on the current list: Cholesky solve + one refinement step with the residual from A itself
   auto solve_passive = [&]() -> int {
-    chol_solve(L, np, cap, c.data(), sv.data());
+    chol_solve(L, np, c.data(), sv.data());
     NN_TRY(hipMemcpyAsync(d.s, sv.data(), (size_t)np * 8, hipMemcpyHostToDevice, s));
     NN_TRY(nnlsm_residual(dX, st_t, st_j, len, d.P, np, d.s, d.b, d.q, s));
     NN_TRY(nnlsm_dots(dX, st_t, st_j, len, d.P, np, d.q, d.out, s));
     NN_TRY(hipMemcpyAsync(tmp.data(), d.out, (size_t)np * 8, hipMemcpyDeviceToHost, s));
     NN_TRY(hipStreamSynchronize(s));
-    chol_solve(L, np, cap, tmp.data(), corr.data());
+    chol_solve(L, np, tmp.data(), corr.data());
     for (int a = 0; a < np; ++a) sv[(size_t)a] += corr[(size_t)a];
     return PRMF_OK;
   };
@@ -1495,11 +1481,10 @@ int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t 
     NN_TRY(nnlsm_dots(dX, st_t, st_j, len, d.P + (np - 1), 1, d.b, d.out + cap - 1, s));
     NN_TRY(hipMemcpyAsync(&c[(size_t)np - 1], d.out + cap - 1, 8, hipMemcpyDeviceToHost, s));
     NN_TRY(hipStreamSynchronize(s));
-    for (int a = 0; a < np; ++a) {
-      G[(size_t)(np - 1) * cap + a] = tmp[(size_t)a];
-      G[(size_t)a * cap + (np - 1)] = tmp[(size_t)a];
-    }
-    bool ok = chol_append_row(G, L, np - 1, cap);
+    G.resize((size_t)np);
+    L.resize((size_t)np);
+    G[(size_t)np - 1].assign(tmp.begin(), tmp.begin() + np);
+    bool ok = chol_row(G, L, np - 1);
     if (ok) {
       xs[(size_t)np - 1] = 0.0;
       if ((rc = solve_passive())) return rc;
@@ -1508,6 +1493,8 @@ int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t 
     if (!ok) {                                        // refuse it for this round and look at the next largest gradient
       P.pop_back();
       --np;
+      G.resize((size_t)np);
+      L.resize((size_t)np);
       rejected.push_back(j);
       if ((rc = set_state(j, 2))) return rc;
       if ((rc = upload_list())) return rc;
@@ -1539,16 +1526,21 @@ int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t 
       }
       const int kept = (int)keep.size();
       for (int a = 0; a < kept; ++a) {
-        for (int t = 0; t < kept; ++t) G[(size_t)a * cap + t] = G[(size_t)keep[(size_t)a] * cap + keep[(size_t)t]];
+        std::vector<double> row((size_t)a + 1);
+        for (int t = 0; t <= a; ++t) row[(size_t)t] = G[(size_t)keep[(size_t)a]][(size_t)keep[(size_t)t]];      // keep is increasing
+        G[(size_t)a].swap(row);
         P[(size_t)a] = P[(size_t)keep[(size_t)a]];
         xs[(size_t)a] = xs[(size_t)keep[(size_t)a]];
         c[(size_t)a] = c[(size_t)keep[(size_t)a]];
       }
+      G.resize((size_t)kept);
+      L.resize((size_t)kept);
       P.resize((size_t)kept);
       np = kept;
       if ((rc = upload_list())) return rc;
       if (np == 0) break;
-      if (!chol_factor(G, L, np, cap)) return fail(nullptr, PRMF_ERR_NUMERIC, "prmf_nnls: passive columns became dependent");
+      for (int a = 0; a < np; ++a)
+        if (!chol_row(G, L, a)) return fail(nullptr, PRMF_ERR_NUMERIC, "prmf_nnls: passive columns became dependent");
       if ((rc = solve_passive())) return rc;
     }
     for (int a = 0; a < np; ++a) xs[(size_t)a] = sv[(size_t)a];
