@@ -7,7 +7,12 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
+#include <cstdlib>
 #include <random>
+#include <string>
+#include <vector>
+#include <unistd.h>
 
 #include "prmf_hip.h"
 #include "prmf_hip_debug.h"
@@ -76,6 +81,76 @@ int main(int argc, char** argv) {
     CHECK(n > ph && ph > w && w >= 2 * mx, "stamp layout %d %d %d %d", n, w, ph, mx);
     CHECK(prmf_debug_set_stamps((void*)0x1000, (size_t)n - 1) == PRMF_ERR_ARG, "short stamp buffer");
     CHECK(prmf_debug_set_stamps((void*)0x1000, (size_t)n) == 0 && prmf_debug_set_stamps(nullptr, 0) == 0, "stamp buffer");
+  }
+  {
+    // the CSV writer is host code end to end: 2000 x 7 values of every magnitude through the threaded path and the single one,
+    // row prefixes, NaN / infinities / signed zeros / subnormals -- read back and compared with strtod
+    const int64_t rows = 2000, cols = 7;
+    std::vector<double> v((size_t)(rows * cols));
+    for (size_t i = 0; i < v.size(); ++i) {
+      uint64_t bits = rng();
+      double d;
+      std::memcpy(&d, &bits, 8);
+      if (i % 5 == 0) d = (double)(int64_t)(rng() % 1000000) / 997.0;
+      v[i] = d;
+    }
+    v[0] = 0.0; v[1] = -0.0; v[2] = 5e-324; v[3] = 1.7976931348623157e308; v[4] = 1e16; v[5] = 1e-5; v[6] = 123456789012345680.0;
+    std::string prefixes;
+    std::vector<int64_t> off((size_t)rows + 1, 0);
+    for (int64_t r = 0; r < rows; ++r) {
+      prefixes += "\"r" + std::to_string(r) + "\",";
+      off[(size_t)r + 1] = (int64_t)prefixes.size();
+    }
+    char path[] = "/tmp/prmf_sanitize_XXXXXX";
+    const int fd = mkstemp(path);
+    CHECK(fd >= 0, "mkstemp");
+    if (fd >= 0) {
+      close(fd);
+      for (int threads : {1, 4, 0}) {
+        CHECK(prmf_write_csv(path, "\"\",\"a\"\n", prefixes.data(), off.data(), v.data(), rows, cols, cols, ',', threads) == PRMF_OK, "write_csv");
+        std::FILE* fh = std::fopen(path, "rb");
+        CHECK(fh != nullptr, "reopen");
+        if (!fh) break;
+        std::string text;
+        char buf[65536];
+        size_t got;
+        while ((got = std::fread(buf, 1, sizeof buf, fh)) > 0) text.append(buf, got);
+        std::fclose(fh);
+        size_t pos = text.find('\n') + 1;
+        long bad = 0;
+        for (int64_t r = 0; r < rows && !bad; ++r) {
+          pos = text.find(',', pos) + 1;                       // past the row label
+          for (int64_t c = 0; c < cols; ++c) {
+            const size_t end = text.find_first_of(",\n", pos);
+            const std::string cell = text.substr(pos, end - pos);
+            const double want = v[(size_t)(r * cols + c)];
+            if (want != want) bad += cell != "\"\"";
+            else bad += std::strtod(cell.c_str(), nullptr) != want || std::signbit(std::strtod(cell.c_str(), nullptr)) != std::signbit(want);
+            pos = end + 1;
+          }
+        }
+        CHECK(bad == 0 && pos == text.size(), "%ld cells read back differently (threads %d)", bad, threads);
+      }
+      CHECK(prmf_write_csv(path, nullptr, nullptr, nullptr, v.data(), 3, 2, 2, ';', 1) == PRMF_OK, "no header, no prefixes");
+      unlink(path);
+    }
+    CHECK(prmf_write_csv("/nonexistent-dir/x.csv", nullptr, nullptr, nullptr, v.data(), 1, 1, 1, ',', 1) == PRMF_ERR_ARG, "unwritable path");
+    CHECK(prmf_write_csv(path, nullptr, prefixes.data(), nullptr, v.data(), 1, 1, 1, ',', 1) == PRMF_ERR_ARG, "prefixes without offsets");
+    CHECK(prmf_write_csv(nullptr, nullptr, nullptr, nullptr, v.data(), 1, 1, 1, ',', 1) == PRMF_ERR_ARG, "NULL path");
+  }
+  {
+    // argument checks of the device-side entry points that end before any device work
+    prmf_text* t = nullptr;
+    int64_t rows = 0;
+    int flags = 0;
+    double out = 0.0, x[4] = {0, 0, 0, 0};
+    CHECK(prmf_text_create(nullptr, 0, 10) == PRMF_ERR_ARG && prmf_text_create(&t, 0, -5) == PRMF_ERR_ARG && t == nullptr, "text_create");
+    CHECK(prmf_text_append(nullptr, "1", 1) == PRMF_ERR_ARG && prmf_text_index(nullptr, ',', 2, &rows, &flags) == PRMF_ERR_ARG, "text NULL handle");
+    CHECK(prmf_text_parse(nullptr, 0, nullptr, nullptr, nullptr, &flags, nullptr) == PRMF_ERR_ARG && prmf_text_destroy(nullptr) == PRMF_OK, "text parse / destroy NULL");
+    CHECK(prmf_sum_squares(0, nullptr, PRMF_X_F32, 2, 2, 2, &out, nullptr) == PRMF_ERR_ARG && prmf_sum_squares(0, nullptr, 9, 0, 0, 0, &out, nullptr) == PRMF_ERR_ARG, "sum_squares");
+    CHECK(prmf_sum_squares(0, nullptr, PRMF_X_BF16, 0, 5, 5, &out, nullptr) == PRMF_OK && out == 0.0, "sum_squares of nothing");
+    CHECK(prmf_nnls(0, nullptr, 2, 2, 2, 0, x, x, nullptr, nullptr, 0, nullptr) == PRMF_ERR_ARG, "nnls NULL matrix");
+    CHECK(prmf_nnls(0, x, 2, 2, 1, 0, x, x, nullptr, nullptr, 0, nullptr) == PRMF_ERR_ARG && prmf_nnls(0, x, 0, 2, 2, 0, x, x, nullptr, nullptr, 0, nullptr) == PRMF_ERR_ARG, "nnls shapes");
   }
   CHECK(prmf_abi_version() >= 2, "abi version %d", prmf_abi_version());
   std::printf("%lld plans checked, %d failures\n", checked, failures);
