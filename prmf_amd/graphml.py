@@ -38,9 +38,16 @@ def read_pathway(fp, node_attribute="name"):
         return _slow(fp, node_attribute)          # let networkx report it in its own words
 
 
-def _data(elem, keys):
+def _data(elem, keys, tag_data, refused):
+    """The <data> children of a node / edge element, typed by their <key>; any other child listed in `refused` (ports, nested
+    graphs) makes the file not plain.  One pass over the children."""
     out = {}
-    for d in elem.findall(NS + "data"):
+    for d in elem:
+        tag = d.tag
+        if tag != tag_data:
+            if tag in refused:
+                raise _NotPlain()
+            continue
         key = keys.get(d.get("key"))
         if key is None or len(d):
             raise _NotPlain()
@@ -48,6 +55,8 @@ def _data(elem, keys):
         text = d.text
         if text is None:
             out[name] = ""
+        elif typ is str:
+            out[name] = text
         elif typ is bool:
             try:
                 out[name] = _BOOL[text.lower()]
@@ -80,15 +89,23 @@ def _fast(fp, node_attribute):
     if len(graphs) != 1:
         raise _NotPlain()
     g = graphs[0]
-    if g.get("edgedefault") == "directed" or g.find(NS + "hyperedge") is not None or g.findall(NS + "data"):
+    if g.get("edgedefault") == "directed":
         raise _NotPlain()
-    names, node_data = [], {}
-    for nd in g.findall(NS + "node"):
-        nid = nd.get("id")
-        if nid is None or nid in node_data or nd.find(NS + "port") is not None or nd.find(NS + "graph") is not None:
-            raise _NotPlain()
-        node_data[nid] = _data(nd, keys)
-        names.append(nid)
+    tag_node, tag_edge, tag_data = NS + "node", NS + "edge", NS + "data"
+    refused = (NS + "port", NS + "graph")
+    names, node_data, edge_elems = [], {}, []
+    for child in g:                                    # one pass: nodes in file order, edges kept for the second step
+        tag = child.tag
+        if tag == tag_node:
+            nid = child.get("id")
+            if nid is None or nid in node_data:
+                raise _NotPlain()
+            node_data[nid] = _data(child, keys, tag_data, refused) if len(child) else {}
+            names.append(nid)
+        elif tag == tag_edge:
+            edge_elems.append(child)
+        elif tag == tag_data or tag == NS + "hyperedge":
+            raise _NotPlain()                           # graph-level data, hyperedges: networkx's business
     # the relabel: nodes that carry the attribute take its value as their name; the map has to stay one-to-one
     if node_attribute is not None:
         mapping = {n: d[node_attribute] for n, d in node_data.items() if node_attribute in d}
@@ -102,15 +119,16 @@ def _fast(fp, node_attribute):
         raise _NotPlain()
     # edges in file order into per-node neighbour lists, as the MultiGraph networkx fills would hold them
     nbrs = {n: {} for n in names}
-    for e in g.findall(NS + "edge"):
-        if e.get("directed") == "true" or e.find(NS + "port") is not None:
+    for e in edge_elems:
+        if e.get("directed") == "true":
             raise _NotPlain()
         s, t = e.get("source"), e.get("target")
         if s not in nbrs or t not in nbrs or t in nbrs[s]:
             raise _NotPlain()                           # undeclared endpoint, or a parallel edge (-> MultiGraph)
-        d = _data(e, keys)
-        if e.get("id"):
-            d["id"] = e.get("id")
+        d = _data(e, keys, tag_data, refused) if len(e) else {}
+        eid = e.get("id")
+        if eid:
+            d["id"] = eid
         nbrs[s][t] = d
         nbrs[t][s] = d
     G = nx.Graph()
