@@ -330,6 +330,8 @@ int prmf_quantile_transform(int device, double* dX, int64_t m, int64_t n, int64_
  *     PRMF_TEXT_WIDE_INT     an integer spelled with more than 15 digits (exact in pandas' int64, not in a double), or an
  *                            integer part of 19 or more digits (pandas' int64 / uint64 probes overflow on it and the column's
  *                            type then depends on what stood above that field)
+ *     PRMF_TEXT_BARE_CR      a carriage return that is not followed by a line feed, anywhere (row names included): pandas
+ *                            ends a line there
  * Calls: prmf_text_create(&t, device, nbytes) reserves device memory for the body; prmf_text_append copies the next piece
  * of it from host memory (any piece size: a 64 MB read buffer keeps the host footprint flat); prmf_text_index finds the
  * fields and checks the line structure (*rows_out lines); prmf_text_parse converts: out = rows x (fields_per_line -
@@ -340,7 +342,7 @@ int prmf_quantile_transform(int device, double* dX, int64_t m, int64_t n, int64_
  * device's null stream; no prmf_ctx is needed; errors are read with prmf_last_error(NULL).
  */
 typedef struct prmf_text prmf_text;
-enum { PRMF_TEXT_RAGGED = 1, PRMF_TEXT_QUOTED = 2, PRMF_TEXT_NOT_NUMERIC = 4, PRMF_TEXT_WIDE_INT = 8 };
+enum { PRMF_TEXT_RAGGED = 1, PRMF_TEXT_QUOTED = 2, PRMF_TEXT_NOT_NUMERIC = 4, PRMF_TEXT_WIDE_INT = 8, PRMF_TEXT_BARE_CR = 16 };
 int prmf_text_create(prmf_text** out, int device, int64_t nbytes);
 int prmf_text_append(prmf_text* text, const void* bytes, int64_t nbytes);
 int prmf_text_index(prmf_text* text, char delimiter, int64_t fields_per_line, int64_t* rows_out, int* flags_out);

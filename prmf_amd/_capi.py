@@ -21,7 +21,7 @@ PRMF_FLAG_EAGER_OBJECTIVE = 0x4
 PRMF_FLAG_DIRECT_RESIDUAL = 0x8
 PRMF_DIST_COLUMN_SHARDED, PRMF_DIST_REPLICATED = 0, 1
 PRMF_COMM_ID_BYTES = 128
-PRMF_TEXT_RAGGED, PRMF_TEXT_QUOTED, PRMF_TEXT_NOT_NUMERIC, PRMF_TEXT_WIDE_INT = 1, 2, 4, 8
+PRMF_TEXT_RAGGED, PRMF_TEXT_QUOTED, PRMF_TEXT_NOT_NUMERIC, PRMF_TEXT_WIDE_INT, PRMF_TEXT_BARE_CR = 1, 2, 4, 8, 16
 OBJ_KEYS = ("recon", "manifold", "ignore", "fro", "gamma", "delta", "obj")
 
 PRMF_OK = 0

@@ -27,7 +27,7 @@ static_assert(PRMF_OBJ_STRIDE == REC_STRIDE && PRMF_OBJ_FLAGS == REC_FLAGS && PR
               PRMF_RECON_DIRECT == REC_FLAG_DIRECT && PRMF_RECON_IMPRECISE == REC_FLAG_IMPRECISE && PRMF_RECON_CLAMPED == REC_FLAG_CLAMPED,
               "record layout of the header and of the kernels");
 static_assert(PRMF_TEXT_RAGGED == TEXT_FLAG_RAGGED && PRMF_TEXT_QUOTED == TEXT_FLAG_QUOTED && PRMF_TEXT_NOT_NUMERIC == TEXT_FLAG_NOT_NUMERIC &&
-              PRMF_TEXT_WIDE_INT == TEXT_FLAG_WIDE_INT, "text flags of the header and of the kernels");
+              PRMF_TEXT_WIDE_INT == TEXT_FLAG_WIDE_INT && PRMF_TEXT_BARE_CR == TEXT_FLAG_BARE_CR, "text flags of the header and of the kernels");
 }
 
 struct prmf_ctx {

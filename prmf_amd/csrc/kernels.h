@@ -311,6 +311,7 @@ constexpr int TEXT_FLAG_RAGGED = 1;        // = PRMF_TEXT_RAGGED ... (include/pr
 constexpr int TEXT_FLAG_QUOTED = 2;
 constexpr int TEXT_FLAG_NOT_NUMERIC = 4;
 constexpr int TEXT_FLAG_WIDE_INT = 8;
+constexpr int TEXT_FLAG_BARE_CR = 16;
 int64_t text_blocks(int64_t nbytes);       // workgroups (= per-workgroup counts) for nbytes of text
 //   counts[text_blocks(nbytes)]: separators (delim or '\n') per 4 KiB of text
 hipError_t text_count(const unsigned char* text, int64_t nbytes, unsigned char delim, int64_t* counts, hipStream_t s);

@@ -41,8 +41,8 @@ constexpr int TEXT_TILE = TEXT_TPB * TEXT_BPL;      // 4 KiB per workgroup
 
 // bit i of *sep: byte base + i is a separator; of *nl: it is '\n'
 __device__ __forceinline__ void classify16(const unsigned char* __restrict__ text, int64_t base, int64_t L, unsigned char delim,
-                                           unsigned* sep, unsigned* nl) {
-  unsigned s = 0, n = 0;
+                                           unsigned* sep, unsigned* nl, unsigned* cr = nullptr) {
+  unsigned s = 0, n = 0, r = 0;
   if (base + TEXT_BPL <= L) {
     const uint4 v = *reinterpret_cast<const uint4*>(text + base);        // base is a multiple of 16, text is hipMalloc'ed
     const unsigned w[4] = {v.x, v.y, v.z, v.w};
@@ -50,17 +50,20 @@ __device__ __forceinline__ void classify16(const unsigned char* __restrict__ tex
     for (int i = 0; i < TEXT_BPL; ++i) {
       const unsigned char c = (unsigned char)(w[i >> 2] >> ((i & 3) * 8));
       n |= (unsigned)(c == '\n') << i;
+      r |= (unsigned)(c == '\r') << i;
       s |= (unsigned)(c == '\n' || c == delim) << i;
     }
   } else {
     for (int i = 0; i < TEXT_BPL && base + i < L; ++i) {
       const unsigned char c = text[base + i];
       n |= (unsigned)(c == '\n') << i;
+      r |= (unsigned)(c == '\r') << i;
       s |= (unsigned)(c == '\n' || c == delim) << i;
     }
   }
   *sep = s;
   *nl = n;
+  if (cr) *cr = r;
 }
 
 __global__ void __launch_bounds__(TEXT_TPB)
@@ -85,8 +88,14 @@ text_positions_kernel(const unsigned char* __restrict__ text, int64_t L, unsigne
   __shared__ int wave_total[TEXT_TPB / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t base = ((int64_t)blockIdx.x * TEXT_TPB + tid) * TEXT_BPL;
-  unsigned sep = 0, nl = 0;
-  if (base < L) classify16(text, base, L, delim, &sep, &nl);
+  unsigned sep = 0, nl = 0, cr = 0;
+  if (base < L) classify16(text, base, L, delim, &sep, &nl, &cr);
+  // a carriage return that is not followed by a line feed ends a line for pandas: such a file is not read here
+  if (cr) {
+    unsigned followed = nl >> 1;                       // bit i: byte i + 1 is '\n'
+    if ((cr >> 15) & 1u) followed |= (unsigned)(base + TEXT_BPL < L && text[base + TEXT_BPL] == '\n') << 15;
+    if (cr & ~followed) atomicOr(flags, TEXT_FLAG_BARE_CR);
+  }
   const int mine = __popc(sep);
   int incl = mine;                                   // inclusive scan over the wave
 #pragma unroll

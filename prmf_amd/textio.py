@@ -43,10 +43,15 @@ def _split_header(line, delimiter):
         text = text.decode("utf-8")
     except UnicodeDecodeError:
         raise NotPlain("header is not UTF-8")
+    if "\r" in text:
+        raise NotPlain("carriage return inside the header")
     if text.startswith("﻿"):
         raise NotPlain("byte-order mark")
     if '"' in text:
-        rows = list(csv.reader(io.StringIO(text), delimiter=delimiter))
+        try:
+            rows = list(csv.reader(io.StringIO(text), delimiter=delimiter, strict=True))      # strict: an open quote is an error
+        except csv.Error as e:
+            raise NotPlain("header: %s" % e)
         if len(rows) != 1:
             raise NotPlain("header spans several lines")
         names = rows[0]
@@ -102,7 +107,8 @@ def _read_frame(path, delimiter, has_header, has_row_names, device, mixed_as_flo
             body_off = len(first)
             fields = len(names)
             labels = names[rn:]
-            if any(lab == "" for lab in labels) or len(set(labels)) != len(labels):
+            # (pandas renames duplicates over ALL names of the line, the corner cell above the row names included)
+            if any(lab == "" for lab in labels) or len(set(names)) != len(names):
                 raise NotPlain("empty or duplicate column names")
             columns = pd.Index(labels, dtype=object)
             index_name = (names[0] or None) if rn else None
@@ -131,7 +137,7 @@ def _read_frame(path, delimiter, has_header, has_row_names, device, mixed_as_flo
             rows, flags = C.c_int64(), C.c_int()
             _capi.check(lib, None, lib.prmf_text_index(handle, delimiter.encode(), fields, C.byref(rows), C.byref(flags)))
             if flags.value:
-                raise NotPlain("lines of different lengths (flags %d)" % flags.value)
+                raise NotPlain("lines of different lengths or a bare carriage return (flags %d)" % flags.value)
             m, n = rows.value, fields - rn
             if m == 0:
                 raise NotPlain("no data line")
@@ -158,7 +164,10 @@ def _read_frame(path, delimiter, has_header, has_row_names, device, mixed_as_flo
         import mmap
         with open(path, "rb") as fh, mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ) as mm:
             lines = [mm[body_off + a:body_off + b] for a, b in spans.tolist()]
-        sub = pd.read_csv(io.BytesIO(b"\n".join(lines) + b"\n"), sep=delimiter, header=None, index_col=0, skip_blank_lines=False)
+        try:
+            sub = pd.read_csv(io.BytesIO(b"\n".join(lines) + b"\n"), sep=delimiter, header=None, index_col=0, skip_blank_lines=False)
+        except (pd.errors.ParserError, pd.errors.EmptyDataError, UnicodeDecodeError, ValueError) as e:
+            raise NotPlain("row names: %s" % e)
         if len(sub.index) != m or sub.shape[1] != 0:
             raise NotPlain("row names that pandas reads as something else than one field each")
         index = sub.index

@@ -28,3 +28,14 @@ def test_random_shapes_vs_oracle():
 
 def test_random_shapes_through_the_multi_rank_step():
     _run("fuzz_ranks.py", seed=12, cases=40, timeout=600)
+
+
+def test_random_and_mutated_text_files_vs_pandas():
+    """A bounded run of tools/fuzz_text.py: well-formed and mutated delimited files through the GPU text reader -- whatever it
+    returns must be pandas' frame exactly; refusing is always allowed (long runs: profiles/r05_fuzz_text.txt)."""
+    env = dict(os.environ, SEED="7", CASES="600", PRMF_TEXT_READER="gpu")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_text.py")], env=env, capture_output=True, text=True, timeout=600)
+    tail = "\n".join((r.stdout + "\n" + r.stderr).strip().splitlines()[-6:])
+    assert r.returncode == 0 and "accepted and equal to pandas' frame" in r.stdout, tail
+    accepted = int(r.stdout.split(" files: ")[1].split(" accepted")[0])
+    assert accepted > 150, tail          # the run is not vacuous

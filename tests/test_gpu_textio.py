@@ -138,6 +138,10 @@ NOT_PLAIN = {
     "sixteen-digit integer": "a,b,c\n1,1234567890123456,3\n4,5,6\n",
     "integer part beyond uint64": "a,b,c\n1.5,2.5,3.5\n4,74233762471773093888.000,6\n",
     "old Mac line ends": "a,b,c\r1,2,3\r4,5,6\r",
+    "carriage return inside a row name": "id,a,b\nx,1.5,2.5\ny\rz,3.5,4.5\n",
+    "carriage return inside a quoted header": '"id","a\rb","c"\nx,1.5,2.5\n',
+    "corner cell equal to a column name": "a,a,b\nx,1.5,2.5\ny,3.5,4.5\n",
+    "unbalanced quote in the header": '"id,a,b\nx,1.5,2.5\n',
     "byte-order mark": "﻿a,b,c\n1,2,3\n4,5,6\n",
     "text": "a,b,c\n1,two,3\n4,5,6\n",
     "thousands": 'a,b,c\n1,"2,000",3\n4,5,6\n',
@@ -154,7 +158,9 @@ def test_files_that_are_not_plain_are_left_to_pandas(tmp_path, what):
         fh.write(NOT_PLAIN[what])
     has_header = what != "one line without end"
     why = []
-    assert textio.read_frame(path, ",", has_header, what == "header one field short", why=why) is None
+    row_names = what in ("header one field short", "carriage return inside a row name", "carriage return inside a quoted header",
+                         "unbalanced quote in the header", "corner cell equal to a column name")
+    assert textio.read_frame(path, ",", has_header, row_names, why=why) is None
     assert why and why[0]
     assert textio.read_frame(path + ".gz", ",", True, False, why=why) is None
 
