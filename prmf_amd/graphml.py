@@ -98,8 +98,8 @@ def _fast(fp, node_attribute):
         tag = child.tag
         if tag == tag_node:
             nid = child.get("id")
-            if nid is None or nid in node_data:
-                raise _NotPlain()
+            if nid is None or nid in node_data or child.get("yfiles.foldertype") is not None:
+                raise _NotPlain()                       # (a yEd group node makes networkx descend into a nested graph)
             node_data[nid] = _data(child, keys, tag_data, refused) if len(child) else {}
             names.append(nid)
         elif tag == tag_edge:

@@ -349,3 +349,13 @@ def test_hold_out_equals_scikit_learn_kfold():
             assert np.array_equal(a, X[train]) and np.array_equal(b, X[test]) and c == [samples[i] for i in train]
     with pytest.raises(ValueError):
         hold_out(np.zeros((10, 2)), list(range(10)), 0.9)          # one fold: scikit-learn refuses
+
+
+@pytest.mark.parametrize("what,cases", [("write", 400), ("graphml", 250)])
+def test_bounded_run_of_the_host_io_fuzzer(what, cases):
+    """tools/fuzz_host_io.py: the CSV writer against DataFrame.to_csv (the same bytes or a refusal) and the GraphML reader against
+    networkx's three steps (the same graph or the same exception) on random and mutated inputs; long runs: profiles/r05_fuzz_text.txt."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_host_io.py"), what], env=dict(os.environ, SEED="5", CASES=str(cases)),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and ("%d " % cases) in r.stdout.splitlines()[-1], (r.stdout + r.stderr)[-1500:]
