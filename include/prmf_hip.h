@@ -285,7 +285,9 @@ int prmf_cv_error(prmf_ctx* ctx, const float* dV, double* err_out, void* stream)
  * -- the Lawson-Hanson active-set method as there; gradient, column inner products and residual on the device, the
  * passive-set factor on the host, one refinement step per solve.  b (equations) and x (unknowns) are HOST arrays;
  * *rnorm_out (nullable) = || A x - b ||_2, *iterations_out (nullable) = active-set steps taken; max_iter <= 0: 3 x the
- * number of unknowns (scipy's default); PRMF_ERR_NUMERIC when it is exceeded ("maximum number of iterations reached").
+ * number of unknowns (scipy's default); PRMF_ERR_NUMERIC when it is exceeded ("maximum number of iterations reached") and
+ * when the passive-set factor (normal equations) loses a problem whose conditioning is beyond it ("ill-conditioned passive
+ * set": no answer is returned rather than a wrong one; the caller falls back to scipy's orthogonal factorisation).
  * Both problems have a unique minimiser for data in general position, so the result equals scipy's up to rounding
  * (tests/test_gpu_nnls_matrix.py: 1e-9).  Synchronises `stream`; no context needed.
  */

@@ -1351,11 +1351,11 @@ int prmf_debug_recon_terms(prmf_ctx* c, int it, double* cross, double* gu, doubl
 // ---------------------------------------------------------------------------
 namespace {
 struct NnlsDev {
-  double *b = nullptr, *r = nullptr, *q = nullptr, *w = nullptr, *s = nullptr, *out = nullptr;
+  double *b = nullptr, *r = nullptr, *q = nullptr, *w = nullptr, *s = nullptr, *out = nullptr, *wabs = nullptr, *babs = nullptr, *scratch = nullptr;
   unsigned char* state = nullptr;
   long long *P = nullptr, *arg = nullptr;
   ~NnlsDev() {
-    (void)hipFree(b); (void)hipFree(r); (void)hipFree(q); (void)hipFree(w); (void)hipFree(s); (void)hipFree(out);
+    (void)hipFree(b); (void)hipFree(r); (void)hipFree(q); (void)hipFree(w); (void)hipFree(s); (void)hipFree(out); (void)hipFree(wabs); (void)hipFree(babs); (void)hipFree(scratch);
     (void)hipFree(state); (void)hipFree(P); (void)hipFree(arg);
   }
 };
@@ -1418,6 +1418,9 @@ int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t 
   NN_TRY(hipMalloc((void**)&d.r, (size_t)len * 8));
   NN_TRY(hipMalloc((void**)&d.q, (size_t)len * 8));
   NN_TRY(hipMalloc((void**)&d.w, (size_t)nvec * 8));
+  NN_TRY(hipMalloc((void**)&d.wabs, (size_t)nvec * 8));
+  NN_TRY(hipMalloc((void**)&d.babs, (size_t)nvec * 8));
+  NN_TRY(hipMalloc((void**)&d.scratch, (size_t)nvec * 8));
   NN_TRY(hipMalloc((void**)&d.state, (size_t)nvec));
   NN_TRY(hipMalloc((void**)&d.s, (size_t)cap * 8));
   NN_TRY(hipMalloc((void**)&d.out, (size_t)cap * 8));
@@ -1426,13 +1429,26 @@ int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t 
   NN_TRY(hipMemcpyAsync(d.b, b, (size_t)len * 8, hipMemcpyHostToDevice, s));
   NN_TRY(hipMemcpyAsync(d.r, b, (size_t)len * 8, hipMemcpyHostToDevice, s));          // x = 0: r = b
   NN_TRY(hipMemsetAsync(d.state, 0, (size_t)nvec, s));
+  NN_TRY(nnlsm_gradient(dX, ld, rows, cols, transposed != 0, d.b, d.scratch, d.babs, s));      // babs[j] = sum_t |a_tj b_t|, once
   Tri G, L;                                 // lower triangles of A_P^T A_P and of its Cholesky factor, in list order
   std::vector<double> c((size_t)cap), sv((size_t)cap), xs((size_t)cap, 0.0), tmp((size_t)cap), corr((size_t)cap);
   std::vector<long long> P;                 // passive list, in order of entry
   std::vector<long long> rejected;          // refused in this round (state 2)
   int np = 0, iters = 0;
-  double tol = -1.0;
-
+  // An unknown may enter while its gradient a_j . r stands out of the rounding noise of that inner product and of the residual
+  // it is taken with (nnlsm_argmax): Lawson-Hanson's "w_j > 0" in floating point, per column, free of row and column scales.
+  const double c1 = 8.0 * 2.220446049250313e-16 * std::sqrt((double)len), c2 = 64.0 * 2.220446049250313e-16;
+  std::vector<double> rhost((size_t)len);
+  double rnorm_now = 0.0;
+  bool suspect = false;                     // a refusal in the current round that exact arithmetic cannot produce
+  auto residual_norm = [&]() -> int {
+    NN_TRY(hipMemcpyAsync(rhost.data(), d.r, (size_t)len * 8, hipMemcpyDeviceToHost, s));
+    NN_TRY(hipStreamSynchronize(s));
+    double ss = 0.0;
+    for (double v : rhost) ss += v * v;
+    rnorm_now = std::sqrt(ss);
+    return PRMF_OK;
+  };
   // s = argmin || A_P s - b || on the current list: Cholesky solve + one refinement step with the residual from A itself
   auto solve_passive = [&]() -> int {
     chol_solve(L, np, c.data(), sv.data());
@@ -1458,18 +1474,23 @@ int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t 
   bool need_gradient = true;
   for (;;) {
     if (need_gradient) {
-      NN_TRY(nnlsm_gradient(dX, ld, rows, cols, transposed != 0, d.r, d.w, s));
+      if ((rc = residual_norm())) return rc;
+      NN_TRY(nnlsm_gradient(dX, ld, rows, cols, transposed != 0, d.r, d.w, d.wabs, s));
       need_gradient = false;
     }
-    NN_TRY(nnlsm_argmax(d.w, d.state, nvec, d.arg, s));
+    NN_TRY(nnlsm_argmax(d.w, d.state, d.wabs, d.babs, c1, c2, nvec, d.arg, s));
     long long arg[2];
     NN_TRY(hipMemcpyAsync(arg, d.arg, 16, hipMemcpyDeviceToHost, s));
     NN_TRY(hipStreamSynchronize(s));
     double wj;
     std::memcpy(&wj, &arg[1], 8);
     const long long j = arg[0];
-    if (tol < 0.0) tol = 1e-12 * (j >= 0 && wj > 0.0 ? wj : 0.0);       // relative to the largest component of A^T b
-    if (j < 0 || !(wj > tol) || np >= cap - 1) break;
+    if (j < 0 || !(wj > 0.0) || np >= cap - 1) {
+      if (getenv("PRMF_NNLS_DEBUG"))
+        std::fprintf(stderr, "prmf_nnls stop: j=%lld wj=%g np=%d cap=%d iters=%d rnorm=%g rejected=%zu suspect=%d\n", j, wj, np, cap, iters,
+                     rnorm_now, rejected.size(), (int)suspect);
+      break;
+    }
     if (++iters > max_iter) return fail(nullptr, PRMF_ERR_NUMERIC, "prmf_nnls: maximum number of iterations reached");
     // column j joins the list: its inner products with the list (one row of A_P^T A_P) and with b
     NN_TRY(nnlsm_column(dX, st_t, st_j, len, j, d.q, s));
@@ -1491,6 +1512,11 @@ int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t 
       ok = sv[(size_t)np - 1] > 0.0;                  // Lawson-Hanson: the entering unknown must come out positive
     }
     if (!ok) {                                        // refuse it for this round and look at the next largest gradient
+      // In exact arithmetic a column with a positive gradient is independent of the list and comes out positive; a refusal of a
+      // column whose gradient is a real descent direction (cosine with the residual above 1e-6) means the Gram factor has lost
+      // the problem (conditioning beyond what normal equations carry): the answer would be wrong, so there is none.
+      const double aj = std::sqrt(tmp[(size_t)np - 1] > 0.0 ? tmp[(size_t)np - 1] : 0.0);
+      if (aj > 0.0 && rnorm_now > 0.0 && wj > 1e-6 * aj * rnorm_now) suspect = true;
       P.pop_back();
       --np;
       G.resize((size_t)np);
@@ -1550,15 +1576,38 @@ int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t 
     for (long long rj : rejected)
       if ((rc = set_state(rj, 0))) return rc;
     rejected.clear();
+    suspect = false;                        // the round found another way down: the refused column gets its chance again
     need_gradient = true;
+  }
+  if (suspect)
+    return fail(nullptr, PRMF_ERR_NUMERIC, "prmf_nnls: ill-conditioned passive set (a descent direction was refused); not solved");
+  // "No free unknown descends" is only as good as the inner products that say so.  Where the residual has become so small next to b
+  // AS A COLUMN SEES IT (sum |a_tj b_t| against sum |a_tj r_t|: rows of wildly different scales) that a gradient below 1e-8 of its
+  // own magnitude could not be told from rounding, an orthogonal factorisation can still make progress and this method cannot know:
+  // it declines.  (Well-scaled data: the ratio is ||b|| / ||r||, and the test only fires for fits exact to 1e-6.)
+  {
+    double bb = 0.0;
+    for (int64_t t = 0; t < len; ++t) bb += b[t] * b[t];
+    if ((rc = residual_norm())) return rc;
+    if (rnorm_now > 1e-10 * std::sqrt(bb)) {
+      std::vector<double> wa((size_t)nvec), ba((size_t)nvec);
+      std::vector<unsigned char> st((size_t)nvec);
+      NN_TRY(nnlsm_gradient(dX, ld, rows, cols, transposed != 0, d.r, d.w, d.wabs, s));
+      NN_TRY(hipMemcpyAsync(wa.data(), d.wabs, (size_t)nvec * 8, hipMemcpyDeviceToHost, s));
+      NN_TRY(hipMemcpyAsync(ba.data(), d.babs, (size_t)nvec * 8, hipMemcpyDeviceToHost, s));
+      NN_TRY(hipMemcpyAsync(st.data(), d.state, (size_t)nvec, hipMemcpyDeviceToHost, s));
+      NN_TRY(hipStreamSynchronize(s));
+      for (int64_t jj = 0; jj < nvec; ++jj)
+        if (st[(size_t)jj] != 1 && ba[(size_t)jj] > 0.0 && c2 * ba[(size_t)jj] > 1e-8 * wa[(size_t)jj])
+          return fail(nullptr, PRMF_ERR_NUMERIC, "prmf_nnls: ill-conditioned problem (the gradient of unknown %lld cannot be resolved to 1e-8); not solved", (long long)jj);
+    }
   }
   for (int a = 0; a < np; ++a) x[P[(size_t)a]] = xs[(size_t)a];
   if (rnorm_out) {
-    std::vector<double> r((size_t)len);
-    NN_TRY(hipMemcpyAsync(r.data(), d.r, (size_t)len * 8, hipMemcpyDeviceToHost, s));
+    NN_TRY(hipMemcpyAsync(rhost.data(), d.r, (size_t)len * 8, hipMemcpyDeviceToHost, s));
     NN_TRY(hipStreamSynchronize(s));
     double ss = 0.0;
-    for (double v : r) ss += v * v;
+    for (double v : rhost) ss += v * v;
     *rnorm_out = std::sqrt(ss);
   }
   if (iterations_out) *iterations_out = iters;

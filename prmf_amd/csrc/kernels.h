@@ -296,8 +296,10 @@ hipError_t quantile_transform_device(double* dX, int64_t m, int64_t n, int64_t l
 // Element t of column j of A is X[t * st_t + j * st_j]  (A = X: st_t = ld, st_j = 1;  A = X^T: st_t = 1, st_j = ld).
 // ---------------------------------------------------------------------------
 hipError_t nnlsm_gradient(const double* X, int64_t ld, int64_t rows, int64_t cols, bool transposed, const double* r, double* w,
-                          hipStream_t s);                                        // w = A^T r, all unknowns
-hipError_t nnlsm_argmax(const double* w, const unsigned char* state, int64_t n, long long* out /* index, bits of w */, hipStream_t s);
+                          double* wabs, hipStream_t s);                          // w = A^T r and wabs[j] = sum_t |a_tj r_t|, all unknowns
+//   the free unknown with the largest w among those with w[j] > c1 * wabs[j] + c2 * babs[j]
+hipError_t nnlsm_argmax(const double* w, const unsigned char* state, const double* wabs, const double* babs, double c1, double c2,
+                        int64_t n, long long* out /* index, bits of w */, hipStream_t s);
 hipError_t nnlsm_column(const double* X, int64_t st_t, int64_t st_j, int64_t len, int64_t j, double* q, hipStream_t s);
 hipError_t nnlsm_dots(const double* X, int64_t st_t, int64_t st_j, int64_t len, const long long* P, int np, const double* q,
                       double* out, hipStream_t s);                               // out[a] = A(:, P[a]) . q

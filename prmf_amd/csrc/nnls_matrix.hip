@@ -36,37 +36,54 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // w[j] = sum_t A(t, j) r[t], A = X (row-major): one lane per column j, rows in order
 __global__ void __launch_bounds__(256)
 nnlsm_grad_cols_kernel(const double* __restrict__ X, int64_t ld, int64_t rows, int64_t cols, const double* __restrict__ r,
-                       double* __restrict__ w) {
+                       double* __restrict__ w, double* __restrict__ wabs) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= cols) return;
-  double acc = 0.0;
-  for (int64_t t = 0; t < rows; ++t) acc += X[t * ld + j] * r[t];
+  double acc = 0.0, mag = 0.0;
+  for (int64_t t = 0; t < rows; ++t) {
+    const double p = X[t * ld + j] * r[t];
+    acc += p;
+    mag += fabs(p);
+  }
   w[j] = acc;
+  wabs[j] = mag;
 }
 
 // w[i] = sum_t X[i][t] r[t], A = X^T: one wave per row i of X
 __global__ void __launch_bounds__(256)
 nnlsm_grad_rows_kernel(const double* __restrict__ X, int64_t ld, int64_t rows, int64_t cols, const double* __restrict__ r,
-                       double* __restrict__ w) {
+                       double* __restrict__ w, double* __restrict__ wabs) {
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= rows) return;
   const double* row = X + i * ld;
-  double acc = 0.0;
-  for (int64_t t = lane; t < cols; t += 64) acc += row[t] * r[t];
+  double acc = 0.0, mag = 0.0;
+  for (int64_t t = lane; t < cols; t += 64) {
+    const double p = row[t] * r[t];
+    acc += p;
+    mag += fabs(p);
+  }
   acc = wave_sum_f64(acc);
-  if (lane == 0) w[i] = acc;
+  mag = wave_sum_f64(mag);
+  if (lane == 0) {
+    w[i] = acc;
+    wabs[i] = mag;
+  }
 }
 
-// the free unknown (state 0) with the largest w: out[0] = its index (-1: none), out[1] = its w (as bits); ties -> lowest index
+// The free unknown (state 0) with the largest gradient among those whose gradient stands out of the rounding noise of its own
+// inner product: w[j] > c1 * sum_t |a_tj r_t|  (the forward error of the sum)  +  c2 * sum_t |a_tj b_t|  (what the residual itself
+// cannot resolve: r = b - A_P s carries eps |b_t| per component).  Per column, so free of row and column scales.
+// out[0] = its index (-1: none), out[1] = its w (as bits); ties -> lowest index
 __global__ void __launch_bounds__(1024)
-nnlsm_argmax_kernel(const double* __restrict__ w, const unsigned char* __restrict__ state, int64_t n, long long* __restrict__ out) {
+nnlsm_argmax_kernel(const double* __restrict__ w, const unsigned char* __restrict__ state, const double* __restrict__ wabs,
+                    const double* __restrict__ babs, double c1, double c2, int64_t n, long long* __restrict__ out) {
   __shared__ double bv[1024];
   __shared__ long long bi[1024];
   double best = 0.0;
   long long at = -1;
   for (int64_t j = threadIdx.x; j < n; j += 1024)
-    if (state[j] == 0 && (at < 0 || w[j] > best)) {
+    if (state[j] == 0 && w[j] > c1 * wabs[j] + c2 * babs[j] && (at < 0 || w[j] > best)) {
       best = w[j];
       at = j;
     }
@@ -127,14 +144,15 @@ nnlsm_residual_kernel(const double* __restrict__ X, int64_t st_t, int64_t st_j, 
 }  // namespace
 
 hipError_t nnlsm_gradient(const double* X, int64_t ld, int64_t rows, int64_t cols, bool transposed, const double* r, double* w,
-                          hipStream_t s) {
-  if (!transposed) nnlsm_grad_cols_kernel<<<dim3((unsigned)((cols + 255) / 256)), 256, 0, s>>>(X, ld, rows, cols, r, w);
-  else nnlsm_grad_rows_kernel<<<dim3((unsigned)((rows + 3) / 4)), 256, 0, s>>>(X, ld, rows, cols, r, w);
+                          double* wabs, hipStream_t s) {
+  if (!transposed) nnlsm_grad_cols_kernel<<<dim3((unsigned)((cols + 255) / 256)), 256, 0, s>>>(X, ld, rows, cols, r, w, wabs);
+  else nnlsm_grad_rows_kernel<<<dim3((unsigned)((rows + 3) / 4)), 256, 0, s>>>(X, ld, rows, cols, r, w, wabs);
   return hipGetLastError();
 }
 
-hipError_t nnlsm_argmax(const double* w, const unsigned char* state, int64_t n, long long* out, hipStream_t s) {
-  nnlsm_argmax_kernel<<<1, 1024, 0, s>>>(w, state, n, out);
+hipError_t nnlsm_argmax(const double* w, const unsigned char* state, const double* wabs, const double* babs, double c1, double c2,
+                        int64_t n, long long* out, hipStream_t s) {
+  nnlsm_argmax_kernel<<<1, 1024, 0, s>>>(w, state, wabs, babs, c1, c2, n, out);
   return hipGetLastError();
 }
 

@@ -98,6 +98,11 @@ def quantile_transform(X, n_quantiles=1000, random_state=None, device=0, copy=Tr
     return out
 
 
+class NnlsDeclined(Exception):
+    """prmf_nnls met a problem whose conditioning is beyond its normal-equations factor and returned nothing; the caller solves it
+    with scipy.optimize.nnls (an orthogonal factorisation of the whole matrix) as the reference does."""
+
+
 class DeviceNnls(object):
     """scipy.optimize.nnls(X, b) / nnls(X.T, b) for ONE data matrix and many right-hand sides, on the GPU (`prmf_nnls`,
     prmf_amd/csrc/nnls_matrix.hip): X is uploaded once as float64 and never copied or transposed again.  The two solves per
@@ -129,6 +134,9 @@ class DeviceNnls(object):
         rc = self.lib.prmf_nnls(self.device, C.c_void_p(self.Xd.data_ptr()), m, n, n, 1 if transposed else 0,
                                 b.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.byref(rnorm), C.byref(iters), 0, stream)
         if rc == _capi.PRMF_ERR_NUMERIC:
+            msg = self.lib.prmf_last_error(None).decode()
+            if "ill-conditioned" in msg:
+                raise NnlsDeclined(msg)
             raise RuntimeError("Maximum number of iterations reached.")          # scipy's words
         if rc != _capi.PRMF_OK:
             raise _capi.PrmfError(rc, self.lib.prmf_last_error(None).decode())

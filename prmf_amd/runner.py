@@ -143,9 +143,14 @@ def pathway_to_vec(X, G, nodelist, rel_weight=5):
 def nmf_init_u(X, v, solver=None):
     """prmf_runner.py:308-317: u = nnls(X^T, v), scaled.  solver: a prmf_amd.preprocess.DeviceNnls holding X (the GPU's
     Lawson-Hanson); None: scipy's on the host, as the reference calls it."""
+    u = None
     if solver is not None:
-        u, res = solver.nnls(v.flatten(), transposed=True)
-    else:
+        from .preprocess import NnlsDeclined
+        try:
+            u, res = solver.nnls(v.flatten(), transposed=True)
+        except NnlsDeclined:
+            pass                                     # conditioning beyond the GPU solver's factor: scipy's, as the reference
+    if u is None:
         import scipy.optimize
         u, res = scipy.optimize.nnls(X.transpose(), v.flatten())
     u = u / np.linalg.norm(u) ** 2
@@ -154,9 +159,14 @@ def nmf_init_u(X, v, solver=None):
 
 def nmf_init_v(X, u, solver=None):
     """prmf_runner.py:319-334: v = nnls(X, u), scaled."""
+    v = None
     if solver is not None:
-        v, res = solver.nnls(u.flatten(), transposed=False)
-    else:
+        from .preprocess import NnlsDeclined
+        try:
+            v, res = solver.nnls(u.flatten(), transposed=False)
+        except NnlsDeclined:
+            pass
+    if v is None:
         import scipy.optimize
         v, res = scipy.optimize.nnls(X, u.flatten())
     v = v / np.linalg.norm(v) ** 2

@@ -81,3 +81,37 @@ def test_degenerate_inputs():
         s.nnls(np.ones(21))
     with pytest.raises(ValueError):
         s.nnls(np.full(20, np.nan))
+
+
+def test_a_problem_beyond_the_normal_equations_is_declined_not_answered():
+    """Rows scaled over twelve orders of magnitude with b inside the cone: the gradients that would still descend cannot be told
+    from rounding in float64 inner products.  prmf_nnls says so (NnlsDeclined) instead of returning its stalled point, and the
+    initialiser then solves that problem with scipy as the reference does."""
+    from prmf_amd.preprocess import NnlsDeclined
+    from prmf_amd.runner import nmf_init_v
+    rs = np.random.RandomState(2)
+    declined = 0
+    for trial in range(12):
+        m, n = 60 + 10 * trial, 90 + 7 * trial
+        X = rs.rand(m, n) * 10.0 ** rs.randint(-6, 6, size=(m, 1))          # A = X: equations (rows) of wildly different scales
+        b = X.dot(np.maximum(rs.randn(n), 0))
+        solver = DeviceNnls(X)
+        try:
+            got, gres = solver.nnls(b)
+        except NnlsDeclined:
+            declined += 1
+            try:                                                            # the command line's path: scipy takes over --
+                want, wres = scipy.optimize.nnls(X, b)
+            except RuntimeError as e:                                       # -- and may give up itself, in its own words
+                with pytest.raises(RuntimeError, match=str(e)[:20]):
+                    nmf_init_v(X, b.reshape(-1, 1), solver)
+                continue
+            v, res = nmf_init_v(X, b.reshape(-1, 1), solver)
+            assert np.array_equal(v.ravel(), want / np.linalg.norm(want) ** 2) and res == wres
+            continue
+        r = b - X.dot(got)                                                  # answered: then it is optimal
+        w = X.T.dot(r)
+        tol = 1e-9 * (np.abs(X).T.dot(np.abs(r)) + np.abs(X).T.dot(np.abs(b)))
+        assert (w[got == 0] <= tol[got == 0]).all() and (np.abs(w[got > 0]) <= tol[got > 0]).all()
+        assert np.linalg.norm(r) <= np.linalg.norm(b - X.dot(scipy.optimize.nnls(X, b)[0])) + 1e-9 * np.linalg.norm(b)
+    assert declined >= 1
