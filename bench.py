@@ -206,22 +206,27 @@ def outer_loop(torch, Xd, n, k, P, x_dtype, seed, iterations=100):
     calls = []
     solver.PrmfEngine.step = timed_step
     try:
-        for _ in range(2):
+        # first call of the process, a warm one (both from the float32 HOST matrix: the upload is inside), and one with the
+        # matrix already on the GPU in the storage type (what the CLI's on-device normalisation hands over)
+        for src in (X, X, Xd):
             np.random.seed(seed)
             marks.clear()
             t0 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
-                solver.nmf_pathway(X, None, library=lib, k_latent=k, max_iter=iterations, x_dtype=x_dtype, tol=0.0)
+                solver.nmf_pathway(src, None, library=lib, k_latent=k, max_iter=iterations, x_dtype=x_dtype, tol=0.0)
             calls.append((time.perf_counter() - t0, sum(marks), len(marks)))
     finally:
         solver.PrmfEngine.step = orig_step
-    (t_first, in_first, rounds), (t_warm, in_warm, _) = calls
+    (t_first, in_first, rounds), (t_warm, in_warm, _), (t_dev, in_dev, _) = calls
     return {"what": "nmf_pathway (outer solver, prmf_runner.py:556-792): %d iterations = %d rounds of 10 with pathway sampling, "
-                    "candidate scoring / restrict / matching, best-iterate copies; float32 host X uploaded inside" % (iterations, rounds),
+                    "candidate scoring / restrict / matching, best-iterate copies; float32 host X uploaded inside "
+                    "(`*_device_resident`: X already on the GPU in the storage type)" % (iterations, rounds),
             "iterations": iterations, "rounds": rounds,
             "seconds_first_call": t_first, "seconds_warm_call": t_warm, "seconds_inner_iterations": in_warm,
             "it_per_s_warm": iterations / t_warm, "it_per_s_first_call": iterations / t_first,
-            "it_per_s_inner_only": iterations / in_warm}
+            "it_per_s_inner_only": iterations / in_warm,
+            "seconds_device_resident": t_dev, "it_per_s_device_resident": iterations / t_dev,
+            "host_matrix_gb": X.nbytes / 1e9}
 
 
 def run_rank(args, ranks, proc):
@@ -233,6 +238,7 @@ def run_rank(args, ranks, proc):
     from prmf_amd.solver import PrmfEngine
 
     world, rank = ranks.world, ranks.rank
+    multi = ranks.multi          # several ranks -- or ONE rank driven through the multi-rank code (PRMF_FORCE_RANK_PATH, prmf_amd/ranks.py)
     dev_index = proc["dev_index"] if proc else (ranks.device_index or 0)
     dev = "cuda:%d" % dev_index
     m, n, k, P, x_dtype = syn.CONFIGS[args.workload]
@@ -240,10 +246,10 @@ def run_rank(args, ranks, proc):
     lo, hi = syn.shard_rows(m, world, rank)
     Xd = syn.x_rows_torch(torch, dev, args.seed, n, k, lo, hi, tdt)
     eng = PrmfEngine(hi - lo, n, k, x_dtype=x_dtype, device=dev_index, nranks=world, rank=rank,
-                     dist_mode=args.dist_mode if world > 1 else None, eager_objective=args.eager_objective)
-    nsq = ranks.sum_float(eng.local_norm_sq(Xd), dev)
+                     dist_mode=args.dist_mode if multi else None, eager_objective=args.eager_objective)
+    nsq = ranks.sum_float(eng.set_x_local(Xd), dev)           # one pass: padded copy, padded transpose, ||X||^2 of this rank's rows
     norm_x = math.sqrt(nsq)
-    eng.set_x(Xd, norm_x_sq=nsq)
+    eng.set_norm_x_sq(nsq)
     pathways = syn.tree_pathways(n, P, 300, args.seed)
     eng.set_library(PathwayLibrary.from_edge_lists(n, pathways))
     active = [kk % P for kk in range(k)]
@@ -254,7 +260,7 @@ def run_rank(args, ranks, proc):
     U0, V0 = U.clone(), V.clone()
 
     runner = None
-    if world > 1:
+    if multi:
         from prmf_amd.distributed import DistributedPrmf
         # The driver-visible line never reports a slow path silently: the in-library RCCL step, or an error on every rank.
         # (rehearsal with the RCCL test double, PRMF_RCCL_LIB: the in-library step although the backend is gloo;
@@ -309,7 +315,7 @@ def run_rank(args, ranks, proc):
     bytes_iter = 2.0 * ml * n * eb + 12.0 * (ml + n) * k + 8.0 * nnz_active + 12.0 * sup_active
 
     extras = {}
-    if world == 1 and not args.no_extras:
+    if not multi and not args.no_extras:
         # (1) calibration: a pure non-temporal stream of the resident X and X^T on THIS box, right next to the timing pass
         sx_ms, sx_b = eng.stream_read("x", 10)
         st_ms, st_b = eng.stream_read("xt", 10)
@@ -344,7 +350,7 @@ def run_rank(args, ranks, proc):
     if rank == 0:
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.workload)
-        if world == 1 and os.path.exists(tpath):
+        if not multi and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_sweep_launch")
         native = runner.native if runner else None
         out = {
@@ -357,8 +363,8 @@ def run_rank(args, ranks, proc):
                                    % (args.workload, m, n, x_dtype, k, P),
                        "samples": m, "genes": n, "k_latent": k, "pathways": P,
                        # 2 sweeps + 2 fused epilogues at every k (k > 64: the column-split epilogue); per-iteration objective: + 3
-                       "launches_per_iteration": None if world > 1 else (7 if args.eager_objective else 4),
-                       "parallelism": ("single GPU" if world == 1 else
+                       "launches_per_iteration": None if multi else (7 if args.eager_objective else 4),
+                       "parallelism": ("single GPU" if not multi else
                                        "X row-sharded x%d, V update %s, RCCL %s" % (
                                            world, eng.dist_mode, "in-library" if native else "host-driven"))},
             "recon_err": objs[-1]["recon"], "objective": objs[-1]["obj"],
@@ -378,7 +384,7 @@ def run_rank(args, ranks, proc):
             out["update_only"] = extras["update_only"]
         out["reps"] = {"n": len(rep_s), "ms_per_step_median": 1e3 * elapsed / args.steps,
                        "ms_per_step_min": 1e3 * rep_s[0] / args.steps, "ms_per_step_max": 1e3 * rep_s[-1] / args.steps}
-        if world > 1:
+        if multi:
             ci = eng.comm_info()
             out["distributed"] = {
                 "mode": ci["mode"], "collectives": "in-library RCCL (prmf_step_dist)" if native else "host-driven (torch.distributed)",
@@ -392,7 +398,7 @@ def run_rank(args, ranks, proc):
             out["config"]["rehearsal"] = ("ranks share GPU(s), exchanges through %s: the sequence is the real one, the time is not a measurement"
                                           % ("the RCCL test double" if os.environ.get("PRMF_RCCL_LIB") else proc["backend"]))
     eng.close()
-    if rank == 0 and world == 1:
+    if rank == 0 and not multi:
         if not args.no_extras and args.workload in ("c2", "c3", "c3f32", "c5shard", "c5shardf32"):
             out["outer_loop"] = outer_loop(torch, Xd, n, k, P, x_dtype, args.seed)
         if not args.no_cpu_baseline:
@@ -404,7 +410,10 @@ def run_rank(args, ranks, proc):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:                                  # one process per GPU, started by torch.distributed.run
+    # PRMF_FORCE_RANK_PATH=1 under the launcher with ONE process: the branch below at world size 1 -- NCCL process group, rank
+    # protocol over it, RCCL communicator bootstrap, prmf_step_dist -- i.e. what the 8-GPU launch executes, on a one-GPU box
+    forced = bool(os.environ.get("PRMF_FORCE_RANK_PATH")) and "RANK" in os.environ
+    if world > 1 or forced:                        # one process per GPU, started by torch.distributed.run
         import torch
         import torch.distributed as dist
         from prmf_amd.ranks import TorchRanks

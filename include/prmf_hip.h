@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PRMF_ABI_VERSION 2
+#define PRMF_ABI_VERSION 3   /* 3: additions only (prmf_set_x_device / _host, prmf_set_norm_x_sq, prmf_match_terms) */
 
 typedef struct prmf_ctx prmf_ctx;
 
@@ -104,6 +104,32 @@ int prmf_destroy(prmf_ctx* ctx);
  * Replaces: the `X` argument of nmf_manifold_vec_update (prmf_runner.py:374).
  */
 int prmf_set_x(prmf_ctx* ctx, const void* dX, int64_t ld, double norm_x_sq, void* stream);
+
+/*
+ * The same upload from a source of ANY float type, with ||X||^2 computed on the way (ABI 3).  One pass over the source
+ * narrows every value to the context's storage type (round to nearest even at every step: f64 -> f32, f32 -> bf16,
+ * f64 -> f32 -> bf16 -- what `Tensor.to(dtype)` does), writes the padded copy and the padded transpose, and sums the
+ * squares of the STORED values in float64 in a fixed tree that does not depend on how the rows arrive (64 x 64 tiles
+ * anchored at the first row; prmf_sum_squares uses the same tree).  *local_norm_sq_out (nullable) = that sum over this
+ * rank's rows; it also becomes the context's ||X||^2 -- with nranks > 1 the caller adds the ranks' values and passes the
+ * total to prmf_set_norm_x_sq.  Both calls synchronise.
+ *   prmf_set_x_device: dX is a DEVICE matrix (m_local x n, leading dimension ld elements of src_dtype).
+ *   prmf_set_x_host:   hX is a HOST matrix (pageable memory is fine): it travels in chunks of ~32 MB; with n_threads > 0
+ *       (n_threads < 0: as many as the host has, at most 16) and a source wider than the storage type, worker threads
+ *       narrow chunk i + 1 into pinned memory while chunk i crosses PCIe and the layout kernels take chunk i - 1 -- half
+ *       (f32 -> bf16, f64 -> f32) or a quarter (f64 -> bf16) of the bytes on the wire; n_threads = 0: every chunk travels as
+ *       it is and is narrowed on the device.  The stored bits are the same either way.  `stream` is synchronised on entry
+ *       (nothing of the caller's may still read the old X); the work runs on streams of the library's own.  The staging
+ *       buffers (2 x 32 MB pinned, 2 x 32 MB on the device) are kept by the process for the next call;
+ *       prmf_release_staging() frees them.
+ * Replaces: the `X` argument of nmf_manifold_vec_update (prmf_runner.py:374) and `norm_X = np.linalg.norm(X)` (:640).
+ */
+enum prmf_src_dtype { PRMF_SRC_F32 = 0, PRMF_SRC_BF16 = 1, PRMF_SRC_F64 = 2 };
+int prmf_set_x_device(prmf_ctx* ctx, const void* dX, int src_dtype, int64_t ld, double* local_norm_sq_out, void* stream);
+int prmf_set_x_host(prmf_ctx* ctx, const void* hX, int src_dtype, int64_t ld, int n_threads, double* local_norm_sq_out,
+                    void* stream);
+int prmf_set_norm_x_sq(prmf_ctx* ctx, double norm_x_sq);
+int prmf_release_staging(void);
 
 /*
  * Upload the whole pathway library once (host pointers; copied to the device).
@@ -262,6 +288,16 @@ int prmf_step_dist(prmf_ctx* ctx, float* dU, float* dV, int n_steps,
  * dV: n x k float32 device buffer.  Synchronises `stream`.
  */
 int prmf_score_candidates(prmf_ctx* ctx, const float* dV, double* scores_out, void* stream);
+
+/*
+ * The terms of the final latent <-> pathway matching, `force_distinct_lapls` (prmf_runner.py:209-258), for every latent
+ * column kk and every library pathway p (host buffers, k*P doubles each; float64 arithmetic on the float32 V):
+ *     quad_out[kk*P + p]   = v_kk^T L_p v_kk          the un-normalised Laplacian L = D - W (:232: L.dot(v).dot(v))
+ *     ignore_out[kk*P + p] = sum_{i in S_p} 1 / (V[i, kk] + 1)      (:235 for k2 = kk and kk's pathway p)
+ * so that V need not be downloaded for the k x (remaining candidates) sparse products of that function; the caller forms
+ * the weights 1 / (gamma quad + delta ignore) and runs the matching.  Synchronises `stream`.  (ABI 3)
+ */
+int prmf_match_terms(prmf_ctx* ctx, const float* dV, double* quad_out, double* ignore_out, void* stream);
 
 /*
  * Held-out reconstruction error, replaces measure_cv_performance

@@ -42,6 +42,12 @@ int prmf_debug_bump_cursor(prmf_ctx* ctx);
  * tools/placement_probe.py */
 int prmf_debug_swap(prmf_ctx* a, prmf_ctx* b, int which);
 
+/* The resident copies as the sweeps read them, padding included: which = 0: X, 1: X^T; prmf_debug_resident_shape gives
+ * the padded rows and the leading dimension (elements of the storage type), prmf_debug_resident_x copies rows x ld elements
+ * to HOST memory (synchronises the device).  tests/test_gpu_setx.py compares every upload path bit for bit. */
+int prmf_debug_resident_shape(const prmf_ctx* ctx, int which, int64_t* rows, int64_t* ld);
+int prmf_debug_resident_x(prmf_ctx* ctx, int which, void* out_host);
+
 /* The sweep planner's decision for one sweep C = A (rows x depth) * packed factor (depth x k) -- pure host arithmetic, no GPU
  * touched (the CPU test suite pins the plan of every benchmark shape with it).  x_dtype as in prmf_create; n_cus = compute
  * units of the device (256 on MI355X).  out[8] = { waves per workgroup, 32-row tiles per wave, panel rows, workgroups,

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libprmf_hip.so")
-SOURCES = ["gemm.hip", "update.hip", "residual.hip", "nnls.hip", "nnls_matrix.hip", "prep.hip", "textio.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "setx.hip", "update.hip", "residual.hip", "nnls.hip", "nnls_matrix.hip", "prep.hip", "textio.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I/opt/rocm/include"]
 
 

@@ -10,8 +10,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libprmf_hip.so")
 
-PRMF_ABI_VERSION = 2
+PRMF_ABI_VERSION = 3
 PRMF_X_F32, PRMF_X_BF16 = 0, 1
+PRMF_SRC_F32, PRMF_SRC_BF16, PRMF_SRC_F64 = 0, 1, 2
 PRMF_OBJ_STRIDE = 10
 PRMF_OBJ_FLAGS, PRMF_OBJ_RECON_SQ_IDENTITY = 8, 9
 PRMF_RECON_DIRECT, PRMF_RECON_IMPRECISE, PRMF_RECON_CLAMPED = 1, 2, 4
@@ -53,6 +54,11 @@ SIGNATURES = {
     "prmf_create": (_i, [C.POINTER(_vp), _i, _i64, _i64, _i, _i, _i, _i, _u]),
     "prmf_destroy": (_i, [_vp]),
     "prmf_set_x": (_i, [_vp, _vp, _i64, _d, _vp]),
+    "prmf_set_x_device": (_i, [_vp, _vp, _i, _i64, C.POINTER(_d), _vp]),
+    "prmf_set_x_host": (_i, [_vp, _vp, _i, _i64, _i, C.POINTER(_d), _vp]),
+    "prmf_set_norm_x_sq": (_i, [_vp, _d]),
+    "prmf_release_staging": (_i, []),
+    "prmf_match_terms": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "prmf_set_pathway_library": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "prmf_set_active": (_i, [_vp, _vp, _vp]),
     "prmf_invalidate_factors": (_i, [_vp]),
@@ -100,6 +106,8 @@ DEBUG_SIGNATURES = {
     "prmf_debug_plan_sweep": (_i, [_i, C.c_longlong, C.c_longlong, _i, _i, C.POINTER(_i)]),
     "prmf_debug_stream": (_i, [_vp, _i, _i, C.POINTER(_d), C.POINTER(_i64), _vp]),
     "prmf_debug_sync_stream": (_i, [_vp, _vp]),
+    "prmf_debug_resident_shape": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "prmf_debug_resident_x": (_i, [_vp, _i, _vp]),
     "prmf_debug_set_tail_probe": (_i, [_vp, _i, _vp, _i]),
 }
 

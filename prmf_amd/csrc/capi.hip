@@ -12,7 +12,11 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <memory>
 #include <new>
 #include <thread>
 #include <utility>
@@ -58,6 +62,10 @@ struct prmf_ctx {
   int64_t Kpad_x = 0, Kpad_xt = 0;    // reduction lengths (n resp. m, padded to 64)
   double norm_x_sq = 0.0;
   bool have_x = false;
+  // scratch of the one-pass layout kernels (setx.hip): tile sums, tile-row sums, the total
+  double* setx_partial = nullptr;
+  double* setx_rowsum = nullptr;
+  double* setx_total = nullptr;
 
   // packed factors + sweep slabs
   void* Vp = nullptr;
@@ -599,6 +607,9 @@ int prmf_destroy(prmf_ctx* c) {
   (void)hipDeviceSynchronize();
   dev_free(c->X);
   dev_free(c->XT);
+  dev_free(c->setx_partial);
+  dev_free(c->setx_rowsum);
+  dev_free(c->setx_total);
   dev_free(c->Vp);
   dev_free(c->Up);
   dev_free(c->slabs);
@@ -650,14 +661,14 @@ int prmf_destroy(prmf_ctx* c) {
   return PRMF_OK;
 }
 
-int prmf_set_x(prmf_ctx* c, const void* dX, int64_t ld, double norm_x_sq, void* stream) {
-  if (!c) return PRMF_ERR_ARG;
-  if (c->m > 0 && !dX) return fail(c, PRMF_ERR_ARG, "dX is NULL");
-  if (ld < c->n) return fail(c, PRMF_ERR_ARG, "ld=%lld < n=%lld", (long long)ld, (long long)c->n);
-  if (!(norm_x_sq >= 0.0) || !std::isfinite(norm_x_sq)) return fail(c, PRMF_ERR_ARG, "norm_x_sq must be finite and >= 0");
+namespace {
+
+// ---- X enters the library (setx.hip) -------------------------------------------------------------------------------
+int src_elem_bytes(int src_dtype) { return src_dtype == PRMF_SRC_F64 ? 8 : (src_dtype == PRMF_SRC_BF16 ? 2 : 4); }
+
+// buffers of the resident copies and the scratch of the layout kernels; the padding is zeroed on `s`
+int setx_prepare(prmf_ctx* c, hipStream_t s) {
   int rc;
-  if ((rc = set_device(c))) return rc;
-  hipStream_t s = (hipStream_t)stream;
   const int eb = elem_bytes(c->x_dtype);
   const int64_t rows_x = round_up(c->m > 0 ? c->m : 1, M_PAD), rows_xt = round_up(c->n, M_PAD);
   // row stride = padded reduction length.  Extra padding between the rows (128 B ... 2 KiB, either copy) was measured again in
@@ -671,12 +682,298 @@ int prmf_set_x(prmf_ctx* c, const void* dX, int64_t ld, double norm_x_sq, void* 
     if ((rc = dev_alloc(c, (char**)&c->X, c->x_bytes, false))) return rc;
     if ((rc = dev_alloc(c, (char**)&c->XT, c->xt_bytes, false))) return rc;
   }
+  if (!c->setx_partial) {
+    if ((rc = dev_alloc(c, &c->setx_partial, (size_t)setx_partial_doubles(c->m, c->n), false))) return rc;
+    if ((rc = dev_alloc(c, &c->setx_rowsum, (size_t)((c->m + 63) / 64), false))) return rc;
+    if ((rc = dev_alloc(c, &c->setx_total, 1))) return rc;
+  }
   HIP_TRY(c, hipMemsetAsync(c->X, 0, c->x_bytes, s));       // the padding (rows >= m, columns >= n) must read as zero
   HIP_TRY(c, hipMemsetAsync(c->XT, 0, c->xt_bytes, s));
-  HIP_TRY(c, launch_copy_pad(c->x_dtype, dX, ld, c->m, c->n, c->X, c->ldx, s));
-  HIP_TRY(c, launch_transpose_pad(c->x_dtype, dX, ld, c->m, c->n, c->XT, c->ldxt, s));
+  return PRMF_OK;
+}
+
+// `rows` rows of the source, starting at row `row0` (a multiple of 64) of this rank's matrix, into X, X^T and the tile-row sums
+int setx_rows(prmf_ctx* c, int src_dtype, const void* src, int64_t ld, int64_t row0, int64_t rows, hipStream_t s) {
+  const int eb = elem_bytes(c->x_dtype);
+  HIP_TRY(c, launch_setx_rows(src_dtype, c->x_dtype, src, ld, rows, c->n, (char*)c->X + row0 * c->ldx * eb, c->ldx,
+                              (char*)c->XT + row0 * eb, c->ldxt, c->setx_partial, c->setx_rowsum + row0 / 64, s));
+  return PRMF_OK;
+}
+
+// Staging of prmf_set_x_host: two pinned host buffers (narrowed chunks), two device buffers (chunks as they arrive), a copy
+// stream and a kernel stream (non-blocking: the pageable copies of the direct path run on the null stream and must not
+// wait for the layout kernels of the chunk before).  Pinning memory costs milliseconds, a solve's setup has none to
+// spare, so ONE set per device is kept by the process between calls (prmf_release_staging frees them); concurrent callers
+// (thread ranks) get sets of their own, which are freed on release.
+struct XStage {
+  int device = -1;
+  void* hb[2] = {nullptr, nullptr};
+  void* ds[2] = {nullptr, nullptr};
+  size_t hcap = 0, dcap = 0;
+  hipStream_t sc = nullptr, sk = nullptr;
+  hipEvent_t evc[2] = {nullptr, nullptr}, evk[2] = {nullptr, nullptr};
+};
+std::mutex g_stage_mu;
+std::vector<XStage*> g_stage_idle;
+
+void stage_free(XStage* st) {
+  if (!st) return;
+  (void)hipSetDevice(st->device);
+  for (int b = 0; b < 2; ++b) {
+    if (st->hb[b]) (void)hipHostFree(st->hb[b]);
+    if (st->ds[b]) (void)hipFree(st->ds[b]);
+    if (st->evc[b]) (void)hipEventDestroy(st->evc[b]);
+    if (st->evk[b]) (void)hipEventDestroy(st->evk[b]);
+  }
+  if (st->sc) (void)hipStreamDestroy(st->sc);
+  if (st->sk) (void)hipStreamDestroy(st->sk);
+  delete st;
+}
+
+XStage* stage_acquire(prmf_ctx* c, size_t hbytes, size_t dbytes) {
+  XStage* st = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_stage_mu);
+    for (size_t i = 0; i < g_stage_idle.size(); ++i)
+      if (g_stage_idle[i]->device == c->device) {
+        st = g_stage_idle[i];
+        g_stage_idle.erase(g_stage_idle.begin() + (long)i);
+        break;
+      }
+  }
+  if (!st) {
+    st = new (std::nothrow) XStage();
+    if (!st) { fail(c, PRMF_ERR_HIP, "out of host memory"); return nullptr; }
+    st->device = c->device;
+    bool ok = hipStreamCreateWithFlags(&st->sc, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&st->sk, hipStreamNonBlocking) == hipSuccess;
+    for (int b = 0; b < 2 && ok; ++b)
+      ok = hipEventCreateWithFlags(&st->evc[b], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&st->evk[b], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { fail(c, PRMF_ERR_HIP, "staging streams / events could not be created"); stage_free(st); return nullptr; }
+  }
+  for (int b = 0; b < 2; ++b) {
+    if (hbytes > st->hcap) {
+      if (st->hb[b]) (void)hipHostFree(st->hb[b]);
+      st->hb[b] = nullptr;
+      if (hipHostMalloc(&st->hb[b], hbytes, hipHostMallocDefault) != hipSuccess) {
+        fail(c, PRMF_ERR_HIP, "hipHostMalloc(%zu bytes of staging) failed", hbytes);
+        st->hcap = 0;
+        stage_free(st);
+        return nullptr;
+      }
+    }
+    if (dbytes > st->dcap) {
+      if (st->ds[b]) (void)hipFree(st->ds[b]);
+      st->ds[b] = nullptr;
+      if (hipMalloc(&st->ds[b], dbytes) != hipSuccess) {
+        fail(c, PRMF_ERR_HIP, "hipMalloc(%zu bytes of staging) failed", dbytes);
+        st->dcap = 0;
+        stage_free(st);
+        return nullptr;
+      }
+    }
+  }
+  if (hbytes > st->hcap) st->hcap = hbytes;
+  if (dbytes > st->dcap) st->dcap = dbytes;
+  return st;
+}
+
+void stage_release(XStage* st) {
+  {
+    std::lock_guard<std::mutex> lock(g_stage_mu);
+    bool have = false;
+    for (XStage* o : g_stage_idle) have = have || o->device == st->device;
+    if (!have) {
+      g_stage_idle.push_back(st);
+      return;
+    }
+  }
+  stage_free(st);
+}
+
+// n worker threads that run one job at a time, each on its share (the narrowing of a chunk's rows)
+class RowWorkers {
+ public:
+  explicit RowWorkers(int n) : n_(n) {
+    for (int i = 0; i < n; ++i) th_.emplace_back([this, i] { loop(i); });
+  }
+  ~RowWorkers() {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      stop_ = true;
+    }
+    go_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  void run(const std::function<void(int, int)>& job) {
+    std::unique_lock<std::mutex> lock(mu_);
+    job_ = &job;
+    pending_ = n_;
+    ++gen_;
+    go_.notify_all();
+    done_.wait(lock, [this] { return pending_ == 0; });
+  }
+
+ private:
+  void loop(int i) {
+    unsigned seen = 0;
+    for (;;) {
+      const std::function<void(int, int)>* job;
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        go_.wait(lock, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+        job = job_;
+      }
+      (*job)(i, n_);
+      {
+        std::lock_guard<std::mutex> lock(mu_);
+        if (--pending_ == 0) done_.notify_all();
+      }
+    }
+  }
+  int n_;
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable go_, done_;
+  const std::function<void(int, int)>* job_ = nullptr;
+  unsigned gen_ = 0;
+  int pending_ = 0;
+  bool stop_ = false;
+};
+
+int setx_finish(prmf_ctx* c, double* local_out, hipStream_t s) {
+  double total = 0.0;
+  if (c->m > 0) {
+    HIP_TRY(c, launch_setx_total(c->setx_rowsum, (c->m + 63) / 64, c->setx_total, s));
+    HIP_TRY(c, hipMemcpyAsync(&total, c->setx_total, sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(c, hipStreamSynchronize(s));
+  c->norm_x_sq = total;
+  c->have_x = true;
+  if (local_out) *local_out = total;
+  return PRMF_OK;
+}
+
+}  // namespace
+
+int prmf_set_x(prmf_ctx* c, const void* dX, int64_t ld, double norm_x_sq, void* stream) {
+  if (!c) return PRMF_ERR_ARG;
+  if (c->m > 0 && !dX) return fail(c, PRMF_ERR_ARG, "dX is NULL");
+  if (ld < c->n) return fail(c, PRMF_ERR_ARG, "ld=%lld < n=%lld", (long long)ld, (long long)c->n);
+  if (!(norm_x_sq >= 0.0) || !std::isfinite(norm_x_sq)) return fail(c, PRMF_ERR_ARG, "norm_x_sq must be finite and >= 0");
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = setx_prepare(c, s))) return rc;
+  if (c->m > 0 && (rc = setx_rows(c, c->x_dtype, dX, ld, 0, c->m, s))) return rc;
   c->norm_x_sq = norm_x_sq;
   c->have_x = true;
+  return PRMF_OK;
+}
+
+int prmf_set_norm_x_sq(prmf_ctx* c, double norm_x_sq) {
+  if (!c) return PRMF_ERR_ARG;
+  if (!(norm_x_sq >= 0.0) || !std::isfinite(norm_x_sq)) return fail(c, PRMF_ERR_ARG, "norm_x_sq must be finite and >= 0");
+  c->norm_x_sq = norm_x_sq;
+  return PRMF_OK;
+}
+
+int prmf_set_x_device(prmf_ctx* c, const void* dX, int src_dtype, int64_t ld, double* local_norm_sq_out, void* stream) {
+  if (!c) return PRMF_ERR_ARG;
+  if (c->m > 0 && !dX) return fail(c, PRMF_ERR_ARG, "dX is NULL");
+  if (ld < c->n) return fail(c, PRMF_ERR_ARG, "ld=%lld < n=%lld", (long long)ld, (long long)c->n);
+  if (src_dtype != PRMF_SRC_F32 && src_dtype != PRMF_SRC_BF16 && src_dtype != PRMF_SRC_F64) return fail(c, PRMF_ERR_ARG, "bad src_dtype %d", src_dtype);
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = setx_prepare(c, s))) return rc;
+  if (c->m > 0 && (rc = setx_rows(c, src_dtype, dX, ld, 0, c->m, s))) return rc;
+  return setx_finish(c, local_norm_sq_out, s);
+}
+
+int prmf_set_x_host(prmf_ctx* c, const void* hX, int src_dtype, int64_t ld, int n_threads, double* local_norm_sq_out, void* stream) {
+  if (!c) return PRMF_ERR_ARG;
+  if (c->m > 0 && !hX) return fail(c, PRMF_ERR_ARG, "hX is NULL");
+  if (ld < c->n) return fail(c, PRMF_ERR_ARG, "ld=%lld < n=%lld", (long long)ld, (long long)c->n);
+  if (src_dtype != PRMF_SRC_F32 && src_dtype != PRMF_SRC_BF16 && src_dtype != PRMF_SRC_F64) return fail(c, PRMF_ERR_ARG, "bad src_dtype %d", src_dtype);
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  HIP_TRY(c, hipStreamSynchronize((hipStream_t)stream));      // nothing queued by the caller still reads the old X
+  const int eb = elem_bytes(c->x_dtype), seb = src_elem_bytes(src_dtype);
+  // Narrow on the host when that halves (or quarters) what crosses PCIe: worker threads convert chunk i + 1 into pinned memory
+  // while the DMA engine moves chunk i and the layout kernels take chunk i - 1.  n_threads = 0 (or a source no wider than
+  // the storage type): the chunk travels as it is (pageable copy) and is narrowed by the layout kernel.
+  int workers = n_threads;
+  if (workers < 0) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    workers = hw > 16 ? 16 : (hw > 1 ? (int)hw : 1);
+  }
+  const bool narrow = workers > 0 && seb > eb && c->m > 0;
+  const int64_t target = 32LL << 20;                          // bytes of SOURCE per chunk
+  int64_t rows_chunk = target / (c->n * (int64_t)seb) / 64 * 64;
+  if (rows_chunk < 64) rows_chunk = 64;
+  if (rows_chunk > round_up(c->m > 0 ? c->m : 1, 64)) rows_chunk = round_up(c->m > 0 ? c->m : 1, 64);
+  const int trav_dtype = narrow ? (c->x_dtype == PRMF_X_BF16 ? PRMF_SRC_BF16 : PRMF_SRC_F32) : src_dtype;   // type on the wire
+  const int teb = src_elem_bytes(trav_dtype);
+  const size_t chunk_bytes = (size_t)(rows_chunk * c->n * teb);
+  XStage* st = stage_acquire(c, narrow ? chunk_bytes : 0, chunk_bytes);
+  if (!st) return PRMF_ERR_HIP;
+  auto bail = [&](int code) {
+    (void)hipStreamSynchronize(st->sc);
+    (void)hipStreamSynchronize(st->sk);
+    stage_release(st);
+    return code;
+  };
+#define SX_TRY(expr)                                                                                       \
+  do {                                                                                                     \
+    hipError_t _e = (expr);                                                                                \
+    if (_e != hipSuccess) return bail(fail(c, PRMF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)));      \
+  } while (0)
+  if ((rc = setx_prepare(c, st->sk))) return bail(rc);
+  if (c->m > 0) {
+    std::unique_ptr<RowWorkers> pool;
+    if (narrow) pool.reset(new RowWorkers(workers));
+    int64_t i = 0;
+    for (int64_t r0 = 0; r0 < c->m; r0 += rows_chunk, ++i) {
+      const int b = (int)(i & 1);
+      const int64_t nr = c->m - r0 < rows_chunk ? c->m - r0 : rows_chunk;
+      if (narrow) {
+        if (i >= 2) SX_TRY(hipEventSynchronize(st->evc[b]));            // the DMA of chunk i - 2 has left this pinned buffer
+        void* dst = st->hb[b];
+        const std::function<void(int, int)> job = [&](int w, int nw) {
+          const int64_t lo = r0 + nr * w / nw, hi = r0 + nr * (w + 1) / nw;
+          host_narrow_rows(src_dtype, c->x_dtype, hX, ld, lo, hi, c->n, (char*)dst + (lo - r0) * c->n * teb);
+        };
+        pool->run(job);
+        if (i >= 2) SX_TRY(hipStreamWaitEvent(st->sc, st->evk[b], 0));  // the kernels of chunk i - 2 have read this device buffer
+        SX_TRY(hipMemcpyAsync(st->ds[b], dst, (size_t)(nr * c->n * teb), hipMemcpyHostToDevice, st->sc));
+        SX_TRY(hipEventRecord(st->evc[b], st->sc));
+        SX_TRY(hipStreamWaitEvent(st->sk, st->evc[b], 0));
+      } else {
+        if (i >= 2) SX_TRY(hipEventSynchronize(st->evk[b]));
+        const char* srow = (const char*)hX + r0 * ld * seb;
+        if (ld == c->n) SX_TRY(hipMemcpy(st->ds[b], srow, (size_t)(nr * c->n * seb), hipMemcpyHostToDevice));
+        else SX_TRY(hipMemcpy2D(st->ds[b], (size_t)(c->n * seb), srow, (size_t)(ld * seb), (size_t)(c->n * seb), (size_t)nr, hipMemcpyHostToDevice));
+      }
+      if ((rc = setx_rows(c, trav_dtype, st->ds[b], c->n, r0, nr, st->sk))) return bail(rc);
+      SX_TRY(hipEventRecord(st->evk[b], st->sk));
+    }
+  }
+#undef SX_TRY
+  rc = setx_finish(c, local_norm_sq_out, st->sk);
+  return bail(rc);
+}
+
+int prmf_release_staging(void) {
+  std::vector<XStage*> all;
+  {
+    std::lock_guard<std::mutex> lock(g_stage_mu);
+    all.swap(g_stage_idle);
+  }
+  for (XStage* st : all) stage_free(st);
   return PRMF_OK;
 }
 
@@ -1272,6 +1569,27 @@ int prmf_score_candidates(prmf_ctx* c, const float* dV, double* scores_out, void
   return PRMF_OK;
 }
 
+int prmf_match_terms(prmf_ctx* c, const float* dV, double* quad_out, double* ignore_out, void* stream) {
+  if (!c || !dV || !quad_out || !ignore_out) return PRMF_ERR_ARG;
+  if (!c->have_lib) return fail(c, PRMF_ERR_STATE, "prmf_set_pathway_library has not been called");
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t need = (int64_t)c->k * c->lib.P;
+  if (2 * need > c->scores_cap) {
+    HIP_TRY(c, hipStreamSynchronize(s));
+    dev_free(c->scores_dev);
+    c->scores_dev = nullptr;
+    if ((rc = dev_alloc(c, &c->scores_dev, (size_t)(2 * need)))) return rc;
+    c->scores_cap = 2 * need;
+  }
+  HIP_TRY(c, launch_match_terms(c->lib, dV, c->k, c->scores_dev, c->scores_dev + need, s));
+  HIP_TRY(c, hipMemcpyAsync(quad_out, c->scores_dev, (size_t)need * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(ignore_out, c->scores_dev + need, (size_t)need * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  return PRMF_OK;
+}
+
 int prmf_cv_error(prmf_ctx* c, const float* dV, double* err_out, void* stream) {
   if (!c || !dV || !err_out) return PRMF_ERR_ARG;
   if (!c->have_x) return fail(c, PRMF_ERR_STATE, "prmf_set_x has not been called");
@@ -1622,16 +1940,17 @@ int prmf_sum_squares(int device, const void* dX, int x_dtype, int64_t m, int64_t
   if (m == 0 || n == 0) return PRMF_OK;
   if (hipSetDevice(device) != hipSuccess) return fail(nullptr, PRMF_ERR_HIP, "hipSetDevice(%d) failed", device);
   hipStream_t s = (hipStream_t)stream;
-  double* partial = nullptr;
-  std::vector<double> host((size_t)SUM_SQUARES_BLOCKS);
-  hipError_t e = hipMalloc((void**)&partial, host.size() * sizeof(double));
-  if (e == hipSuccess) e = launch_sum_squares(x_dtype, dX, ld, m, n, partial, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(host.data(), partial, host.size() * sizeof(double), hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(partial);
-  if (e != hipSuccess) return fail(nullptr, PRMF_ERR_HIP, "prmf_sum_squares: %s", hipGetErrorString(e));
+  // the summation tree of the layout pass (setx.hip): the same bits as the norm prmf_set_x_device / _host report
+  const int64_t np = setx_partial_doubles(m, n), tr = (m + 63) / 64;
+  double* scratch = nullptr;
   double total = 0.0;
-  for (double v : host) total += v;          // index order: the same bits on every run
+  hipError_t e = hipMalloc((void**)&scratch, (size_t)(np + tr + 1) * sizeof(double));
+  if (e == hipSuccess) e = launch_setx_rows(x_dtype, x_dtype, dX, ld, m, n, nullptr, 0, nullptr, 0, scratch, scratch + np, s);
+  if (e == hipSuccess) e = launch_setx_total(scratch + np, tr, scratch + np + tr, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(&total, scratch + np + tr, sizeof(double), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(scratch);
+  if (e != hipSuccess) return fail(nullptr, PRMF_ERR_HIP, "prmf_sum_squares: %s", hipGetErrorString(e));
   *out = total;
   return PRMF_OK;
 }
@@ -1930,6 +2249,24 @@ int prmf_debug_swap(prmf_ctx* a, prmf_ctx* b, int which) {
     case 4: std::swap(a->Up, b->Up); break;
     default: return PRMF_ERR_ARG;
   }
+  return PRMF_OK;
+}
+
+int prmf_debug_resident_x(prmf_ctx* c, int which, void* out_host) {
+  if (!c || !out_host || (which != 0 && which != 1)) return PRMF_ERR_ARG;
+  if (!c->have_x) return fail(c, PRMF_ERR_STATE, "prmf_set_x has not been called");
+  int rc;
+  if ((rc = set_device(c))) return rc;
+  HIP_TRY(c, hipDeviceSynchronize());
+  const size_t bytes = which == 0 ? c->x_bytes : c->xt_bytes;
+  HIP_TRY(c, hipMemcpy(out_host, which == 0 ? c->X : c->XT, bytes, hipMemcpyDeviceToHost));
+  return PRMF_OK;
+}
+
+int prmf_debug_resident_shape(const prmf_ctx* c, int which, int64_t* rows, int64_t* ld) {
+  if (!c || !rows || !ld || (which != 0 && which != 1)) return PRMF_ERR_ARG;
+  *rows = which == 0 ? round_up(c->m > 0 ? c->m : 1, M_PAD) : round_up(c->n, M_PAD);
+  *ld = which == 0 ? c->Kpad_x : c->Kpad_xt;
   return PRMF_OK;
 }
 

@@ -1172,114 +1172,4 @@ hipError_t launch_stream_read(const void* p, size_t bytes, int n_cus, void* sink
   return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------
-// ||X||_F^2 of the stored matrix in float64 (np.linalg.norm(X) at prmf_runner.py:640, before the root): every value widened,
-// squared and summed in double -- per lane over its columns, per workgroup in a fixed tree, the workgroups' partials added in
-// index order by the caller: the same bits on every run.  (It was a chain of torch ops on the host side -- .double() ** 2 .sum()
-// per row chunk --, 8 ms at 50000 x 20000 and 0.13 s for the first call of a process, which loads torch's pow kernel.)
-// ---------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ double widen(T v);
-template <>
-__device__ __forceinline__ double widen<float>(float v) { return (double)v; }
-template <>
-__device__ __forceinline__ double widen<uint16_t>(uint16_t v) { return (double)__uint_as_float((uint32_t)v << 16); }      // bf16
-
-template <typename T>
-__global__ void __launch_bounds__(256) sum_squares_kernel(const T* __restrict__ X, int64_t ld, int64_t rows, int64_t cols,
-                                                          double* __restrict__ partial) {
-  __shared__ double red[256];
-  double acc = 0.0;
-  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
-    const T* row = X + r * ld;
-    for (int64_t c = threadIdx.x; c < cols; c += 256) {
-      const double v = widen<T>(row[c]);
-      acc += v * v;
-    }
-  }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
-}
-
-hipError_t launch_sum_squares(int x_dtype, const void* X, int64_t ld, int64_t rows, int64_t cols, double* partial, hipStream_t s) {
-  if (x_dtype == 0) sum_squares_kernel<float><<<SUM_SQUARES_BLOCKS, 256, 0, s>>>((const float*)X, ld, rows, cols, partial);
-  else sum_squares_kernel<uint16_t><<<SUM_SQUARES_BLOCKS, 256, 0, s>>>((const uint16_t*)X, ld, rows, cols, partial);
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
-// one-time layout kernels (prmf_set_x): padded copy and padded transpose
-// ---------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256) copy_pad_kernel(const T* __restrict__ src, int64_t ld_src, int64_t rows, int64_t cols,
-                                                       T* __restrict__ dst, int64_t ld_dst) {
-  int64_t row = blockIdx.y;
-  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < cols; c += (int64_t)gridDim.x * 256)
-    dst[row * ld_dst + c] = src[row * ld_src + c];
-  (void)rows;
-}
-
-template <typename T>
-__global__ void __launch_bounds__(256) transpose_pad_kernel(const T* __restrict__ src, int64_t ld_src, int64_t rows, int64_t cols,
-                                                            T* __restrict__ dst, int64_t ld_dst) {
-  __shared__ T tile[64][65];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
-  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    int64_t rr = r0 + ty + 4 * i, cc = c0 + tx;
-    tile[ty + 4 * i][tx] = (rr < rows && cc < cols) ? src[rr * ld_src + cc] : T(0);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    int64_t cc = c0 + ty + 4 * i, rr = r0 + tx;
-    if (cc < cols && rr < rows) dst[cc * ld_dst + rr] = tile[tx][ty + 4 * i];
-  }
-}
-
-hipError_t launch_copy_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst,
-                           int64_t ld_dst, hipStream_t s) {
-  if (rows == 0 || cols == 0) return hipSuccess;
-  if (rows > 0x7fffffffLL) return hipErrorInvalidValue;
-  // gridDim.y is limited to 65535: fold rows
-  int64_t done = 0;
-  while (done < rows) {
-    int64_t nr = rows - done < 65535 ? rows - done : 65535;
-    dim3 grid((unsigned)((cols + 255) / 256 > 64 ? 64 : (cols + 255) / 256), (unsigned)nr);
-    if (x_dtype == 1)
-      copy_pad_kernel<unsigned short><<<grid, 256, 0, s>>>((const unsigned short*)src + done * ld_src, ld_src, nr, cols,
-                                                           (unsigned short*)dst + done * ld_dst, ld_dst);
-    else
-      copy_pad_kernel<float><<<grid, 256, 0, s>>>((const float*)src + done * ld_src, ld_src, nr, cols,
-                                                  (float*)dst + done * ld_dst, ld_dst);
-    done += nr;
-  }
-  return hipGetLastError();
-}
-
-hipError_t launch_transpose_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst,
-                                int64_t ld_dst, hipStream_t s) {
-  if (rows == 0 || cols == 0) return hipSuccess;
-  int64_t done = 0;
-  const int64_t max_rows = 65535LL * 64;
-  while (done < rows) {
-    int64_t nr = rows - done < max_rows ? rows - done : max_rows;
-    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((nr + 63) / 64));
-    if (x_dtype == 1)
-      transpose_pad_kernel<unsigned short><<<grid, 256, 0, s>>>((const unsigned short*)src + done * ld_src, ld_src, nr,
-                                                                cols, (unsigned short*)dst + done, ld_dst);
-    else
-      transpose_pad_kernel<float><<<grid, 256, 0, s>>>((const float*)src + done * ld_src, ld_src, nr, cols,
-                                                       (float*)dst + done, ld_dst);
-    done += nr;
-  }
-  return hipGetLastError();
-}
-
 }  // namespace prmf

@@ -147,9 +147,6 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
                        bool split = false /* f32 X as three bf16 pieces, packedB in the bf16 hi/lo layout */,
                        const SweepPrologue* prologue = nullptr /* runs inside the sweep when its jobs fit the grid, else as a launch of its own */,
                        bool attr_only = false /* launch nothing: raise the kernel's dynamic-LDS limit on the current device (prmf_create) */);
-//   partial[SUM_SQUARES_BLOCKS] (device): per-workgroup sums of squares of a rows x cols f32 (x_dtype 0) / bf16 (1) matrix, float64
-constexpr int SUM_SQUARES_BLOCKS = 1024;
-hipError_t launch_sum_squares(int x_dtype, const void* X, int64_t ld, int64_t rows, int64_t cols, double* partial, hipStream_t s);
 hipError_t launch_stream_read(const void* p, size_t bytes, int n_cus, void* sink /* >= 2 n_cus ints, never written */, hipStream_t s);
 // Pathway terms of the V update as extra workgroups of the U epilogue launch (they depend on the OLD V and gamma / delta
 // only; the epilogue leaves a quarter of the chip's slots idle and runs longer than the terms' dependent-load chain, so
@@ -170,10 +167,20 @@ static inline int graph_job_split(int max_support) {      // one workgroup per 1
 }
 // the same prologue work as a stand-alone launch (end of a batch: no sweep follows)
 hipError_t launch_prologue_alone(const SweepPrologue& p, hipStream_t s);
-hipError_t launch_copy_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols,
-                           void* dst, int64_t ld_dst, hipStream_t s);
-hipError_t launch_transpose_pad(int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols,
-                                void* dst, int64_t ld_dst, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// setx.hip: X enters the library in one pass -- narrow to the storage type, padded copy, padded transpose, ||X||^2
+// ---------------------------------------------------------------------------
+// src_dtype: 0 f32, 1 bf16, 2 f64 (include/prmf_hip.h PRMF_SRC_*); x_dtype: the storage type (0 f32, 1 bf16).
+// `rows` rows of the source starting at a multiple of 64 rows of the matrix; X / XT point at that first row / column
+// (both null: only the sums); partial: setx_partial_doubles(rows, cols) doubles of scratch; rowsum: this launch's tile rows
+// ((rows + 63) / 64 doubles, float64 sums of squares of the STORED values), summed by launch_setx_total.
+int64_t setx_partial_doubles(int64_t rows, int64_t cols);
+hipError_t launch_setx_rows(int src_dtype, int x_dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols,
+                            void* X, int64_t ldx, void* XT, int64_t ldxt, double* partial, double* rowsum, hipStream_t s);
+hipError_t launch_setx_total(const double* rowsum, int64_t tile_rows, double* out, hipStream_t s);
+// host: rows [r0, r1) of a host matrix narrowed to the storage type (same roundings), compact (leading dimension = cols)
+void host_narrow_rows(int src_dtype, int x_dtype, const void* src, int64_t ld, int64_t r0, int64_t r1, int64_t cols, void* dst);
 
 // ---------------------------------------------------------------------------
 // update.hip
@@ -257,6 +264,8 @@ hipError_t launch_post(const float* gram_partial, int nparts, int k, double* Gv,
 // candidate scores k x P
 hipError_t launch_score_candidates(const PathwayLibDev& lib, const float* V, int64_t n, int k,
                                    double* colnorm_scratch, double* scores, hipStream_t s);
+// the weights of the final matching: quad[kk * P + p] = v_kk^T L_p v_kk, ignore[kk * P + p] = sum_{i in S_p} 1 / (v_i,kk + 1)
+hipError_t launch_match_terms(const PathwayLibDev& lib, const float* V, int k, double* quad, double* ignore, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // residual.hip: sum (X - U V^T)^2 directly (prmf_runner.py:337), one more sweep over the resident X

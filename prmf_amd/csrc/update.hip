@@ -1929,10 +1929,13 @@ __host__ __device__ inline size_t score_lds_bytes(int ns, int nnz) {
   return (size_t)ns * 33 * 4 + (size_t)ns * 16 + (size_t)nnz * 8 + (size_t)(ns + 1) * 4 + (size_t)nnz * 4 + 16;
 }
 
-template <bool USE_LDS>
+// RAW (prmf_match_terms: the weights of force_distinct_lapls, prmf_runner.py:227-246): the same walk on the column as it
+// is -- no column normalisation, D^-1/2 = 1 -- gives v^T L_p v = sum_s v_s (deg_s v_s - sum_e w_e v_c(e)) into `scores`
+// and sum_s 1 / (v_s + 1) over the support into `scores2`.
+template <bool USE_LDS, bool RAW>
 __global__ void __launch_bounds__(256)
 score_kernel(PathwayLibDev lib, const float* __restrict__ V, int k, const double* __restrict__ colnorm,
-             double* __restrict__ scores) {
+             double* __restrict__ scores, double* __restrict__ scores2) {
   extern __shared__ double score_smem[];
   __shared__ double red[2][4][32];
   const int p = blockIdx.x, kk0 = blockIdx.y * 32;
@@ -1943,7 +1946,7 @@ score_kernel(PathwayLibDev lib, const float* __restrict__ V, int k, const double
   const int ns = (int)(lib.sup_ptr[p + 1] - s0);
   const int64_t e0 = lib.row_ptr[s0];
   const int nnz = (int)(lib.row_ptr[s0 + ns] - e0);
-  const double inv = kk < k ? 1.0 / colnorm[kk] : 0.0;
+  const double inv = RAW ? 1.0 : (kk < k ? 1.0 / colnorm[kk] : 0.0);
   ScoreLds L;
   if constexpr (USE_LDS) {
     // doubles first (8-byte aligned), then the 4-byte arrays
@@ -1959,7 +1962,7 @@ score_kernel(PathwayLibDev lib, const float* __restrict__ V, int k, const double
       L.ys[s * 33 + jj] = col < k ? V[(int64_t)lib.sup_idx[s0 + s] * k + col] : 0.f;
     }
     for (int s = tid; s < ns; s += 256) {
-      L.dis[s] = lib.sup_dis[s0 + s];
+      L.dis[s] = RAW ? 1.0 : lib.sup_dis[s0 + s];
       L.deg[s] = lib.sup_deg[s0 + s];
     }
     for (int s = tid; s <= ns; s += 256) L.rowp[s] = (int)(lib.row_ptr[s0 + s] - e0);
@@ -1980,17 +1983,17 @@ score_kernel(PathwayLibDev lib, const float* __restrict__ V, int k, const double
           const int cl = L.col[e];
           wy += L.w[e] * ((double)L.ys[cl * 33 + j] * inv * L.dis[cl]);
         }
-        mass += vh * vh;
+        mass += RAW ? 1.0 / (vh + 1.0) : vh * vh;
         man += ysv * (L.deg[s] * ysv - wy);
       } else {
         const double vh = (double)V[(int64_t)lib.sup_idx[s0 + s] * k + kk] * inv;
-        const double ysv = vh * lib.sup_dis[s0 + s];
+        const double ysv = RAW ? vh : vh * lib.sup_dis[s0 + s];
         double wy = 0.0;
         for (int64_t e = lib.row_ptr[s0 + s]; e < lib.row_ptr[s0 + s + 1]; ++e) {
           const int cl = lib.col_local[e];
-          wy += lib.w[e] * ((double)V[(int64_t)lib.sup_idx[s0 + cl] * k + kk] * inv * lib.sup_dis[s0 + cl]);
+          wy += lib.w[e] * ((double)V[(int64_t)lib.sup_idx[s0 + cl] * k + kk] * inv * (RAW ? 1.0 : lib.sup_dis[s0 + cl]));
         }
-        mass += vh * vh;
+        mass += RAW ? 1.0 / (vh + 1.0) : vh * vh;
         man += ysv * (lib.sup_deg[s0 + s] * ysv - wy);
       }
     }
@@ -2006,23 +2009,38 @@ score_kernel(PathwayLibDev lib, const float* __restrict__ V, int k, const double
   if (tid < 32 && kk0 + tid < k) {
     const double ms = ((red[0][0][tid] + red[0][1][tid]) + red[0][2][tid]) + red[0][3][tid];
     const double mn = ((red[1][0][tid] + red[1][1][tid]) + red[1][2][tid]) + red[1][3][tid];
-    scores[(int64_t)(kk0 + tid) * lib.P + p] = sqrt(ms) + (1.0 - mn);
+    if (RAW) {
+      scores[(int64_t)(kk0 + tid) * lib.P + p] = mn;
+      scores2[(int64_t)(kk0 + tid) * lib.P + p] = ms;
+    } else {
+      scores[(int64_t)(kk0 + tid) * lib.P + p] = sqrt(ms) + (1.0 - mn);
+    }
   }
+}
+
+template <bool RAW>
+static hipError_t launch_score_form(const PathwayLibDev& lib, const float* V, int k, const double* colnorm, double* scores,
+                                    double* scores2, hipStream_t s) {
+  const dim3 grid(lib.P, (k + 31) / 32);
+  const size_t lds = score_lds_bytes(lib.max_support, lib.max_nnz);
+  if (lds <= 150 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(score_kernel<true, RAW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    score_kernel<true, RAW><<<grid, 256, lds, s>>>(lib, V, k, colnorm, scores, scores2);
+  } else {
+    score_kernel<false, RAW><<<grid, 256, 0, s>>>(lib, V, k, colnorm, scores, scores2);   // pathway too large for LDS: global gathers
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_score_candidates(const PathwayLibDev& lib, const float* V, int64_t n, int k, double* colnorm_scratch,
                                    double* scores, hipStream_t s) {
   colnorm_kernel<<<k, 256, 0, s>>>(V, n, k, colnorm_scratch);
-  const dim3 grid(lib.P, (k + 31) / 32);
-  const size_t lds = score_lds_bytes(lib.max_support, lib.max_nnz);
-  if (lds <= 150 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(score_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    score_kernel<true><<<grid, 256, lds, s>>>(lib, V, k, colnorm_scratch, scores);
-  } else {
-    score_kernel<false><<<grid, 256, 0, s>>>(lib, V, k, colnorm_scratch, scores);   // pathway too large for LDS: global gathers
-  }
-  return hipGetLastError();
+  return launch_score_form<false>(lib, V, k, colnorm_scratch, scores, nullptr, s);
+}
+
+hipError_t launch_match_terms(const PathwayLibDev& lib, const float* V, int k, double* quad, double* ignore, hipStream_t s) {
+  return launch_score_form<true>(lib, V, k, nullptr, quad, ignore, s);
 }
 
 }  // namespace prmf

@@ -64,7 +64,7 @@ class DistributedPrmf(object):
         if self.world != engine.nranks:
             raise ValueError("engine was created for %d ranks, process group has %d" % (engine.nranks, self.world))
         if native is None:
-            native = self.world > 1 and self.ranks.on_gpu and hasattr(engine, "comm_init")
+            native = self.ranks.multi and self.ranks.on_gpu and hasattr(engine, "comm_init")
         self.native = False
         if native:
             # engine.comm_init decides collectively: it either succeeds on every rank or raises on every rank, so no
@@ -78,7 +78,7 @@ class DistributedPrmf(object):
                 import sys
                 sys.stderr.write("prmf_amd: in-library RCCL communicator unavailable (%s); "
                                  "PRMF_ALLOW_HOST_COLLECTIVES is set: using host-driven collectives\n" % e)
-        self.coll = self.ranks if (self.world > 1 and not self.native) else None
+        self.coll = self.ranks if (self.ranks.multi and not self.native) else None
         self.buf = None if self.native else engine.comm_buffers()
         if self.coll is not None and hasattr(engine, "set_global_rows"):
             # host-driven: the library cannot all-reduce the sample count itself (prmf_hip.h: prmf_set_global_rows)

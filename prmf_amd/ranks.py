@@ -38,18 +38,24 @@ class TorchRanks(object):
     """The ranks of a torch.distributed process group (None: the world; not initialised: one rank)."""
 
     def __init__(self, group=None):
+        import os
         self.group, self.world, self.rank, self.dist = group, 1, 0, None
         self.device_index = None
         try:
             import torch.distributed as dist
         except ImportError:
             return
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        # PRMF_FORCE_RANK_PATH=1: an initialised group of ONE rank is driven like any other -- its broadcasts, reductions,
+        # the RCCL communicator bootstrap and prmf_step_dist all run (on one rank they are identities).  This is how the code
+        # the 8-GPU launch executes runs on a one-GPU box with the real librccl, which refuses two ranks on one device
+        # (tests/test_gpu_rank_process.py); nothing else reads the variable.
+        forced = bool(os.environ.get("PRMF_FORCE_RANK_PATH"))
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or forced):
             self.dist, self.world, self.rank = dist, dist.get_world_size(group), dist.get_rank(group)
 
     @property
     def multi(self):
-        return self.world > 1
+        return self.dist is not None
 
     @property
     def on_gpu(self):

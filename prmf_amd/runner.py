@@ -439,7 +439,9 @@ Solve an optimization problem of the form
         cmd += list(sys.argv[1:] if argv is None else argv)
         sys.exit(subprocess.call(cmd))
     rank, group_ready = 0, False
-    if world > 1:
+    # PRMF_FORCE_RANK_PATH=1 under the launcher with ONE process: the multi-process branch at world size 1 (prmf_amd/ranks.py)
+    forced = bool(os.environ.get("PRMF_FORCE_RANK_PATH")) and "RANK" in os.environ
+    if world > 1 or forced:
         import torch
         import torch.distributed as dist
         rank = int(os.environ.get("RANK", "0"))
@@ -461,7 +463,7 @@ Solve an optimization problem of the form
         if rank != 0:              # rank 0 speaks for the job
             sys.stdout = open(os.devnull, "w")
     try:
-        _run(args, rank, world)
+        _run(args, rank, world, process_ranks=group_ready)
     except BaseException:
         # no barrier on the way out of a failure: the other ranks may be inside a different collective (or gone); this
         # process ends non-zero and the launcher ends the job
@@ -478,12 +480,12 @@ Solve an optimization problem of the form
         dist.destroy_process_group()
 
 
-def _run(args, rank, world, local_ranks=0):
+def _run(args, rank, world, local_ranks=0, process_ranks=False):
     manifolds = ManifoldSet.from_args(args)
     if args.seed is not None:                              # both legacy streams, as the reference seeds them
         np.random.seed(int(args.seed))
         random.seed(int(args.seed))
-    rank_local = (world > 1 and args.data.endswith(".npy") and args.nodelist is not None and args.cross_validation is None
+    rank_local = ((world > 1 or process_ranks) and args.data.endswith(".npy") and args.nodelist is not None and args.cross_validation is None
                   and args.manifolds_init is None)
     if rank_local:
         # several process ranks, binary input: nobody reads the whole matrix (RowSource)
@@ -509,7 +511,7 @@ def _run(args, rank, world, local_ranks=0):
             from .preprocess import quantile_transform
             # one process, one GPU, nothing else that reads X on the host (--manifolds-init does): the normalised matrix
             # stays on the device and nmf_pathway takes it from there
-            stay = world == 1 and not local_ranks and args.manifolds_init is None
+            stay = world == 1 and not process_ranks and local_ranks <= 1 and args.manifolds_init is None
             if stay:
                 import torch
                 X = quantile_transform(X, device=torch.cuda.current_device(), on_device=True)
@@ -543,6 +545,7 @@ def _run(args, rank, world, local_ranks=0):
             solve["library"] = PathwayLibrary.from_graphs(manifolds.graphs, nodelist)
         U, V, obj_data = LocalRanks(local_ranks).run(lambda view: nmf_pathway(X, manifolds.graphs, group=view, **solve))[0]
     else:
+        X = [X]                                             # handed over: nmf_pathway drops the matrix once the library holds it
         U, V, obj_data = nmf_pathway(X, manifolds.graphs, **solve)                                # the GPU solve (:1067)
     if rank != 0:                                          # every rank holds the same U, V, obj_data; rank 0 writes them
         return

@@ -119,26 +119,109 @@ class PrmfEngine(object):
         return a.to(device=dev, dtype=dtype or a.dtype).contiguous()
 
     # -- inputs ---------------------------------------------------------------
-    def set_x(self, X, norm_x_sq=None):
-        """Upload this rank's rows of X (numpy or torch, any float dtype; rounded
-        to the engine's x dtype).  norm_x_sq = ||X||_F^2 of the GLOBAL matrix; if
-        None it is computed from the rounded local X (single rank)."""
+    def _x_source(self, X):
+        """(kind, object kept alive, pointer, PRMF_SRC_* code, leading dimension) of a matrix prmf_set_x_host / _device can
+        read in place: a float32 / float64 ndarray with contiguous rows, or a 2-D float32 / bfloat16 / float64 tensor on
+        this GPU; anything else is widened to float64 on the host first (exact for integers below 2^53 and for float16)."""
         torch = self.torch
-        Xd = self.device_tensor(X, self.torch_x_dtype)
-        if tuple(Xd.shape) != (self.m, self.n):
-            raise ValueError("X has shape {} != (m_local, n) = {}".format(tuple(Xd.shape), (self.m, self.n)))
-        if norm_x_sq is None:
-            if self.nranks != 1:
-                raise ValueError("norm_x_sq (global) is required with nranks > 1")
-            norm_x_sq = self.local_norm_sq(Xd)
-        self._check(self.lib.prmf_set_x(self.ctx, C.c_void_p(Xd.data_ptr()), self.n, float(norm_x_sq), self._stream()))
-        torch.cuda.current_stream(self.device).synchronize()   # Xd may be freed after this
-        self.norm_x_sq = float(norm_x_sq)
+        if isinstance(X, torch.Tensor):
+            if X.is_cuda and X.ndim == 2 and X.dtype in (torch.float32, torch.bfloat16, torch.float64):
+                if X.device.index != self.device:
+                    X = X.to("cuda:%d" % self.device)
+                if X.shape[1] > 0 and X.stride(1) != 1:
+                    X = X.contiguous()
+                code = {torch.float32: _capi.PRMF_SRC_F32, torch.bfloat16: _capi.PRMF_SRC_BF16, torch.float64: _capi.PRMF_SRC_F64}[X.dtype]
+                ld = X.stride(0) if X.shape[0] > 1 else X.shape[1]
+                return "device", X, X.data_ptr(), code, max(int(ld), X.shape[1])
+            X = X.detach().cpu().to(torch.float64).numpy() if X.dtype != torch.float32 else X.detach().cpu().numpy()
+        X = np.asarray(X)
+        if X.ndim != 2:
+            raise ValueError("X must be a matrix, got shape {}".format(X.shape))
+        if X.dtype not in (np.float32, np.float64):
+            X = X.astype(np.float64)
+        if ((X.shape[1] > 0 and X.strides[1] != X.itemsize) or (X.shape[0] > 1 and X.strides[0] < X.shape[1] * X.itemsize)
+                or X.strides[0] % X.itemsize):
+            X = np.ascontiguousarray(X)
+        ld = X.strides[0] // X.itemsize if X.shape[0] > 1 else X.shape[1]
+        return "host", X, X.ctypes.data, (_capi.PRMF_SRC_F32 if X.dtype == np.float32 else _capi.PRMF_SRC_F64), max(int(ld), X.shape[1])
+
+    def set_x(self, X, norm_x_sq=None, host_threads=-1):
+        """This rank's rows of X into the library: a numpy matrix (float32 / float64; it travels chunk by chunk, narrowed to
+        the engine's storage type on the way -- `prmf_set_x_host`) or a tensor on the GPU (float32 / bfloat16 / float64 --
+        `prmf_set_x_device`).  One pass writes the padded copy, the padded transpose and ||X||^2 of the stored values
+        (`self.local_sq`: this rank's rows).  norm_x_sq = ||X||_F^2 of the GLOBAL matrix; None (single rank): the local
+        value.  Returns the norm the engine now holds."""
+        if norm_x_sq is None and self.nranks != 1:
+            raise ValueError("norm_x_sq (global) is required with nranks > 1 (or: set_x_local, add the ranks' sums, set_norm_x_sq)")
+        self.set_x_async(X, norm_x_sq, host_threads, thread=False).result()
         return self.norm_x_sq
+
+    def set_x_local(self, X, host_threads=-1):
+        """`set_x` of a multi-rank run's first half: the rows go in, the LOCAL sum of squares comes back; the caller adds
+        the ranks' values and hands the total to `set_norm_x_sq`."""
+        return self.set_x_async(X, None, host_threads, thread=False).result()
+
+    def set_x_async(self, X, norm_x_sq=None, host_threads=-1, thread=True):
+        """`set_x` on a helper thread (the library call releases the GIL: a 4 GB upload is 0.05-0.08 s during which the
+        caller can draw its random factors and build the pathway library).  `.result()` joins, re-raises what the upload
+        raised and returns the local sum of squares."""
+        kind, keep, ptr, code, ld = self._x_source(X)
+        if tuple(keep.shape) != (self.m, self.n):
+            raise ValueError("X has shape {} != (m_local, n) = {}".format(tuple(keep.shape), (self.m, self.n)))
+        stream = self._stream()
+        box = {"keep": keep}                # the source stays alive until the copy has finished, and no longer
+        del keep, X
+
+        def work():
+            try:
+                out = C.c_double()
+                if kind == "device":
+                    rc = self.lib.prmf_set_x_device(self.ctx, C.c_void_p(ptr), code, ld, C.byref(out), stream)
+                else:
+                    rc = self.lib.prmf_set_x_host(self.ctx, C.c_void_p(ptr), code, ld, int(host_threads), C.byref(out), stream)
+                self._check(rc)
+                box["value"] = out.value
+            except BaseException as e:      # re-raised by result()
+                box["error"] = e
+
+        class Pending(object):
+            def result(_self):
+                if th is not None:
+                    th.join()
+                box.pop("keep", None)
+                if "error" in box:
+                    raise box["error"]
+                self.local_sq = box["value"]
+                if norm_x_sq is not None:
+                    self.set_norm_x_sq(norm_x_sq)
+                else:
+                    self.norm_x_sq = box["value"]
+                return box["value"]
+
+        th = None
+        if not thread:
+            work()
+        else:
+            import threading
+            th = threading.Thread(target=work, name="prmf-set-x")
+            th.start()
+        return Pending()
+
+    def _legacy_set_x(self, Xd, norm_x_sq=0.0):
+        """`prmf_set_x` as rounds 1-5 called it: a device matrix already in the storage type, the norm supplied by the
+        caller, asynchronous on the stream (kept in the ABI; tests compare it with the one-pass entry points)."""
+        self._check(self.lib.prmf_set_x(self.ctx, C.c_void_p(Xd.data_ptr()), Xd.stride(0), float(norm_x_sq), self._stream()))
+        self.torch.cuda.current_stream(self.device).synchronize()
+        self.norm_x_sq = float(norm_x_sq)
+
+    def set_norm_x_sq(self, norm_x_sq):
+        """||X||_F^2 of the GLOBAL matrix (multi-rank: the sum of the ranks' local values)"""
+        self._check(self.lib.prmf_set_norm_x_sq(self.ctx, float(norm_x_sq)))
+        self.norm_x_sq = float(norm_x_sq)
 
     def local_norm_sq(self, Xd):
         """sum of squares of the rounded local X (a contiguous device tensor in the engine's dtype) in float64
-        (`prmf_sum_squares`: one kernel, fixed summation order)."""
+        (`prmf_sum_squares`: one kernel pass, the summation tree of the upload: the value `set_x` returns)."""
         torch = self.torch
         if not (isinstance(Xd, torch.Tensor) and Xd.is_cuda and Xd.dtype == self.torch_x_dtype and Xd.ndim == 2 and Xd.is_contiguous()):
             raise ValueError("local_norm_sq takes a contiguous 2-D device tensor of the engine's x dtype")
@@ -297,12 +380,12 @@ class PrmfEngine(object):
         t = os.environ.get("PRMF_COLLECTIVE_TIMEOUT_S")
         if t:
             self.set_comm_timeout(float(t))
-        if self.nranks == 1:
+        ranks = as_ranks(group)
+        if self.nranks == 1 and not ranks.multi:
             self._check_create(self.lib.prmf_comm_unique_id(_ptr(idbuf)))
             self._check(self.lib.prmf_comm_init(self.ctx, _ptr(idbuf)))
             self._native_comm = True
             return
-        ranks = as_ranks(group)
         if ranks.world != self.nranks or ranks.rank != self.rank:
             raise ValueError("engine is rank %d of %d, the group says %d of %d" % (self.rank, self.nranks, ranks.rank, ranks.world))
         cdev = "cuda:%d" % self.device
@@ -351,6 +434,14 @@ class PrmfEngine(object):
         out = np.zeros((self.k, self.library.P))
         self._check(self.lib.prmf_score_candidates(self.ctx, C.c_void_p(V.data_ptr()), _ptr(out), self._stream()))
         return out
+
+    def match_terms(self, V):
+        """(quad, ignore), both k x P: v_k^T L_p v_k with the un-normalised Laplacian and sum_{i in S_p} 1 / (V[i, k] + 1)
+        -- what force_distinct_lapls (prmf_runner.py:227-246) weighs its matching with (`prmf_match_terms`)."""
+        quad = np.zeros((self.k, self.library.P))
+        ign = np.zeros((self.k, self.library.P))
+        self._check(self.lib.prmf_match_terms(self.ctx, C.c_void_p(V.data_ptr()), _ptr(quad), _ptr(ign), self._stream()))
+        return quad, ign
 
     def cv_error(self, V):
         """Per-row NNLS reconstruction error of this engine's X (the held-out samples) against V
@@ -447,36 +538,12 @@ def nmf_manifold_vec_update_tradeoff(X, U, V, k_to_W, k_to_D, k_to_L, k_to_feat_
 # ---------------------------------------------------------------------------
 def restrict(scores_kP, latent_to_pathway_data, percentile=19.9):
     """prmf_runner.py:129-194 on a precomputed k x P score matrix (the GPU scores
-    every pair; only the still-candidate ones are read here)."""
-    rv = {}
-    # the percentile of every latent's candidate scores: ONE numpy call per list length (np.percentile along an axis
-    # gives each row the value the per-row call gives, bit for bit -- tested), not one per latent: the lists have the
-    # same length for all latents in the first rounds (64 calls of 35 us each per round at k = 64)
-    by_len = {}
-    for k, data in latent_to_pathway_data.items():
-        if len(data) > 1:
-            by_len.setdefault(len(data), []).append(k)
-    cut = {}
-    for _n, ks in by_len.items():
-        S = np.stack([scores_kP[k, [x[0] for x in latent_to_pathway_data[k]]] for k in ks])
-        for k, c in zip(ks, np.percentile(S, percentile, axis=1)):
-            cut[k] = c
-    for k, data in latent_to_pathway_data.items():
-        inds = [x[0] for x in data]
-        if len(inds) > 1:
-            scores = scores_kP[k, inds]
-            keep = np.where(scores > cut[k])[0]
-            if len(keep) == 0:
-                # :174-182 all scores tie: the reference asks np.random.choice for a
-                # negative sample size here and raises ValueError; so do we.
-                size = math.ceil(len(inds) * (1 - percentile) / 100)
-                chosen = np.random.choice(np.array(inds), size=size, replace=False)
-                rv[k] = [(int(c), float(scores_kP[k, c])) for c in chosen]
-            else:
-                rv[k] = [(inds[i], float(scores[i])) for i in keep]
-        else:
-            rv[k] = data
-    return rv
+    every pair; only the still-candidate ones are read here).  Dict in, dict out; the solver keeps the candidates as arrays
+    between the rounds (`_Candidates.restrict`, the same code)."""
+    c = _Candidates(0, 0)
+    c.take_dict(latent_to_pathway_data)
+    c.restrict(scores_kP, percentile)
+    return c.as_dict()
 
 
 def print_latent_to_pathway_data(latent_to_pathway_data, out=None):
@@ -544,7 +611,8 @@ def force_distinct_lapls(V, library, latent_to_pathway_data, k_to_lapl, gamma, d
     """prmf_runner.py:209-258: max-weight matching between latent factors and their
     remaining candidate pathways, weight 1/(gamma v^T L v + delta*ignore).  As in the
     reference the ignore term is overwritten (not summed) over the active supports
-    (:233-235), so it is the last latent's value."""
+    (:233-235), so it is the last latent's value.  Host form (V: n x k ndarray); the solver itself takes the two terms
+    from the GPU (`PrmfEngine.match_terms`) and calls `force_distinct_from_terms`."""
     k_last = max(k_to_lapl.keys())
     ign = float(np.sum(1.0 / (V[library.supports[k_to_lapl[k_last]], k_last] + 1)))
     # v_k^T L_p v_k for every remaining (latent, pathway) pair, one sparse product per pathway (PathwayLibrary.laplacian_quadratics)
@@ -556,16 +624,82 @@ def force_distinct_lapls(V, library, latent_to_pathway_data, k_to_lapl, gamma, d
     for lapl, ks in by_pathway.items():
         for k, q in zip(ks, library.laplacian_quadratics(lapl, V, ks)):
             quad[(k, lapl)] = q
+    return _match_from(lambda k, lapl: quad[(k, lapl)], ign, latent_to_pathway_data, gamma, delta)
+
+
+def force_distinct_from_terms(quad_kP, ignore_kP, latent_to_pathway_data, k_to_lapl, gamma, delta):
+    """The same with the two terms of every (latent, pathway) pair already evaluated (k x P arrays, `prmf_match_terms`):
+    no download of V, no sparse products on the host."""
+    k_last = max(k_to_lapl.keys())
+    ign = float(ignore_kP[k_last, k_to_lapl[k_last]])
+    return _match_from(lambda k, lapl: float(quad_kP[k, lapl]), ign, latent_to_pathway_data, gamma, delta)
+
+
+def _match_from(quad_of, ign, latent_to_pathway_data, gamma, delta):
     per_latent = []
     for k, data in latent_to_pathway_data.items():
         ws = []
         for lapl, _score in data:
-            denom = gamma * quad[(k, lapl)] + delta * ign
+            denom = gamma * quad_of(k, lapl) + delta * ign
             ws.append((lapl, 0 if denom == 0 else 1 / denom))
         per_latent.append((k, ws))
     for k, p in _max_weight_matching(per_latent):
         latent_to_pathway_data[k] = [(p, 2)]
     return latent_to_pathway_data
+
+
+class _Candidates(object):
+    """latent_to_pathway_data (prmf_runner.py:700: latent -> [(pathway, score), ...]) held as one index array and one score
+    array per latent between the rounds -- restrict cuts them with array operations -- and turned into the reference's
+    dict of tuple lists only where that form is the contract (the verbose table, the matching, the returned obj_data).
+    Entries keep the reference's types: the initial score is the int 1, a matched pair's the int 2, restrict's are floats."""
+
+    def __init__(self, k_latent, P):
+        self.inds = {k: np.arange(P, dtype=np.int64) for k in range(k_latent)}
+        self.scores = {k: np.ones(P, dtype=np.int64) for k in range(k_latent)}
+
+    def min_len(self):
+        return min(len(v) for v in self.inds.values())
+
+    def any_open(self):
+        return any(len(v) > 1 for v in self.inds.values())
+
+    def as_dict(self):
+        out = {}
+        for k, inds in self.inds.items():
+            sc = self.scores[k]
+            conv = int if sc.dtype.kind == "i" else float
+            out[k] = [(int(p), conv(x)) for p, x in zip(inds.tolist(), sc.tolist())]
+        return out
+
+    def take_dict(self, l2p):
+        for k, data in l2p.items():
+            self.inds[k] = np.array([x[0] for x in data], dtype=np.int64)
+            sc = [x[1] for x in data]
+            self.scores[k] = np.array(sc, dtype=np.int64 if all(isinstance(x, int) for x in sc) else np.float64)
+
+    def restrict(self, scores_kP, percentile=19.9):
+        """prmf_runner.py:129-194 on the k x P score matrix of the GPU.  Latents with equally many candidates are cut
+        together: np.percentile along an axis gives every row the value the per-row call gives, bit for bit (tested)."""
+        by_len = {}
+        for k, inds in self.inds.items():
+            if len(inds) > 1:
+                by_len.setdefault(len(inds), []).append(k)
+        for _n, ks in by_len.items():
+            IND = np.stack([self.inds[k] for k in ks])
+            S = scores_kP[np.asarray(ks)[:, None], IND]
+            keep = S > np.percentile(S, percentile, axis=1)[:, None]
+            for r, k in enumerate(ks):
+                if not keep[r].any():
+                    # :174-182 all scores tie: the reference asks np.random.choice for a negative sample size here and
+                    # raises ValueError; so do we.
+                    size = math.ceil(len(IND[r]) * (1 - percentile) / 100)
+                    chosen = np.random.choice(IND[r], size=size, replace=False)
+                    self.inds[k] = np.asarray(chosen, dtype=np.int64)
+                    self.scores[k] = scores_kP[k, self.inds[k]].astype(np.float64)
+                else:
+                    self.inds[k] = IND[r][keep[r]]
+                    self.scores[k] = S[r][keep[r]].astype(np.float64)
 
 
 def multinomial_one(p):
@@ -603,6 +737,9 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
     say = print if ranks.rank == 0 else (lambda *a, **kw: None)
     # X: the reference's ndarray; a RowSource (rank-local input: .shape, .rows(lo, hi)); or a 2-D tensor already on the GPU
     # (prmf_amd.preprocess.quantile_transform(on_device=True): the normalised matrix never visits the host)
+    if isinstance(X, list) and len(X) == 1:
+        X = X.pop()      # ownership handed over: the matrix is dropped as soon as the library holds its copies (the CLI's
+        #                  normalised float64 matrix on the GPU is 8 m n bytes next to the engine's own 2 x 4 m n)
     on_gpu = hasattr(X, "is_cuda") and X.is_cuda
     X = X if (hasattr(X, "rows") or on_gpu) else np.asarray(X)
     m, n = X.shape
@@ -612,25 +749,45 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
         lo, hi = shard_rows(m, ranks.world, ranks.rank)
     engine = PrmfEngine(hi - lo, n, k_latent, x_dtype=x_dtype, nranks=ranks.world, rank=ranks.rank,
                         dist_mode=dist_mode if ranks.multi else None, device=ranks.device_index)
+    # The cyclic collector is held off for the duration of the solve and put back as it was: a full collection walks every
+    # container of the caller's process (the pathway library alone is thousands of arrays) and lands wherever an allocation
+    # happens to trigger it -- 10-25 ms of a 150 ms solve at 50000 x 20000 (profiles/r06_outer_loop_host_time.txt).  Nothing
+    # here builds reference cycles; reference counting frees everything else as always.
+    import gc
+    gc_was_on = gc.isenabled()
+    gc.disable()
     try:
         torch = engine.torch
         dev = "cuda:%d" % engine.device
-        Xd = engine.device_tensor(X.rows(lo, hi) if hasattr(X, "rows") else X[lo:hi], engine.torch_x_dtype)
-        norm_sq = ranks.sum_float(engine.local_norm_sq(Xd), dev)
-        engine.set_x(Xd, norm_x_sq=norm_sq)
-        del Xd
+        # X goes up on a helper thread (one pass in the library: narrowing, padded copy, padded transpose, ||X||^2 -- a host
+        # matrix chunk by chunk under its own PCIe copy); what does not need X yet runs under it: the reference's random
+        # draws (:651-653: the ORDER of the draws is the contract, not when they happen) and the pathway library (:670-696)
+        pending = engine.set_x_async(X.rows(lo, hi) if hasattr(X, "rows") else X[lo:hi])
+        early = None
+        try:
+            # rank 0's factors are THE factors, drawn here (:651-653) or handed in: every rank takes rank 0's (a caller's
+            # per-rank initialisers need not agree, e.g. set iteration order under different hash seeds); as tensors
+            given = ranks.from_rank0((U_init is not None, V_init is not None)) if ranks.multi else (U_init is not None, V_init is not None)
+            if ranks.rank == 0 or not ranks.multi:
+                if not given[0]:
+                    U_init = 3 * (1 - np.random.rand(m, k_latent))
+                if not given[1]:
+                    V_init = 3 * (1 - np.random.rand(n, k_latent))
+            if library is None:
+                try:
+                    library = PathwayLibrary.from_graphs(Gs, nodelist)    # :670-696
+                except Exception as e:      # the reference meets its graphs after the shape checks below: so does this error
+                    early = e
+        finally:
+            local_sq = pending.result()
+            del pending
+            X = None
+        norm_sq = ranks.sum_float(local_sq, dev)
+        engine.set_norm_x_sq(norm_sq)
         norm_X = math.sqrt(norm_sq)                                 # :640 (of the X the GPUs hold)
         say("norm(X) = {}".format(norm_X))                          # :641
         gamma = gamma * norm_X / k_latent                           # :644
         delta = delta * 10 / norm_X                                 # :645
-        # rank 0's factors are THE factors, drawn here (:651-653) or handed in: every rank takes rank 0's (a caller's
-        # per-rank initialisers need not agree, e.g. set iteration order under different hash seeds); as tensors
-        given = ranks.from_rank0((U_init is not None, V_init is not None)) if ranks.multi else (U_init is not None, V_init is not None)
-        if ranks.rank == 0 or not ranks.multi:
-            if not given[0]:
-                U_init = 3 * (1 - np.random.rand(m, k_latent))
-            if not given[1]:
-                V_init = 3 * (1 - np.random.rand(n, k_latent))
         if ranks.multi:
             shp = ranks.from_rank0((np.shape(U_init), np.shape(V_init)) if ranks.rank == 0 else None)
             U_init = ranks.array_from_rank0(U_init, shp[0], dev)
@@ -639,8 +796,8 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
             raise ValueError("Invalid U_init with shape {} != (m_obs, k_latent) = {}".format(U_init.shape, (m, k_latent)))
         if V_init.shape != (n, k_latent):
             raise ValueError("Invalid V_init with shape {} != (n_feature, k_latent) = {}".format(V_init.shape, (n, k_latent)))
-        if library is None:
-            library = PathwayLibrary.from_graphs(Gs, nodelist)    # :670-696
+        if early is not None:
+            raise early
         engine.set_library(library)
         U = engine.device_tensor(U_init[lo:hi], torch.float32)
         V = engine.device_tensor(V_init, torch.float32)
@@ -652,7 +809,7 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
         else:
             step = engine.step
 
-        l2p = {k: [(p, 1) for p in range(library.P)] for k in range(k_latent)}     # :700
+        cands = _Candidates(k_latent, library.P)                    # :700
         converged, candidates_remain = False, True
         obj, obj_data = math.inf, {}
         best = {"obj_data": {"obj": np.inf}}
@@ -661,10 +818,9 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
         while i < max_iter and (candidates_remain or not converged):
             if ranks.rank == 0:
                 for k in range(k_latent):                          # :717-729
-                    inds = [x[0] for x in l2p[k]]
-                    scores = np.array([x[1] for x in l2p[k]])
+                    scores = cands.scores[k]
                     sample = multinomial_one(scores / np.sum(scores))
-                    k_to_lapl[k] = inds[np.where(sample != 0)[0][0]]
+                    k_to_lapl[k] = int(cands.inds[k][np.where(sample != 0)[0][0]])
             k_to_lapl = ranks.from_rank0(k_to_lapl)
             if round_log is not None:
                 round_log.append([int(k_to_lapl[k]) for k in range(k_latent)])
@@ -696,19 +852,20 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
                 best["V"].copy_(V)
                 best["obj_data"] = obj_data
             if candidates_remain:                                   # :754-770  (V is replicated: every rank decides alike)
-                if min(len(v) for v in l2p.values()) <= k_latent:
-                    Vh = V.cpu().numpy().astype(np.float64)
-                    l2p = force_distinct_lapls(Vh, library, l2p, dict(k_to_lapl), gamma, delta)
+                if cands.min_len() <= k_latent:
+                    # the two terms of every (latent, pathway) pair from the GPU (k x P each): V stays where it is
+                    quad, ign = engine.match_terms(V)
+                    cands.take_dict(force_distinct_from_terms(quad, ign, cands.as_dict(), dict(k_to_lapl), gamma, delta))
                     candidates_remain = False
                 else:
                     if ranks.rank == 0:
                         sys.stderr.write('Before restrict: ' + str(datetime.datetime.now()) + '\n')     # :762
-                    l2p = restrict(engine.score_candidates(V), l2p)
+                    cands.restrict(engine.score_candidates(V))
                     if ranks.rank == 0:
                         sys.stderr.write('After restrict: ' + str(datetime.datetime.now()) + '\n')      # :764
-                    candidates_remain = any(len(v) > 1 for v in l2p.values())
+                    candidates_remain = cands.any_open()
                 if verbose and ranks.rank == 0:
-                    print_latent_to_pathway_data(l2p)                                              # :759, :770
+                    print_latent_to_pathway_data(cands.as_dict())                                  # :759, :770
             prev_obj, obj = obj, obj_data["obj"]
             converged = abs(obj - prev_obj) / obj < tol              # :772-774
         if best["obj_data"]["obj"] < obj_data["obj"]:                # :778-782
@@ -717,10 +874,12 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
         U_out = ranks.gather_rows(torch, U, m).astype(np.float64)
         V_out = V.cpu().numpy().astype(np.float64)
         obj_data = dict(obj_data)
-        obj_data["latent_to_pathway_data"] = l2p
+        obj_data["latent_to_pathway_data"] = cands.as_dict()
         return U_out, V_out, obj_data
     finally:
         engine.close()
+        if gc_was_on:
+            gc.enable()
 
 
 def measure_cv_performance(gene_by_latent_train, data_test, x_dtype="f32", device=0):

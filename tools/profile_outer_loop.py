@@ -63,8 +63,29 @@ def wrap(name):
     return orig
 
 
-names = ("__init__", "device_tensor", "local_norm_sq", "set_x", "set_library", "set_active", "step", "score_candidates", "close")
+names = ("__init__", "set_x_async", "device_tensor", "set_norm_x_sq", "set_library", "set_active", "step", "score_candidates", "match_terms", "close")
 origs = {nm: wrap(nm) for nm in names}
+_start = solver.PrmfEngine.set_x_async          # (already wrapped: the time to START the upload); its join is timed apart
+
+
+def start_and_time_join(self, *a, **kw):
+    pend = _start(self, *a, **kw)
+    t_started = time.perf_counter()
+    join = pend.result
+
+    def result():
+        t0 = time.perf_counter()
+        try:
+            return join()
+        finally:
+            acc["upload: waited for at the join"] = acc.get("upload: waited for at the join", 0.0) + time.perf_counter() - t0
+            acc["host work under the upload"] = acc.get("host work under the upload", 0.0) + t0 - t_started
+    pend.result = result
+    return pend
+
+
+solver.PrmfEngine.set_x_async = start_and_time_join
+names = names + ("upload: waited for at the join", "host work under the upload")
 t0 = time.perf_counter()
 call()
 total = time.perf_counter() - t0
@@ -72,6 +93,17 @@ print("warm call %.1f ms: " % (1e3 * total) + " | ".join("%s %.1f" % (nm, 1e3 * 
       " | everything else %.1f  (ms)" % (1e3 * (total - sum(acc.values()) + acc.get("device_tensor", 0) * 0)), flush=True)
 for nm, o in origs.items():
     setattr(solver.PrmfEngine, nm, o)
+# the upload alone: host threads narrowing vs the chunk narrowed on the device
+eng = solver.PrmfEngine(m, n, k, x_dtype=xd)
+for label, th in (("narrowed by 16 host threads", -1), ("8 threads", 8), ("4 threads", 4), ("narrowed on the device (pageable copies)", 0)):
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        eng.set_x(X, host_threads=th)
+        ts.append(time.perf_counter() - t0)
+    print("set_x(host float32 %d x %d -> %s), %s: %s ms  (%.1f GB/s of source)" % (
+        m, n, xd, label, " ".join("%.1f" % (1e3 * t) for t in ts), X.nbytes / min(ts) / 1e9), flush=True)
+eng.close()
 pr = cProfile.Profile()
 pr.enable()
 call()
