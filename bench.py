@@ -33,6 +33,70 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak at the nominal clock (same guide: ~2.5 PF dense, never the 2:1-sparsity figure)
+NOMINAL_CLOCK_GHZ = 2.4
+
+
+def stored_counters(workload):
+    """What the counter passes of this round left under profiles/ for `workload`, IF they were taken on the sweep kernel this
+    tree builds (`sweep_sources_sha16`, prmf_amd/_build.py): HBM bytes per sweep launch (separate --pmc FETCH_SIZE / WRITE_SIZE
+    passes, FETCH x2 on gfx950: tools/pmc_summary.py) and the shader clock held under the kernel (GRBM_GUI_ACTIVE / 8 /
+    duration: tools/pmc_mfma_summary.py).  A measurement of another kernel is not reported."""
+    from prmf_amd._build import sweep_sources_sha16
+    stamp = sweep_sources_sha16()
+    out = {"traffic": None, "clock_ghz": None, "sweep_sources_sha16": stamp, "stale": []}
+    for key, fname, field in (("traffic", "pmc_traffic_%s.json", "hbm_bytes_per_sweep_launch"), ("clock_ghz", "pmc_mfma_%s.json", "effective_clock_ghz")):
+        path = os.path.join(ROOT, "profiles", fname % workload)
+        if not os.path.exists(path):
+            continue
+        d = json.load(open(path))
+        if d.get("sweep_sources_sha16") == stamp:
+            out[key] = d.get(field)
+        else:
+            out["stale"].append(os.path.basename(path))
+    return out
+
+
+def sweep_roofline(workload, x_dtype, ml, n, k, ms_xv, ms_xtu, step_s, nnz_active, sup_active):
+    """The roofline block of one workload from the average durations of its two sweep launches (HIP events on the launch
+    stream, this run) and the duration of a whole iteration.  BOTH bounds are priced and `bound` names the one that binds:
+      hbm   algorithmic bytes per launch (the data matrix once + the factor once + the product once: SURVEY 8d) / 8 TB/s
+      mfma  matrix instructions ISSUED per launch -- every product runs hi + lo of the factor (2 bf16 MFMAs; f32 X: three
+            exact pieces of X against hi / lo, 5) on the latent columns padded to 32 -- / the dense bf16 peak AT THE CLOCK THE
+            CHIP HOLDS under this kernel (counter measurement, profiles/pmc_mfma_<workload>.json; nominal 2.4 GHz if none)."""
+    eb = 2 if x_dtype == "bf16" else 4
+    kp = (k + 31) // 32 * 32
+    bytes_launch = 0.5 * ((ml * n * eb + n * k * 4 + ml * k * 4) + (ml * n * eb + ml * k * 4 + n * k * 4))
+    avg_ms = 0.5 * (ms_xv + ms_xtu)
+    gbs = bytes_launch / (avg_ms * 1e-3) / 1e9
+    flops_launch = 2.0 * ml * n * k                                   # the product itself
+    issued = (2 if x_dtype == "bf16" else 5) * 2.0 * ml * n * kp      # what the matrix pipe executes for it
+    tflops_issued = issued / (avg_ms * 1e-3) / 1e12
+    sc = stored_counters(workload)
+    clock = sc["clock_ghz"]
+    peak_at_clock = MFMA_BF16_PEAK_TFLOPS * (clock / NOMINAL_CLOCK_GHZ) if clock else None
+    t_hbm = bytes_launch / (HBM_PEAK_GBS * 1e9)
+    t_mfma = issued / ((peak_at_clock or MFMA_BF16_PEAK_TFLOPS) * 1e12)
+    bound = "mfma" if t_mfma > t_hbm else "hbm"
+    bytes_iter = 2.0 * ml * n * eb + 12.0 * (ml + n) * k + 8.0 * nnz_active + 12.0 * sup_active
+    hbm = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "floor_ms": 1e3 * t_hbm}
+    mfma = {"achieved": tflops_issued, "peak": peak_at_clock or MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tflops_issued / (peak_at_clock or MFMA_BF16_PEAK_TFLOPS), "floor_ms": 1e3 * t_mfma,
+            "peak_nominal": MFMA_BF16_PEAK_TFLOPS, "frac_of_nominal": tflops_issued / MFMA_BF16_PEAK_TFLOPS,
+            "clock_ghz": clock, "clock_source": ("profiles/pmc_mfma_%s.json" % workload) if clock else "none for this kernel: nominal %.1f GHz" % NOMINAL_CLOCK_GHZ,
+            "issued_flops_per_launch": issued, "mfma_per_product": 2 if x_dtype == "bf16" else 5, "k_padded": kp}
+    top = hbm if bound == "hbm" else mfma
+    rf = {"bound": bound, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+          "traffic": sc["traffic"], "traffic_ratio": (sc["traffic"] / bytes_launch) if sc["traffic"] else None,
+          "traffic_source": {"sweep_sources_sha16": sc["sweep_sources_sha16"], "stale_measurements_not_reported": sc["stale"]},
+          "hbm": hbm, "mfma": mfma, "tflops": flops_launch / (avg_ms * 1e-3) / 1e12,
+          "kernel": "sweep_kernel (X*V and X^T*U, 2 launches/iteration)",
+          "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_flops_per_launch": flops_launch,
+          "avg_launch_ms": avg_ms, "ms_xv": ms_xv, "ms_xtu": ms_xtu,
+          "sweep_share_of_step": 2 * avg_ms / (1e3 * step_s),
+          "iteration_bytes": bytes_iter, "iteration_frac": bytes_iter / step_s / 1e9 / HBM_PEAK_GBS,
+          "iteration_floor_ms": 2e3 * max(t_hbm, t_mfma), "iteration_frac_of_binding_floor": 2 * max(t_hbm, t_mfma) / step_s}
+    return rf
 
 
 def parse():
@@ -45,6 +109,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the measurements next to the headline: pure-stream calibration, update-only rate, outer loop")
+    ap.add_argument("--secondary", default="auto",
+                    help="the other BASELINE workloads measured after the headline and reported under `secondary`: a comma list of "
+                         "c2, c3f32, c5, c4_share_of_8, c5_share_of_8; `auto` (default): all of them after the c3 headline, none "
+                         "after another workload; `none`")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--cpu-baseline-size", default="auto", choices=["auto", "full", "sample"],
                     help="CPU baseline at the full matrix, on the bounded row sample (extrapolated), or full when the host memory allows (auto)")
@@ -229,6 +297,132 @@ def outer_loop(torch, Xd, n, k, P, x_dtype, seed, iterations=100):
             "host_matrix_gb": X.nbytes / 1e9}
 
 
+def measure_single(torch, name, seed, steps, warmup, reps):
+    """One more workload on this GPU, measured like the headline (median of `reps` timed blocks of `steps` iterations, then a
+    short pass with HIP events around the sweep launches) -- the numbers the driver's record had no line for until round 6."""
+    from prmf_amd import PathwayLibrary
+    from prmf_amd import synthetic as syn
+    from prmf_amd.solver import PrmfEngine
+    m, n, k, P, x_dtype = syn.CONFIGS[name]
+    dev = "cuda:%d" % torch.cuda.current_device()
+    Xd = syn.x_rows_torch(torch, dev, seed, n, k, 0, m, torch.bfloat16 if x_dtype == "bf16" else torch.float32)
+    eng = PrmfEngine(m, n, k, x_dtype=x_dtype)
+    try:
+        norm_x = math.sqrt(eng.set_x(Xd))
+        del Xd
+        pathways = syn.tree_pathways(n, P, 300, seed)
+        eng.set_library(PathwayLibrary.from_edge_lists(n, pathways))
+        active = [kk % P for kk in range(k)]
+        eng.set_active(active)
+        gamma, delta = norm_x / k, 10.0 / norm_x
+        U = syn.init_factor_torch(torch, dev, seed + 1, m, k)
+        V = syn.init_factor_torch(torch, dev, seed + 2, n, k)
+        eng.step(U, V, warmup, gamma, delta)
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            objs, _ = eng.step(U, V, steps, gamma, delta)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        el = sorted(ts)[len(ts) // 2]
+        eng.set_timing(True)
+        eng.step(U, V, min(steps, 20), gamma, delta)
+        torch.cuda.synchronize()
+        ms_xv, ms_xtu, _ = eng.timing()
+        rf = sweep_roofline(name, x_dtype, m, n, k, ms_xv, ms_xtu, el / steps,
+                            sum(2 * len(pathways[p][0]) for p in active), sum(len(pathways[p][2]) for p in active))
+        return {"workload": "%dx%d (%s), k=%d, P=%d" % (m, n, x_dtype, k, P), "it_per_s": steps / el, "ms_per_step": 1e3 * el / steps,
+                "steps": steps, "reps": reps, "sweep_ms": [ms_xv, ms_xtu], "bound": rf["bound"], "frac": rf["frac"],
+                "hbm_frac": rf["hbm"]["frac"], "mfma_frac": rf["mfma"]["frac"], "mfma_clock_ghz": rf["mfma"]["clock_ghz"],
+                "iteration_frac": rf["iteration_frac"], "iteration_frac_of_binding_floor": rf["iteration_frac_of_binding_floor"],
+                "traffic_ratio": rf["traffic_ratio"], "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"],
+                "issued_flops_per_launch": rf["mfma"]["issued_flops_per_launch"], "recon_err": objs[-1]["recon"]}
+    finally:
+        eng.close()
+
+
+def measure_share(torch, name, nranks, seed, iters, whole_ms):
+    """Device time of ONE rank's share of an N-rank run on this GPU: the real kernel sequence of the column-sharded mode at
+    the real share shape through the host-driven phase calls, with device copies standing in for the two exchanges (no
+    wire: the numbers of the solve are meaningless, the kernels and their sizes are the real ones).  `whole_ms`: the
+    one-GPU iteration of the global problem measured in this run -> the scaling the share allows BEFORE any exchange."""
+    from prmf_amd import PathwayLibrary
+    from prmf_amd import synthetic as syn
+    from prmf_amd.solver import PrmfEngine
+    m, n, k, P, x_dtype = syn.CONFIGS[name]
+    dev = "cuda:%d" % torch.cuda.current_device()
+    lo, hi = syn.shard_rows(m, nranks, 0)
+    Xd = syn.x_rows_torch(torch, dev, seed, n, k, lo, hi, torch.bfloat16 if x_dtype == "bf16" else torch.float32)
+    eng = PrmfEngine(hi - lo, n, k, x_dtype=x_dtype, nranks=nranks, rank=0, dist_mode="colshard")
+    try:
+        eng.set_x(Xd, norm_x_sq=float(nranks) * eng.local_norm_sq(Xd))
+        del Xd
+        eng.set_library(PathwayLibrary.from_edge_lists(n, syn.tree_pathways(n, P, 300, seed)))
+        eng.set_active([kk % P for kk in range(k)])
+        U = syn.init_factor_torch(torch, dev, seed + 1, m, k, lo, hi)
+        V = syn.init_factor_torch(torch, dev, seed + 2, n, k)
+        b = eng.comm_buffers()
+        eng.set_timing(True)
+        ts = []
+        for _ in range(3):
+            V.copy_(syn.init_factor_torch(torch, dev, seed + 2, n, k))
+            eng.invalidate_factors()
+            eng.begin(U, V, 1.0, 1.0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _i in range(iters):
+                eng.phase_u()
+                eng.phase_q()
+                b["q_recv"].copy_(b["q_send"][:b["q_recv"].numel()])                              # stand-in for the reduce-scatter
+                eng.phase_v()
+                b["v_recv"].view(nranks, -1).copy_(b["v_send"].unsqueeze(0).expand(nranks, -1))   # stand-in for the all-gather
+                eng.phase_post()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+            try:
+                eng.end(iters)
+            except FloatingPointError:
+                pass
+        ms = 1e3 * sorted(ts)[1] / iters
+        ms_xv, ms_xtu, _ = eng.timing()
+        eb = 2 if x_dtype == "bf16" else 4
+        ml = hi - lo
+        bytes_launch = ml * n * eb + 2.0 * (n + ml) * k           # average of the two sweeps: matrix once + factor once + product once
+        bytes_iter = 2.0 * ml * n * eb + 12.0 * (ml + n) * k
+        return {"workload": "rank 0 of %d of %dx%d (%s), k=%d: %d rows" % (nranks, m, n, x_dtype, k, ml), "ms_per_iteration_device": ms,
+                "iterations": iters, "sweep_ms": [ms_xv, ms_xtu], "other_kernels_ms": ms - ms_xv - ms_xtu,
+                "sweep_hbm_frac": bytes_launch / (0.5e-3 * (ms_xv + ms_xtu)) / 1e9 / HBM_PEAK_GBS,
+                "iteration_frac": bytes_iter / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "whole_problem_ms_one_gpu": whole_ms, "speedup_bound_before_exchanges": (whole_ms / ms) if whole_ms else None,
+                "note": "two device copies stand in for the reduce-scatter and the all-gather; no wire time is in this number"}
+    finally:
+        eng.close()
+
+
+def secondary_workloads(torch, args, c3_ms, names):
+    """The workloads BASELINE.json names besides the headline, each measured in this run on this box."""
+    out = {}
+    plan = (("c2", 40, 10, 3), ("c3f32", 20, 5, 3), ("c5", 10, 3, 3))
+    for name, steps, warmup, reps in plan:
+        if name not in names:
+            continue
+        try:
+            out[name] = measure_single(torch, name, args.seed, steps, warmup, reps)
+        except Exception as e:        # a workload that does not fit this box must not take the headline line with it
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    for name, whole, label in (("c3", c3_ms, "c4_share_of_8"), ("c5", out.get("c5", {}).get("ms_per_step"), "c5_share_of_8")):
+        if label not in names:
+            continue
+        try:
+            out[label] = measure_share(torch, name, 8, args.seed, 30, whole)
+        except Exception as e:
+            out[label] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    return out
+
+
 def run_rank(args, ranks, proc):
     """One rank of the benchmark.  `ranks`: prmf_amd.ranks protocol (processes or threads); proc: the process-mode
     settings (local rank, backend) or None for thread ranks."""
@@ -297,22 +491,10 @@ def run_rank(args, ranks, proc):
     torch.cuda.synchronize(dev_index)
     ms_xv, ms_xtu, _ = eng.timing() if hi > lo else (float("nan"), float("nan"), 0)
     eng.set_timing(False)
-    eb = 2 if x_dtype == "bf16" else 4
     ml = hi - lo
-    # algorithmic bytes per sweep launch: the data matrix once + the factor once + the product once
-    bytes_launch = 0.5 * ((ml * n * eb + n * k * 4 + ml * k * 4) + (ml * n * eb + ml * k * 4 + n * k * 4))
-    avg_ms = 0.5 * (ms_xv + ms_xtu)
-    achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
-    # Every sweep runs on the bf16 MFMA (bf16 X: 2 instructions per 16-element product with the hi/lo factor; f32 X: 5, the
-    # three-piece split).  At the nominal 2.5 PFLOP/s even the heaviest case (f32 X, k = 128: 5 x 2 m n k = 8e11 flop
-    # per launch = 0.32 ms) is no slower than its HBM time at 8 TB/s (0.31 ms), so HBM is the roof for every workload;
-    # DESIGN.md section 5 has the clock the chip actually sustains under these kernels.
-    flops_launch = 2.0 * ml * n * k
-    tflops = flops_launch / (avg_ms * 1e-3) / 1e12
-    # whole-iteration roofline: B = 2 m n s_X + 12 (m + n) k + 8 sum nnz + 12 sum |S|
     nnz_active = sum(2 * len(pathways[p][0]) for p in active)
     sup_active = sum(len(pathways[p][2]) for p in active)
-    bytes_iter = 2.0 * ml * n * eb + 12.0 * (ml + n) * k + 8.0 * nnz_active + 12.0 * sup_active
+    rf = sweep_roofline(args.workload, x_dtype, ml, n, k, ms_xv, ms_xtu, elapsed / args.steps, nnz_active, sup_active)
 
     extras = {}
     if not multi and not args.no_extras:
@@ -348,10 +530,6 @@ def run_rank(args, ranks, proc):
 
     out = None
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.workload)
-        if not multi and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_sweep_launch")
         native = runner.native if runner else None
         out = {
             "metric": "nmf_update_iterations_per_sec", "value": args.steps / elapsed, "unit": "iterations/s",
@@ -368,16 +546,10 @@ def run_rank(args, ranks, proc):
                                        "X row-sharded x%d, V update %s, RCCL %s" % (
                                            world, eng.dist_mode, "in-library" if native else "host-driven"))},
             "recon_err": objs[-1]["recon"], "objective": objs[-1]["obj"],
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "tflops": tflops},
+            "roofline": rf,
         }
-        out["roofline"].update({"traffic": traffic,
-                                "kernel": "sweep_kernel (X*V and X^T*U, 2 launches/iteration)",
-                                "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_flops_per_launch": flops_launch,
-                                "avg_launch_ms": avg_ms, "ms_xv": ms_xv, "ms_xtu": ms_xtu,
-                                "sweep_share_of_step": 2 * avg_ms / (1e3 * elapsed / args.steps),
-                                "iteration_bytes": bytes_iter,
-                                "iteration_frac": bytes_iter / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS})
+        if multi:
+            rf["traffic"] = rf["traffic_ratio"] = None          # the counter passes were taken on the single-GPU shapes
         if "stream" in extras:
             out["roofline"].update(extras["stream"])
         if "update_only" in extras:
@@ -404,6 +576,12 @@ def run_rank(args, ranks, proc):
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, Xd, U0, V0, pathways, active, gamma, delta, m, args.cpu_seconds, args.cpu_baseline_size)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        names = {"auto": ["c2", "c3f32", "c5", "c4_share_of_8", "c5_share_of_8"] if (args.workload == "c3" and not args.no_extras) else [],
+                 "none": []}.get(args.secondary, [x for x in args.secondary.split(",") if x])
+        if names:
+            del Xd, U, V, U0, V0
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_workloads(torch, args, out["ms_per_step"] if args.workload == "c3" else None, names)
     return out
 
 

@@ -40,7 +40,11 @@ enum prmf_status {
   PRMF_ERR_STATE = -3,       /* call order violated (e.g. step before set_x) */
   PRMF_ERR_NUMERIC = -4,     /* NaN/Inf in the objective: the reference would raise
                                 FloatingPointError (np.seterr(divide='raise'), prmf_runner.py:22) */
-  PRMF_ERR_UNSUPPORTED = -5
+  PRMF_ERR_UNSUPPORTED = -5,
+  PRMF_ERR_IO = -7,          /* prmf_write_csv: the file could not be opened / written; prmf_last_error(NULL) = "...: errno N: text"
+                                (the Python host raises OSError(N, ...) as DataFrame.to_csv would) */
+  PRMF_ERR_DECLINED = -6     /* prmf_nnls: the problem's conditioning is beyond the method used here; NO answer was written
+                                (the caller solves it another way -- the Python host calls scipy, as the reference does) */
 };
 
 enum prmf_x_dtype {
@@ -321,9 +325,10 @@ int prmf_cv_error(prmf_ctx* ctx, const float* dV, double* err_out, void* stream)
  * -- the Lawson-Hanson active-set method as there; gradient, column inner products and residual on the device, the
  * passive-set factor on the host, one refinement step per solve.  b (equations) and x (unknowns) are HOST arrays;
  * *rnorm_out (nullable) = || A x - b ||_2, *iterations_out (nullable) = active-set steps taken; max_iter <= 0: 3 x the
- * number of unknowns (scipy's default); PRMF_ERR_NUMERIC when it is exceeded ("maximum number of iterations reached") and
- * when the passive-set factor (normal equations) loses a problem whose conditioning is beyond it ("ill-conditioned passive
- * set": no answer is returned rather than a wrong one; the caller falls back to scipy's orthogonal factorisation).
+ * number of unknowns (scipy's default); PRMF_ERR_NUMERIC when it is exceeded ("maximum number of iterations reached");
+ * PRMF_ERR_DECLINED when the passive-set factor (normal equations) loses a problem whose conditioning is beyond it -- the
+ * passive columns became dependent, a descent direction was refused, or a gradient cannot be resolved: no answer is
+ * returned rather than a wrong one; the caller falls back to scipy's orthogonal factorisation).
  * Both problems have a unique minimiser for data in general position, so the result equals scipy's up to rounding
  * (tests/test_gpu_nnls_matrix.py: 1e-9).  Synchronises `stream`; no context needed.
  */
@@ -396,7 +401,8 @@ int prmf_text_destroy(prmf_text* text);
  * ended by "\n".  header_line (nullable): written first as it is (the caller quotes the labels and ends the line);
  * row_prefixes / row_prefix_offsets (both or neither): the bytes that start row r -- its quoted label and the separator
  * -- are row_prefixes[row_prefix_offsets[r] .. row_prefix_offsets[r + 1]).  values: rows x cols, leading dimension ld,
- * HOST memory.  n_threads < 1: one per core, at most 16.  Host work only (no device, no context).
+ * HOST memory.  n_threads < 1: one per core, at most 16.  Host work only (no device, no context).  PRMF_ERR_IO when the
+ * file cannot be created or written (errno in the message).
  */
 int prmf_write_csv(const char* path, const char* header_line, const char* row_prefixes, const int64_t* row_prefix_offsets,
                    const double* values, int64_t rows, int64_t cols, int64_t ld, char separator, int n_threads);

@@ -28,6 +28,21 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+SWEEP_SOURCES = ["gemm.hip", "prologue.h", "kernels.h", "bf16split.h"]
+
+
+def sweep_sources_sha16():
+    """Fingerprint of the sources the sweep kernel is built from.  Counter measurements kept under profiles/ (HBM traffic,
+    the clock held under the kernel) carry it, and bench.py reports them only while it still matches: the kernel cannot
+    change without this changing."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SWEEP_SOURCES:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
     """Compile every translation unit for gfx950 and link the shared library."""
     if not force and not _stale():

@@ -26,7 +26,7 @@ PRMF_TEXT_RAGGED, PRMF_TEXT_QUOTED, PRMF_TEXT_NOT_NUMERIC, PRMF_TEXT_WIDE_INT, P
 OBJ_KEYS = ("recon", "manifold", "ignore", "fro", "gamma", "delta", "obj")
 
 PRMF_OK = 0
-PRMF_ERR_ARG, PRMF_ERR_HIP, PRMF_ERR_STATE, PRMF_ERR_NUMERIC, PRMF_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+PRMF_ERR_ARG, PRMF_ERR_HIP, PRMF_ERR_STATE, PRMF_ERR_NUMERIC, PRMF_ERR_UNSUPPORTED, PRMF_ERR_DECLINED, PRMF_ERR_IO = -1, -2, -3, -4, -5, -6, -7
 
 
 class CommSizes(C.Structure):

@@ -1884,7 +1884,7 @@ int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t 
       if ((rc = upload_list())) return rc;
       if (np == 0) break;
       for (int a = 0; a < np; ++a)
-        if (!chol_row(G, L, a)) return fail(nullptr, PRMF_ERR_NUMERIC, "prmf_nnls: passive columns became dependent");
+        if (!chol_row(G, L, a)) return fail(nullptr, PRMF_ERR_DECLINED, "prmf_nnls: ill-conditioned passive set (the passive columns became dependent to 1e-13); not solved");
       if ((rc = solve_passive())) return rc;
     }
     for (int a = 0; a < np; ++a) xs[(size_t)a] = sv[(size_t)a];
@@ -1898,7 +1898,7 @@ int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t 
     need_gradient = true;
   }
   if (suspect)
-    return fail(nullptr, PRMF_ERR_NUMERIC, "prmf_nnls: ill-conditioned passive set (a descent direction was refused); not solved");
+    return fail(nullptr, PRMF_ERR_DECLINED, "prmf_nnls: ill-conditioned passive set (a descent direction was refused); not solved");
   // "No free unknown descends" is only as good as the inner products that say so.  Where the residual has become so small next to b
   // AS A COLUMN SEES IT (sum |a_tj b_t| against sum |a_tj r_t|: rows of wildly different scales) that a gradient below 1e-8 of its
   // own magnitude could not be told from rounding, an orthogonal factorisation can still make progress and this method cannot know:
@@ -1917,7 +1917,7 @@ int prmf_nnls(int device, const double* dX, int64_t rows, int64_t cols, int64_t 
       NN_TRY(hipStreamSynchronize(s));
       for (int64_t jj = 0; jj < nvec; ++jj)
         if (st[(size_t)jj] != 1 && ba[(size_t)jj] > 0.0 && c2 * ba[(size_t)jj] > 1e-8 * wa[(size_t)jj])
-          return fail(nullptr, PRMF_ERR_NUMERIC, "prmf_nnls: ill-conditioned problem (the gradient of unknown %lld cannot be resolved to 1e-8); not solved", (long long)jj);
+          return fail(nullptr, PRMF_ERR_DECLINED, "prmf_nnls: ill-conditioned problem (the gradient of unknown %lld cannot be resolved to 1e-8); not solved", (long long)jj);
     }
   }
   for (int a = 0; a < np; ++a) x[P[(size_t)a]] = xs[(size_t)a];
@@ -2167,7 +2167,7 @@ int prmf_write_csv(const char* path, const char* header_line, const char* row_pr
   }
   if (rows * cols < 65536) n_threads = 1;
   const int err = text_write_matrix(path, header_line, row_prefixes, row_prefix_offsets, values, rows, cols, ld, separator, n_threads);
-  if (err) return text_fail(nullptr, PRMF_ERR_ARG, "prmf_write_csv(%s): %s", path, err > 0 ? std::strerror(err) : "write failed");
+  if (err) return text_fail(nullptr, PRMF_ERR_IO, "prmf_write_csv(%s): errno %d: %s", path, err > 0 ? err : 5, err > 0 ? std::strerror(err) : "write failed");
   return PRMF_OK;
 }
 

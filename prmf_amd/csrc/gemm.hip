@@ -928,7 +928,7 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
   p.panels = (int)(round_up(M, p.panel_rows) / p.panel_rows);
   p.nchunks = (int)(Kpad / chunk_elems(x_dtype));          // even (K_PAD)
   p.ngroups = p.nchunks / UNIT;                            // work units per row panel
-  // one workgroup per resident slot (a multiple of 8: one share per XCD), but at least 8 chunks each
+  // one workgroup per resident slot (a multiple of 8: one share per XCD); fewer for a matrix too small to give every slot work:
   int64_t G = (int64_t)n_cus * (p.nw == SWEEP_NW_WIDE ? 1 : SWEEP_WGS_PER_CU);
   const int64_t total_units = (int64_t)p.panels * p.ngroups;
   // A matrix too small to give every slot work: down to 4 chunks per workgroup while that still fills one workgroup per CU,

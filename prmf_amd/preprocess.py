@@ -55,6 +55,9 @@ def _to_device_f64(torch, X, device):
         return torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(dev)
     if X.dtype.kind in "iu" and X.dtype.itemsize == 8:
         return torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(dev)      # 64-bit integers: numpy's own rounding
+    if X.dtype not in (np.float32, np.float16, np.int8, np.int16, np.int32, np.uint8):
+        # uint16 / uint32 / long double ...: torch.from_numpy does not take them; widened on the host
+        return torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(dev)
     out = torch.empty(X.shape, dtype=torch.float64, device=dev)
     rows = max(1, (160 << 20) // max(1, X.shape[1] * X.dtype.itemsize))
     for r0 in range(0, X.shape[0], rows):
@@ -118,6 +121,10 @@ class DeviceNnls(object):
         self.shape = X.shape
         self.Xd = _to_device_f64(torch, X, self.device).contiguous()
         self._torch = torch
+        # scipy.optimize.nnls refuses a matrix with NaN / inf (ValueError); prmf_nnls would find no candidate in a NaN
+        # gradient and return x = 0 with PRMF_OK.  One reduction on the device, once per matrix.
+        if not bool(torch.isfinite(self.Xd).all().item()):
+            raise ValueError("array must not contain infs or NaNs")
 
     def nnls(self, b, transposed=False):
         """-> (x, rnorm) like scipy.optimize.nnls(X.T if transposed else X, b)."""
@@ -133,10 +140,9 @@ class DeviceNnls(object):
         stream = C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
         rc = self.lib.prmf_nnls(self.device, C.c_void_p(self.Xd.data_ptr()), m, n, n, 1 if transposed else 0,
                                 b.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.byref(rnorm), C.byref(iters), 0, stream)
+        if rc == _capi.PRMF_ERR_DECLINED:          # a status of its own: every refusal, whatever its wording
+            raise NnlsDeclined(self.lib.prmf_last_error(None).decode())
         if rc == _capi.PRMF_ERR_NUMERIC:
-            msg = self.lib.prmf_last_error(None).decode()
-            if "ill-conditioned" in msg:
-                raise NnlsDeclined(msg)
             raise RuntimeError("Maximum number of iterations reached.")          # scipy's words
         if rc != _capi.PRMF_OK:
             raise _capi.PrmfError(rc, self.lib.prmf_last_error(None).decode())

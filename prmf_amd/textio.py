@@ -72,6 +72,14 @@ def read_frame(path, delimiter, has_header, has_row_names, device=0, why=None, m
         if why is not None:
             why.append(str(e))
         return None
+    except _capi.PrmfError as e:
+        # a HIP failure on the way (text + 16 B per field must fit the free HBM; every rank of a multi-process run reads):
+        # a file pandas can read is still read -- by pandas.  Argument / call-order errors are bugs and surface.
+        if e.code != _capi.PRMF_ERR_HIP:
+            raise
+        if why is not None:
+            why.append("the GPU reader failed (%s)" % e)
+        return None
 
 
 def wanted(path):
@@ -224,5 +232,10 @@ def write_frame(path, values, index, columns):
     rc = lib.prmf_write_csv(os.fsencode(path), header, prefixes, offsets.ctypes.data_as(C.c_void_p) if offsets is not None else None,
                             a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], a.shape[1], b",", 0)
     del keep
+    if rc == _capi.PRMF_ERR_IO:      # what DataFrame.to_csv raises for the same failure (script/prmf_runner.py:1068-1071)
+        import re
+        msg = lib.prmf_last_error(None).decode("utf-8", "replace")
+        hit = re.search(r"errno (\d+): (.*)$", msg)
+        raise OSError(int(hit.group(1)) if hit else 5, hit.group(2) if hit else msg, os.fspath(path))
     _capi.check(lib, None, rc)
     return True

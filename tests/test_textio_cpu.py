@@ -150,6 +150,8 @@ def test_writer_leaves_what_is_not_plain_to_pandas(tmp_path):
     assert not textio.write_frame(out, a, [True, False, True], ["a", "b"])
     assert not textio.write_frame(out, a, None, ["a", 2])
     assert not os.path.exists(out)
-    from prmf_amd import _capi
-    with pytest.raises(_capi.PrmfError):
+    # an I/O failure is the exception DataFrame.to_csv raises for it (PRMF_ERR_IO -> OSError with the errno)
+    with pytest.raises(OSError) as ei:
         textio.write_frame(str(tmp_path / "no" / "such" / "dir.csv"), a, None, ["a", "b"])
+    import errno
+    assert ei.value.errno == errno.ENOENT

@@ -48,6 +48,9 @@ def main():
     sweeps = [v for k, v in res["kernels"].items() if k.startswith("sweep_kernel")]
     if sweeps:
         res["hbm_bytes_per_sweep_launch"] = sum(v["hbm_bytes_per_launch"] for v in sweeps) / len(sweeps)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from prmf_amd._build import sweep_sources_sha16
+    res["sweep_sources_sha16"] = sweep_sources_sha16()       # the kernel these counters belong to (bench.py reports them only while it matches)
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res["kernels"].items():
         print("%-60s fetch %10.2f MB  write %9.2f MB per launch (%d launches)" % (k[:60], v["fetch_bytes_per_launch"] / 1e6,
