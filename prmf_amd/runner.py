@@ -36,6 +36,9 @@ from argparse import RawTextHelpFormatter
 
 import numpy as np
 
+MAX_K_LATENT = 128      # libprmf_hip: 1 <= k <= 128 (include/prmf_hip.h, prmf_create)
+EXIT_K_LATENT = 26      # exit code of a --k-latent beyond it (the reference's own codes are 22-25, script/prmf_runner.py:904-993)
+
 
 def add_prmf_arguments(parser):
     """Flag surface of prmf/prmf_args.py:7-26."""
@@ -420,6 +423,12 @@ Solve an optimization problem of the form
                         help="multi-GPU V update: sharded by latent columns (default) or replicated on every rank")
     args = parser.parse_args(argv)
 
+    if args.k_latent > MAX_K_LATENT:
+        # the reference takes any --k-latent (prmf/prmf_args.py:14); this build's kernels tile the latent columns into at most
+        # four 32-column MFMA tiles (prmf_create: PRMF_ERR_UNSUPPORTED).  Said here, before any input is read.
+        sys.stderr.write("prmf_runner (MI355X build): --k-latent %d is not supported: libprmf_hip handles at most %d latent factors "
+                         "(the reference implementation has no such limit)\n" % (args.k_latent, MAX_K_LATENT))
+        sys.exit(EXIT_K_LATENT)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and args.n_gpus > 1 and args.launcher == "threads":
         if args.seed is None:

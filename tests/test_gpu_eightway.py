@@ -636,6 +636,7 @@ def _medium_pathway_worker(world, mode, q):
     q.put((res, Ur, Vr, [t["obj"] for t in t_ref], r_ref, [[int(p) for p, _s in mr[kk]] for kk in sorted(mr)]))
 
 
+@pytest.mark.slow
 def test_nmf_pathway_at_medium_size_on_five_ranks_vs_oracle(mock):
     """The sharded outer solver where the goldens do not reach (700 x 3000, k = 12 on FIVE ranks: kc = 3, ranks 4 owns no
     column; 40 candidate pathways, several `restrict` rounds, the matching): every rank returns the same result, and it is

@@ -22,10 +22,12 @@ def _run(script, seed, cases, timeout):
     assert ("all %d " % cases) in r.stdout, tail
 
 
+@pytest.mark.slow
 def test_random_shapes_vs_oracle():
     _run("fuzz_shapes.py", seed=11, cases=60, timeout=600)
 
 
+@pytest.mark.slow
 def test_random_shapes_through_the_multi_rank_step():
     _run("fuzz_ranks.py", seed=12, cases=40, timeout=600)
 

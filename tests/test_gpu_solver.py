@@ -99,6 +99,7 @@ def test_score_candidates_vs_reference(golden_dir, name, kw):
     eng.close()
 
 
+@pytest.mark.slow
 def test_score_candidates_at_c5_shape_vs_oracle():
     """`restrict`'s score matrix (prmf_runner.py:115-127) at the shape of BASELINE.json configs[4] -- 25000 genes,
     k = 128, P = 1000 pathways of 300 genes -- against oracle.score_latent_pathway_match on sampled (latent, pathway)
@@ -430,6 +431,7 @@ def test_cli_library_cache(golden_dir, tmp_path):
     assert max(obj_txt_errors(vals, json.loads(str(g["obj_txt"]))).values()) < TOL_OBJ
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("m,n,k,P,x_dtype", [(700, 3000, 12, 40, "f32"), (300, 9000, 20, 64, "bf16")])
 def test_outer_solver_at_medium_size_vs_oracle(m, n, k, P, x_dtype):
     """The whole outer loop (prmf_runner.py:556-792: per-round pathway sampling, candidate scoring, `restrict`, the

@@ -131,6 +131,22 @@ def test_cli_exit_codes(tmp_path):
     r = _run_cli(["--data", c["data"], "--outdir", out, "--manifolds", c["manifolds"][0], "--delimiter", "\t",
                   "--nodelist", bad_nodes], out)
     assert r.returncode == 24 and "Invalid manifolds" in r.stderr
+    # the one limit this build has and the reference has not (prmf/prmf_args.py:14 takes any -k): more than 128 latent factors.
+    # Declared before any input is read, with an exit code of its own; 128 itself is accepted by the parser stage.
+    r = _run_cli(["--data", c["data"], "--outdir", out, "--manifolds", c["manifolds"][0], "--delimiter", "\t", "--nodelist", c["nodelist"],
+                  "-k", "160"], out)
+    assert r.returncode == 26 and "--k-latent 160 is not supported" in r.stderr and "at most 128" in r.stderr
+    assert not os.path.exists(os.path.join(out, "U.csv"))
+
+
+def test_library_refuses_more_than_128_latent_columns():
+    """prmf_create returns PRMF_ERR_UNSUPPORTED for k > 128 (include/prmf_hip.h) -- checked before any device is touched"""
+    import ctypes as C
+    from prmf_amd import _capi
+    lib = _capi.load()
+    ctx = C.c_void_p()
+    assert lib.prmf_create(C.byref(ctx), 0, 10, 10, 129, _capi.PRMF_X_F32, 1, 0, 0) == _capi.PRMF_ERR_UNSUPPORTED
+    assert b"129 > 128" in lib.prmf_last_error(None) and not ctx.value
 
 
 def test_verbose_candidate_table_format(capsys):
