@@ -59,7 +59,8 @@ enum prmf_x_dtype {
  * anyway), which is exact to ~1e-8 ||X||^2 at k <= 64 and ~1e-7 ||X||^2 at k > 64 (float32 accumulation of X^T U)
  * -- i.e. recon to that fraction times (||X|| / recon)^2 / 2.  The reference materialises X - U V^T (:337) and never
  * cancels, so when the identity value drops below 2e-4 ||X||^2 (k <= 64: recon / ||X|| < 1.4%) resp. 2e-3 ||X||^2
- * (k > 64: 4.5%) -- plus 0.13 / sqrt(min(m, n) k) of ||X||^2 for small factors, whose 16-bit packing for the sweeps
+ * (k > 64: 4.5%; times samples-per-rank / 32768 beyond 32768 samples per rank: the error of that accumulation chain grows
+ * with its length) -- plus 0.13 / sqrt(min(m, n) k) of ||X||^2 for small factors, whose 16-bit packing for the sweeps
  * does not average out -- the library evaluates sum (X - U V^T)^2 directly with one more sweep over X: for the LAST record of a
  * prmf_step / prmf_end batch (the one the outer loop's convergence test reads, :772-774).  With the tradeoff feedback
  * on (recon feeds gamma every step, :542-548) or PRMF_FLAG_DIRECT_RESIDUAL set, EVERY record takes the direct residual,

@@ -439,7 +439,16 @@ bool direct_forced(const prmf_ctx* c) { return (c->flags & PRMF_FLAG_DIRECT_RESI
 double direct_below(const prmf_ctx* c) {
   const int64_t m_all = c->nranks == 1 ? c->m : (c->m_global >= 0 ? c->m_global : c->n);
   const double entries = (double)(m_all < c->n ? (m_all > 0 ? m_all : 1) : c->n) * c->k;
-  return ((c->NT <= 2 ? RECON_DIRECT_THRESHOLD_LO : RECON_DIRECT_THRESHOLD) + RECON_DIRECT_FACTOR_TERM / std::sqrt(entries)) * c->norm_x_sq;
+  // k > 64 (one accumulator chain for the hi and lo products): the error of <X^T U, V> grows with the length of that chain --
+  // the samples one rank reduces over.  Measured: 8.4e-8 ||X||^2 at 25000 samples, 4.5e-7 at 200000 (the whole of BASELINE
+  // configs[4] on one GPU: recon 4.6e-5 off at a 7 % fit, profiles/r05_parity_measured.jsonl), so the threshold scales with it
+  // (rank-invariant: the global count over the ranks, rounded up).
+  double chain = 1.0;
+  if (c->NT > 2) {
+    const double rows = std::ceil((double)(m_all > 0 ? m_all : 1) / (double)c->nranks);
+    if (rows > RECON_DIRECT_CHAIN_ROWS) chain = rows / RECON_DIRECT_CHAIN_ROWS;
+  }
+  return ((c->NT <= 2 ? RECON_DIRECT_THRESHOLD_LO : RECON_DIRECT_THRESHOLD * chain) + RECON_DIRECT_FACTOR_TERM / std::sqrt(entries)) * c->norm_x_sq;
 }
 
 // The launches behind a record whose kernel may have raised c->need_dev: sum (X - U V^T)^2 over this rank's rows (the

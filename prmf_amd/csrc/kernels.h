@@ -30,7 +30,8 @@ constexpr int REC_FLAG_DIRECT = 1, REC_FLAG_IMPRECISE = 2, REC_FLAG_CLAMPED = 4;
 // (every f32 X sweep; bf16 X at k <= 64), ~1e-7 at k > 64.  Below these fractions of ||X||^2 the relative error of recon
 // passes ~2.5e-5 and the direct residual takes over (recon / ||X|| < 1.4% resp. 4.5%).
 constexpr double RECON_DIRECT_THRESHOLD_LO = 2e-4;      // k <= 64
-constexpr double RECON_DIRECT_THRESHOLD = 2e-3;         // k > 64
+constexpr double RECON_DIRECT_THRESHOLD = 2e-3;         // k > 64, reductions of up to RECON_DIRECT_CHAIN_ROWS samples per rank;
+constexpr double RECON_DIRECT_CHAIN_ROWS = 32768.0;     //   longer ones: x (samples per rank / 32768) -- see direct_below (capi.hip)
 // + RECON_DIRECT_FACTOR_TERM / sqrt(min(m, n) k): the rounding of the sweeps' hi/lo-packed factors (16 mantissa bits,
 // 4e-6 per entry) enters <X^T U, V> through the min(m, n) k entries of the smaller factor and only averages over those
 constexpr double RECON_DIRECT_FACTOR_TERM = 0.13;

@@ -128,6 +128,46 @@ static int run_case(int64_t m, int64_t n, int k, int x_dtype, unsigned flags, in
     CK(prmf_cv_error(ctx, dV, err.data(), nullptr));
     for (double e : err) REQUIRE(e >= 0.0 && e <= 1.0 + 1e-9);
   }
+  // the terms of the final matching (ABI 3): finite, the quadratic form of a Laplacian and a sum of positive terms
+  {
+    std::vector<double> quad((size_t)k * P), ign((size_t)k * P);
+    CK(prmf_match_terms(ctx, dV, quad.data(), ign.data(), nullptr));
+    for (size_t i = 0; i < quad.size(); ++i) REQUIRE(std::isfinite(quad[i]) && quad[i] >= -1e-9 && ign[i] > 0.0);
+  }
+  // the one-pass uploads (ABI 3): the same matrix from the HOST (narrowed by worker threads, and on the device) and from the
+  // device in its source type leave the same ||X||^2 as the sum the caller computed, and the same next step
+  {
+    double l_host = -1, l_host0 = -1, l_dev = -1;
+    std::vector<double> o1(PRMF_OBJ_STRIDE), o2(PRMF_OBJ_STRIDE), o3(PRMF_OBJ_STRIDE);
+    float *U2 = nullptr, *V2 = nullptr;
+    HK(hipMalloc(&U2, U.size() * 4 + 16));
+    HK(hipMalloc(&V2, V.size() * 4 + 16));
+    auto one_step = [&](std::vector<double>& o) -> int {
+      HK(hipMemcpy(U2, U.data(), U.size() * 4, hipMemcpyHostToDevice));
+      HK(hipMemcpy(V2, V.data(), V.size() * 4, hipMemcpyHostToDevice));
+      CK(prmf_invalidate_factors(ctx));
+      CK(prmf_step(ctx, U2, V2, 1, gamma, delta, -1.0, o.data(), nullptr, nullptr));
+      return 0;
+    };
+    CK(prmf_set_x_host(ctx, X.data(), PRMF_SRC_F32, n, 3, &l_host, nullptr));
+    if (one_step(o1)) return 1;
+    CK(prmf_set_x_host(ctx, X.data(), PRMF_SRC_F32, n, 0, &l_host0, nullptr));
+    if (one_step(o2)) return 1;
+    float* dXf = nullptr;
+    HK(hipMalloc(&dXf, X.size() * 4));
+    HK(hipMemcpy(dXf, X.data(), X.size() * 4, hipMemcpyHostToDevice));
+    CK(prmf_set_x_device(ctx, dXf, PRMF_SRC_F32, n, &l_dev, nullptr));
+    if (one_step(o3)) return 1;
+    REQUIRE(l_host == l_host0 && l_host == l_dev && std::fabs(l_host - nsq) <= 1e-12 * nsq);
+    REQUIRE(std::memcmp(o1.data(), o2.data(), o1.size() * 8) == 0 && std::memcmp(o1.data(), o3.data(), o1.size() * 8) == 0);
+    REQUIRE(prmf_set_x_host(ctx, X.data(), 7, n, 1, &l_host, nullptr) == PRMF_ERR_ARG);
+    REQUIRE(prmf_set_x_host(ctx, X.data(), PRMF_SRC_F32, n - 1, 1, &l_host, nullptr) == PRMF_ERR_ARG);
+    REQUIRE(prmf_set_norm_x_sq(ctx, -1.0) == PRMF_ERR_ARG);
+    CK(prmf_set_norm_x_sq(ctx, nsq));
+    HK(hipFree(dXf));
+    HK(hipFree(U2));
+    HK(hipFree(V2));
+  }
   // the caller rewrites V: invalidate, step again; then error paths on the live context
   HK(hipMemcpy(dV, V.data(), V.size() * 4, hipMemcpyHostToDevice));
   CK(prmf_invalidate_factors(ctx));
@@ -280,6 +320,8 @@ int main() {
     (void)hipFree(dA);
     (void)hipFree(dAf);
   }
+  REQUIRE(prmf_release_staging() == PRMF_OK);       // the staging buffers prmf_set_x_host keeps between calls
+  REQUIRE(prmf_release_staging() == PRMF_OK);       // (idempotent)
   std::printf("wide OK\n");
   std::fflush(stdout);
 #if defined(__has_feature)

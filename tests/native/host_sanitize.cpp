@@ -134,7 +134,7 @@ int main(int argc, char** argv) {
       CHECK(prmf_write_csv(path, nullptr, nullptr, nullptr, v.data(), 3, 2, 2, ';', 1) == PRMF_OK, "no header, no prefixes");
       unlink(path);
     }
-    CHECK(prmf_write_csv("/nonexistent-dir/x.csv", nullptr, nullptr, nullptr, v.data(), 1, 1, 1, ',', 1) == PRMF_ERR_ARG, "unwritable path");
+    CHECK(prmf_write_csv("/nonexistent-dir/x.csv", nullptr, nullptr, nullptr, v.data(), 1, 1, 1, ',', 1) == PRMF_ERR_IO, "unwritable path");
     CHECK(prmf_write_csv(path, nullptr, prefixes.data(), nullptr, v.data(), 1, 1, 1, ',', 1) == PRMF_ERR_ARG, "prefixes without offsets");
     CHECK(prmf_write_csv(nullptr, nullptr, nullptr, nullptr, v.data(), 1, 1, 1, ',', 1) == PRMF_ERR_ARG, "NULL path");
   }

@@ -166,7 +166,10 @@ def test_whole_round_vs_fp64_at_full_size(workload, x_dtype, steps):
     Laplacians -- at the 1e-4 bar.  Measures the drift of the float32 state over a round at 50000 x 20000, and at
     k = 128 (25000 x 25000 for a round; 200000 x 25000 for three iterations of records), where the identity-based recon
     carries the float32 accumulation error of X^T U (4.5e-5 after one iteration at the full C5 shape):
-    the records of these ordinary fits (recon / ||X|| ~ 10%) must stay identity-based (no flag) AND within the bar."""
+    the records of these ordinary fits (recon / ||X|| ~ 10%) must stay identity-based (no flag) AND within the bar -- except at
+    the whole C5 shape since round 6: with 200000 samples per accumulation chain the threshold below which the batch's LAST
+    record takes the direct residual scales with the chain (capi.hip direct_below), so that record is exact to 1e-5 and flagged
+    DIRECT, the earlier ones of the batch keep the identity value (within the bar) and are flagged IMPRECISE."""
     import torch
     from fp64_model import Fp64Model
     eng, Xd, U, V, pathways, active, gamma, delta = _engine(torch, workload, x_dtype, 17)
@@ -184,8 +187,13 @@ def test_whole_round_vs_fp64_at_full_size(workload, x_dtype, steps):
     res.update(_tile_check(torch, "V", V, V64, 1e-3))
     res["flags"] = int(max(eng.last_flags))
     res["recon_over_normx"] = objs[-1]["recon"] / math.sqrt(eng.norm_x_sq)
+    res["rel_recon_last_record"] = abs(objs[-1]["recon"] - od["recon"]) / od["recon"]
     report("whole_round_vs_fp64[%s-%s]" % (workload, x_dtype), steps=steps, **res)
-    assert res["flags"] == 0, eng.last_flags              # an ordinary fit: the identity value stands, unflagged
+    if workload == "c5":
+        assert eng.last_flags[-1] == 1 and all(f == 2 for f in eng.last_flags[:-1]), eng.last_flags      # DIRECT last, IMPRECISE before
+        assert res["rel_recon_last_record"] < 1e-5, res
+    else:
+        assert res["flags"] == 0, eng.last_flags          # an ordinary fit: the identity value stands, unflagged
     assert res["rel_U"] < 1e-4 and res["rel_V"] < 1e-4, res
     assert res["bad_tiles_U"] == 0 and res["bad_tiles_V"] == 0, res
     for key in OBJ_KEYS:

@@ -127,7 +127,8 @@ def test_full_size_c3_properties(workload, x_dtype):
     fro = float((U.double() ** 2).sum())
     report("full_size_properties[%s-%s]" % (workload, x_dtype), rel_recon=abs(objs[-1]["recon"] - recon) / recon,
            rel_fro=abs(objs[-1]["fro"] - fro) / fro)
-    assert abs(objs[-1]["recon"] - recon) <= 1e-4 * recon, (objs[-1]["recon"], recon)
+    # (whole C5: 200000-sample chains at k = 128 -- the last record of the batch is the direct residual since round 6)
+    assert abs(objs[-1]["recon"] - recon) <= (1e-5 if workload == "c5" else 1e-4) * recon, (objs[-1]["recon"], recon)
     assert abs(objs[-1]["fro"] - fro) <= 1e-5 * fro
     assert objs[-1]["obj"] == pytest.approx(objs[-1]["recon"] + objs[-1]["gamma"] * objs[-1]["manifold"]
                                             + objs[-1]["delta"] * objs[-1]["ignore"] + objs[-1]["fro"], rel=1e-12)
