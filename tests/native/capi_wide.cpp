@@ -158,7 +158,7 @@ static int run_case(int64_t m, int64_t n, int k, int x_dtype, unsigned flags, in
     HK(hipMemcpy(dXf, X.data(), X.size() * 4, hipMemcpyHostToDevice));
     CK(prmf_set_x_device(ctx, dXf, PRMF_SRC_F32, n, &l_dev, nullptr));
     if (one_step(o3)) return 1;
-    REQUIRE(l_host == l_host0 && l_host == l_dev && std::fabs(l_host - nsq) <= 1e-12 * nsq);
+    REQUIRE(l_host == l_host0 && l_host == l_dev && std::fabs(l_host - nsq) <= 1e-10 * nsq);   // (nsq: the naive running sum above, 4e7 terms)
     REQUIRE(std::memcmp(o1.data(), o2.data(), o1.size() * 8) == 0 && std::memcmp(o1.data(), o3.data(), o1.size() * 8) == 0);
     REQUIRE(prmf_set_x_host(ctx, X.data(), 7, n, 1, &l_host, nullptr) == PRMF_ERR_ARG);
     REQUIRE(prmf_set_x_host(ctx, X.data(), PRMF_SRC_F32, n - 1, 1, &l_host, nullptr) == PRMF_ERR_ARG);
