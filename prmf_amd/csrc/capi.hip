@@ -539,6 +539,7 @@ int prmf_create(prmf_ctx** out, int device, int64_t m_local, int64_t n, int k, i
   c->n_cus = n_cus;
   SweepTuning tune;                                     // the library's only tuning hook, for the decomposition test
   if (const char* e = getenv("PRMF_SWEEP_XCD")) tune.force_slices = atoi(e);
+  if (const char* e = getenv("PRMF_SWEEP_NO_EXACT")) tune.no_exact = atoi(e) != 0;
   c->plan_xv = plan_gemm(x_dtype, m_local > 0 ? m_local : 1, c->Kpad_x, c->NT, n_cus, tune);
   c->plan_xtu = plan_gemm(x_dtype, n, c->Kpad_xt, c->NT, n_cus, tune);
   // f32 X: the sweep splits every f32 value of X exactly into three bf16 pieces in registers and runs the
@@ -1188,7 +1189,7 @@ int prmf_phase_u(prmf_ctx* c, void* stream) {
   if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 0], s));
   // P = X V                                             (prmf_runner.py:420)
   HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xv, c->X, c->ldx, c->m, c->Vp, c->NT, c->slabs, c->slab_stride_p, s, c->split_f32,
-                         pro.kind != PROLOGUE_NONE ? &pro : nullptr));
+                         pro.kind != PROLOGUE_NONE ? &pro : nullptr, false, c->V, c->n, c->k));
   if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 1], s));
   c->gv_pending = false;
   // U <- U * P / (U Gv + U)                              (:421-422); the pathway terms of the own columns (they depend on
@@ -1223,7 +1224,7 @@ int prmf_phase_q(prmf_ctx* c, void* stream) {
     const bool in_sweep = gram_in_sweep(c);
     if (in_sweep) pro = mid_prologue(c, c->cursor);
     HIP_TRY(c, launch_gemm(c->x_dtype, c->plan_xtu, c->XT, c->ldxt, c->n, c->Up, c->NT, c->slabs, c->slab_stride_q, s, c->split_f32,
-                           in_sweep ? &pro : nullptr));
+                           in_sweep ? &pro : nullptr, false, c->U, c->m, c->k));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[(size_t)c->cursor * 4 + 3], s));
     // both multi-rank modes exchange Q, so they need its summed dense form (by owner column block)
     if (!c->fused_v || c->replicated)
@@ -2299,7 +2300,7 @@ int prmf_debug_plan_sweep(int x_dtype, long long rows, long long depth, int k, i
   if (!out || rows < 0 || depth < 1 || k < 1 || k > 128 || n_cus < 1 || (x_dtype != PRMF_X_F32 && x_dtype != PRMF_X_BF16)) return PRMF_ERR_ARG;
   const int NT = (k + 31) / 32;
   const GemmPlan p = plan_gemm(x_dtype, rows > 0 ? rows : 1, round_up(depth, K_PAD), NT, n_cus, SweepTuning{});
-  const int v[8] = {p.nw, p.mt, p.panel_rows, p.grid, p.nx, p.max_seg, (p.bdb ? 1 : 0) | (p.pp ? 2 : 0), p.panels};
+  const int v[8] = {p.nw, p.mt, p.panel_rows, p.grid, p.nx, p.max_seg, (p.bdb ? 1 : 0) | (p.pp ? 2 : 0) | (p.exact ? 4 : 0), p.panels};
   for (int i = 0; i < 8; ++i) out[i] = v[i];
   return PRMF_OK;
 }
@@ -2314,7 +2315,7 @@ int prmf_get_sweep_info(const prmf_ctx* c, prmf_sweep_info* out) {
   out->grid_xv = c->plan_xv.grid;
   out->grid_xtu = c->plan_xtu.grid;
   out->f32_split = c->split_f32 ? 1 : 0;
-  out->reserved = 0;
+  out->reserved = (c->plan_xv.exact ? 1 : 0) | (c->plan_xtu.exact ? 2 : 0);      // bit 0 / 1: X V / X^T U is the exact short-reduction product
   return PRMF_OK;
 }
 

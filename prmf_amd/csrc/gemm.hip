@@ -881,6 +881,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 //   Cache by every segment) 2.62 -> 2.21 ms; with a 12.8 MB factor -2% at 25000 rows and +7% at 200000 rows -- hence the
 //   threshold.
 constexpr int SWEEP_NW = 4, SWEEP_MT = 2, SWEEP_WGS_PER_CU = 2, SWEEP_NW_WIDE = 8;
+constexpr int EXACT_MAX_K = 1024, EXACT_PANEL_ROWS = 256;      // the exact short-reduction product (exact_product_kernel below)
 #ifndef PRMF_WIDE_MB
 #define PRMF_WIDE_MB 32.0
 #endif
@@ -898,6 +899,24 @@ static int f32_wave_tiles(int x_dtype, int NT) { return (x_dtype == 0 && NT != 2
 
 GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, const SweepTuning& tune) {
   GemmPlan p;
+  if (Kpad <= EXACT_MAX_K && !tune.no_exact) {
+    // a short reduction: the exact float32 product, one slab per panel (exact_product_kernel)
+    p.exact = true;
+    p.nw = 4;
+    p.mt = 1;
+    p.bdb = false;
+    p.panel_rows = EXACT_PANEL_ROWS;
+    p.panels = (int)(round_up(M, p.panel_rows) / p.panel_rows);
+    p.nchunks = (int)(Kpad / 32);
+    p.ngroups = p.nchunks;
+    p.grid = (int)(((int64_t)p.panels * p.panel_rows / 32 * NT + 3) / 4);
+    p.nx = 1;
+    p.pmax = 1;
+    p.max_seg = 1;
+    p.slab_nt = false;
+    p.segmask.assign(p.panels, segmask_t(1));
+    return p;
+  }
   p.nw = SWEEP_NW;
   p.bdb = NT <= 2;
   p.mt = f32_wave_tiles(x_dtype, NT);
@@ -1085,12 +1104,131 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Short reductions (round 6): the exact product
+// ---------------------------------------------------------------------------
+// The streaming sweep multiplies with the factor packed to hi + lo bf16: 16-17 mantissa bits.  Over a long reduction that
+// rounding averages out (1.1e-6 / sqrt(K) per latent column: 5e-9 at 50000 samples); over a SHORT one it does not -- every
+// output row of a column gets the same relative shift, because X is positive and every row sums the same K rounded factor
+// entries: 1.5e-7 at 301 samples, 3e-7 at 100 (the reference's own test problems), which the normalised objective terms and
+// the tradeoff feedback amplify (profiles/r06_first_step_errors.txt: on the reference's 100 x 1000 case the packing IS the
+// library's error -- trace 1.7e-6 with it, 1.2e-8 without, tools/packing_model_small.py).  A reduction of at most
+// EXACT_MAX_K elements (after padding) therefore runs on v_mfma_f32_32x32x2_f32 -- exact float32 products, a fused
+// multiply-add chain bit for bit (the guide) -- against the float32 factor itself, unpacked.  1/16 of the bf16 rate on a
+// product that is microseconds long: 500 x 20000, k = 6 (the reference's typical use): X^T U 15 us as before.
+//
+// One wave per (32-row tile, 32-column tile); the A tile of a 32-element chunk travels line-complete into a wave-private
+// LDS tile (row stride 36 floats), the 16 B-fragment values of the chunk come straight from the factor (L2), both one
+// chunk ahead of the 16 MFMAs that consume them.  The result leaves as slab 0 in the sweep's fragment order: every
+// consumer (fused epilogues, dense-Q sum, prmf_debug_slab_sum) reads it as a panel with one segment.
+
+template <bool A_BF16>
+__global__ void __launch_bounds__(256) exact_product_kernel(const void* __restrict__ Av, int64_t lda /* elements */, int nchunks,
+                                                            const float* __restrict__ B, int64_t k_valid, int k, int NT,
+                                                            int64_t npairs, float* __restrict__ slab) {
+  __shared__ __attribute__((aligned(16))) float tileA[4][2][32 * 36];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
+  if (pair >= npairs) return;                      // (no workgroup barrier below: the tile is wave-private)
+  const int64_t tile = pair / NT;
+  const int t = (int)(pair % NT);
+  const int r = lane & 31, h = lane >> 5;
+  const int col = 32 * t + r;
+  const float colmask = col < k ? 1.f : 0.f;
+  const int colc = col < k ? col : k - 1;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  u32x4 a_next[4];
+  float b_next[16];
+  auto issue = [&](int c) {
+    if (A_BF16) {        // 32 rows x 64 B: lane -> row 16 j + (lane >> 2), 16-B piece lane & 3 (8 values)
+      const unsigned short* A = (const unsigned short*)Av + (tile * 32) * lda + (int64_t)c * 32;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        a_next[j] = *reinterpret_cast<const u32x4*>(A + (int64_t)(16 * j + (lane >> 2)) * lda + 8 * (lane & 3));
+    } else {             // 32 rows x 128 B: lane -> row 8 j + (lane >> 3), 16-B piece lane & 7 (4 values)
+      const float* A = (const float*)Av + (tile * 32) * lda + (int64_t)c * 32;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        a_next[j] = *reinterpret_cast<const u32x4*>(A + (int64_t)(8 * j + (lane >> 3)) * lda + 4 * (lane & 7));
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      int64_t kr = (int64_t)c * 32 + 2 * s2 + h;          // rows past the factor's end meet zero columns of A: clamped, finite
+      kr = kr < k_valid ? kr : k_valid - 1;
+      b_next[s2] = B[kr * k + colc];
+    }
+  };
+  issue(0);
+  for (int c = 0; c < nchunks; ++c) {
+    float* T = tileA[wave][c & 1];
+    float b_cur[16];
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) b_cur[s2] = b_next[s2] * colmask;
+    if (A_BF16) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = 16 * j + (lane >> 2), c0 = 8 * (lane & 3);
+        f32x4 lo4, hi4;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          lo4[2 * e] = __uint_as_float(a_next[j][e] << 16);
+          lo4[2 * e + 1] = __uint_as_float(a_next[j][e] & 0xFFFF0000u);
+          hi4[2 * e] = __uint_as_float(a_next[j][2 + e] << 16);
+          hi4[2 * e + 1] = __uint_as_float(a_next[j][2 + e] & 0xFFFF0000u);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          T[row * 36 + c0 + e] = lo4[e];
+          T[row * 36 + c0 + 4 + e] = hi4[e];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T[(8 * j + (lane >> 3)) * 36 + 4 * (lane & 7) + e] = __uint_as_float(a_next[j][e]);
+    }
+    if (c + 1 < nchunks) issue(c + 1);               // in flight under this chunk's MFMAs
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(T[r * 36 + 2 * s2 + h], b_cur[s2], acc, 0, 0, 0);
+  }
+  f32x4* out = reinterpret_cast<f32x4*>(slab);
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    const f32x4 v = {acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]};
+    out[((tile * NT + t) * 4 + q4) * 64 + lane] = v;
+  }
+}
+
+static hipError_t launch_exact_product(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, const float* B, int64_t k_valid,
+                                       int k, int NT, float* slabs, hipStream_t s) {
+  if (!B || k_valid < 1 || k < 1) return hipErrorInvalidValue;
+  const int64_t tiles = (int64_t)p.panels * p.panel_rows / 32, npairs = tiles * NT;
+  const int nchunks = p.nchunks;                    // 32 reduction elements each (both storages)
+  const unsigned grid = (unsigned)((npairs + 3) / 4);
+  if (x_dtype == 1) exact_product_kernel<true><<<grid, 256, 0, s>>>(A, lda, nchunks, B, k_valid, k, NT, npairs, slabs);
+  else exact_product_kernel<false><<<grid, 256, 0, s>>>(A, lda, nchunks, B, k_valid, k, NT, npairs, slabs);
+  return hipGetLastError();
+}
+
 hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, int64_t M_store,
                        const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s, bool split,
-                       const SweepPrologue* prologue, bool attr_only) {
+                       const SweepPrologue* prologue, bool attr_only, const float* factor, int64_t k_valid, int k) {
   const int64_t lda16 = lda * elem_bytes(x_dtype) / 16;
   SweepPrologue pro = prologue ? *prologue : SweepPrologue{};
   if (pro.kind != PROLOGUE_NONE && pro.nparts > GRAM_MAX_PARTS) return hipErrorInvalidValue;
+  if (p.exact) {                                    // a short reduction: the exact float32 product (see above)
+    if (attr_only) return hipSuccess;
+    if (pro.kind != PROLOGUE_NONE) {
+      if (pro.ncols != 0) return hipErrorInvalidValue;
+      const hipError_t e = launch_prologue_alone(pro, s);
+      if (e != hipSuccess) return e;
+    }
+    return launch_exact_product(x_dtype, p, A, lda, factor, k_valid, k, NT, slabs, s);
+  }
   if (pro.kind != PROLOGUE_NONE && !attr_only) {
     // The prologue's jobs (k^2 / 8 Gram entries + k + 1 column sums) are dealt over the sweep's workgroups.  A small
     // matrix launches few of them (one for 100 x 2000): at k = 64 its 512 jobs then ran one after the other -- 0.79 ms

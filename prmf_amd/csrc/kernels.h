@@ -124,11 +124,14 @@ struct GemmPlan {
   int pmax = 1;             // most workgroups that touch one (panel, slice)
   int max_seg = 1;          // slabs allocated: nx * pmax
   bool slab_nt = true;      // partial slabs leave as non-temporal stores (false: plain stores, small slab volumes)
+  bool exact = false;       // a reduction of <= 1024 elements: exact float32 products against the unpacked factor (gemm.hip,
+                            //   exact_product_kernel), one slab per panel; the fields above then describe that launch
   std::vector<segmask_t> segmask;  // [panels] bit s set <=> slab s holds a segment of this panel
 };
 // Test hooks, read from the environment ONCE per prmf_create (capi.hip) -- the planner itself takes no knobs.
 struct SweepTuning {
   int force_slices = 0;     // PRMF_SWEEP_XCD = 1 | 2 | 4 | 8: force the number of reduction slices (decomposition-equivalence test)
+  bool no_exact = false;    // PRMF_SWEEP_NO_EXACT = 1: short reductions through the streaming sweep too (A/B and equivalence tests)
 };
 GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, const SweepTuning& tune);
 // debug only (prmf_debug_set_stamps): layout of the sweep's stamp buffer, in uint64 entries.  Fixed regions that do not
@@ -147,7 +150,9 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
                        const void* packedB, int NT, float* slabs, int64_t slab_stride, hipStream_t s,
                        bool split = false /* f32 X as three bf16 pieces, packedB in the bf16 hi/lo layout */,
                        const SweepPrologue* prologue = nullptr /* runs inside the sweep when its jobs fit the grid, else as a launch of its own */,
-                       bool attr_only = false /* launch nothing: raise the kernel's dynamic-LDS limit on the current device (prmf_create) */);
+                       bool attr_only = false /* launch nothing: raise the kernel's dynamic-LDS limit on the current device (prmf_create) */,
+                       const float* factor = nullptr /* exact plans: the float32 factor itself [k_valid][k], row-major */,
+                       int64_t k_valid = 0, int k = 0);
 hipError_t launch_stream_read(const void* p, size_t bytes, int n_cus, void* sink /* >= 2 n_cus ints, never written */, hipStream_t s);
 // Pathway terms of the V update as extra workgroups of the U epilogue launch (they depend on the OLD V and gamma / delta
 // only; the epilogue leaves a quarter of the chip's slots idle and runs longer than the terms' dependent-load chain, so

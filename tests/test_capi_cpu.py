@@ -139,7 +139,16 @@ def test_sweep_plans_of_the_benchmark_shapes():
     tiny = plan(F32, 100, 2000, 6)
     assert tiny["grid"] == 32 and tiny["max_slabs"] <= 64
     assert plan(F32, 2000, 2000, 6)["grid"] == 256 and plan(F32, 500, 2000, 6)["grid"] == 128
-    assert plan(F32, 500, 20000, 6)["grid"] == 256 and plan(F32, 20000, 500, 6)["grid"] == 512      # the reference's typical size
+    assert plan(F32, 500, 20000, 6)["grid"] == 256      # the reference's typical size: X V (depth 20000) streams as before ...
+    # ... and X^T U, a reduction over 500 samples, is the EXACT short-reduction product since round 6 (depth <= 1024 after padding:
+    # float32 MFMA against the unpacked factor, one slab per 256-row panel, one wave per (32-row tile, 32-column tile); bit 2)
+    xtu = plan(F32, 20000, 500, 6)
+    assert (xtu["double_buffered"] & 4, xtu["panel_rows"], xtu["max_slabs"], xtu["slices"], xtu["panels"]) == (4, 256, 1, 1, 79)
+    assert xtu["grid"] == (79 * 8 * 1 + 3) // 4
+    assert plan(BF16, 20000, 1024, 64)["double_buffered"] & 4 and not plan(BF16, 20000, 1025, 64)["double_buffered"] & 4
+    assert plan(F32, 1000, 100, 6)["double_buffered"] & 4 and plan(F32, 100, 1000, 6)["double_buffered"] & 4      # the reference's test problems: both
+    for xd, rows, depth, k in ((BF16, 50000, 20000, 64), (BF16, 20000, 50000, 64), (F32, 10000, 5000, 16), (BF16, 20000, 6250, 64)):
+        assert not plan(xd, rows, depth, k)["double_buffered"] & 4                                  # no benchmark shape is touched
     # bad arguments
     out = (C.c_int * 8)()
     assert lib.prmf_debug_plan_sweep(BF16, 10, 0, 4, 256, out) == _capi.PRMF_ERR_ARG
