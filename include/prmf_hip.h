@@ -425,7 +425,7 @@ typedef struct prmf_sweep_info {
   int32_t grid_xv, grid_xtu;
   int32_t f32_split;        /* 1: f32 X, multiplied as three bf16 pieces on the bf16 MFMA; 0: bf16 X */
   int32_t reserved;         /* bit 0 / bit 1: the X*V / X^T*U product is the EXACT short-reduction form (a reduction of at most
-                               1024 elements: float32 MFMA against the unpacked factor instead of the hi/lo bf16 sweep) */
+                               512 / (32-column tiles) elements: float32 MFMA against the unpacked factor instead of the hi/lo bf16 sweep) */
 } prmf_sweep_info;
 int prmf_get_sweep_info(const prmf_ctx* ctx, prmf_sweep_info* out);
 

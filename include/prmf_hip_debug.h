@@ -52,7 +52,7 @@ int prmf_debug_resident_x(prmf_ctx* ctx, int which, void* out_host);
  * touched (the CPU test suite pins the plan of every benchmark shape with it).  x_dtype as in prmf_create; n_cus = compute
  * units of the device (256 on MI355X).  out[8] = { waves per workgroup, 32-row tiles per wave, panel rows, workgroups,
  * reduction slices, slabs per panel (upper bound), bit 0: factor chunk double-buffered, bit 1: ping-pong chunk loop, bit 2: the
- * exact short-reduction product (depth <= 1024 after padding), panels }. */
+ * exact short-reduction product (padded depth x column tiles <= 512), panels }. */
 int prmf_debug_plan_sweep(int x_dtype, long long rows, long long depth, int k, int n_cus, int* out);
 
 /* Calibration: a pure stream of the resident matrix (which = 0: the padded copy of X, 1: of X^T) -- one workgroup per

@@ -881,7 +881,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 //   Cache by every segment) 2.62 -> 2.21 ms; with a 12.8 MB factor -2% at 25000 rows and +7% at 200000 rows -- hence the
 //   threshold.
 constexpr int SWEEP_NW = 4, SWEEP_MT = 2, SWEEP_WGS_PER_CU = 2, SWEEP_NW_WIDE = 8;
-constexpr int EXACT_MAX_K = 1024, EXACT_PANEL_ROWS = 256;      // the exact short-reduction product (exact_product_kernel below)
+constexpr int EXACT_MAX_K = 512, EXACT_PANEL_ROWS = 256;      // the exact short-reduction product (exact_product_kernel below): padded depth x column tiles <= 512
 #ifndef PRMF_WIDE_MB
 #define PRMF_WIDE_MB 32.0
 #endif
@@ -899,7 +899,7 @@ static int f32_wave_tiles(int x_dtype, int NT) { return (x_dtype == 0 && NT != 2
 
 GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, const SweepTuning& tune) {
   GemmPlan p;
-  if (Kpad <= EXACT_MAX_K && !tune.no_exact) {
+  if (Kpad * NT <= EXACT_MAX_K && !tune.no_exact) {
     // a short reduction: the exact float32 product, one slab per panel (exact_product_kernel)
     p.exact = true;
     p.nw = 4;
@@ -909,12 +909,18 @@ GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, cons
     p.panels = (int)(round_up(M, p.panel_rows) / p.panel_rows);
     p.nchunks = (int)(Kpad / 32);
     p.ngroups = p.nchunks;
-    p.grid = (int)(((int64_t)p.panels * p.panel_rows / 32 * NT + 3) / 4);
+    // reduction slices (= slabs per panel): enough waves for eight per CU, at least two chunks per slice, at most 8
+    const int64_t pairs = (int64_t)p.panels * p.panel_rows / 32 * NT;
+    int64_t sl = (8 * (int64_t)n_cus + pairs - 1) / pairs;
+    if (sl > p.nchunks / 2) sl = p.nchunks / 2;
+    if (sl > 8) sl = 8;
+    if (sl < 1) sl = 1;
     p.nx = 1;
-    p.pmax = 1;
-    p.max_seg = 1;
+    p.pmax = (int)sl;
+    p.max_seg = (int)sl;
+    p.grid = (int)((pairs * sl + 3) / 4);
     p.slab_nt = false;
-    p.segmask.assign(p.panels, segmask_t(1));
+    p.segmask.assign(p.panels, (segmask_t(1) << sl) - 1);
     return p;
   }
   p.nw = SWEEP_NW;
@@ -1115,21 +1121,37 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
 // library's error -- trace 1.7e-6 with it, 1.2e-8 without, tools/packing_model_small.py).  A reduction of at most
 // EXACT_MAX_K elements (after padding) therefore runs on v_mfma_f32_32x32x2_f32 -- exact float32 products, a fused
 // multiply-add chain bit for bit (the guide) -- against the float32 factor itself, unpacked.  1/16 of the bf16 rate on a
-// product that is microseconds long: 500 x 20000, k = 6 (the reference's typical use): X^T U 15 us as before.
+// product that is microseconds long (tools/ab_exact_product.py).  Longer reductions gain less (the shift falls like
+// 1 / sqrt(K)) and pay more (the float32 pipe, in proportion to depth x column tiles): the limit is
+// (padded depth) x (32-column tiles) <= 512 -- 512 samples at k <= 32, 256 at k <= 64, 128 at k <= 128.  Measured against the
+// streaming form in one session: 500 x 20000, k = 6 (the reference's typical use) 57.8 -> 60.2 us per iteration, 100 x 1000
+// 34.4 -> 35.2 us; at k = 64 / 128 with 500 samples it would have been +12 % (hence the product rule).
 //
-// One wave per (32-row tile, 32-column tile); the A tile of a 32-element chunk travels line-complete into a wave-private
+// One wave per (32-row tile, 32-column tile, reduction slice); the A tile of a 32-element chunk travels line-complete into a wave-private
 // LDS tile (row stride 36 floats), the 16 B-fragment values of the chunk come straight from the factor (L2), both one
-// chunk ahead of the 16 MFMAs that consume them.  The result leaves as slab 0 in the sweep's fragment order: every
-// consumer (fused epilogues, dense-Q sum, prmf_debug_slab_sum) reads it as a panel with one segment.
+// chunk ahead of the 16 MFMAs that consume them.  A slice's result leaves as slab `slice` in the sweep's fragment order:
+// every consumer (fused epilogues, dense-Q sum, prmf_debug_slab_sum) reads a panel with that many segments.
 
 template <bool A_BF16>
 __global__ void __launch_bounds__(256) exact_product_kernel(const void* __restrict__ Av, int64_t lda /* elements */, int nchunks,
                                                             const float* __restrict__ B, int64_t k_valid, int k, int NT,
-                                                            int64_t npairs, float* __restrict__ slab) {
+                                                            int nslices, int64_t npairs, float* __restrict__ slabs, int64_t slab_stride,
+                                                            const SweepPrologue pro) {
   __shared__ __attribute__((aligned(16))) float tileA[4][2][32 * 36];
+  if (pro.kind != PROLOGUE_NONE) {                 // the reductions that ride in a sweep ride here too (uniform branch)
+    run_sweep_prologue(pro, reinterpret_cast<char*>(&tileA[0][0][0]), (int)sizeof(tileA));
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
-  if (pair >= npairs) return;                      // (no workgroup barrier below: the tile is wave-private)
+  const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+  if (item >= npairs * nslices) return;            // (no workgroup barrier below: the tile is wave-private)
+  // a (tile, column tile) pair is shared by `nslices` waves, each a contiguous range of the reduction chunks and a slab of
+  // its own (summed in slab order by the consumer): a short product on few rows would otherwise be a handful of waves
+  // walking their chunks one memory round trip at a time
+  const int slice = (int)(item / npairs);
+  const int64_t pair = item % npairs;
+  const int c_lo = (int)((int64_t)nchunks * slice / nslices), c_hi = (int)((int64_t)nchunks * (slice + 1) / nslices);
+  float* const slab = slabs + (int64_t)slice * slab_stride;
   const int64_t tile = pair / NT;
   const int t = (int)(pair % NT);
   const int r = lane & 31, h = lane >> 5;
@@ -1160,8 +1182,8 @@ __global__ void __launch_bounds__(256) exact_product_kernel(const void* __restri
       b_next[s2] = B[kr * k + colc];
     }
   };
-  issue(0);
-  for (int c = 0; c < nchunks; ++c) {
+  if (c_lo < c_hi) issue(c_lo);
+  for (int c = c_lo; c < c_hi; ++c) {
     float* T = tileA[wave][c & 1];
     float b_cur[16];
 #pragma unroll
@@ -1190,10 +1212,16 @@ __global__ void __launch_bounds__(256) exact_product_kernel(const void* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) T[(8 * j + (lane >> 3)) * 36 + 4 * (lane & 7) + e] = __uint_as_float(a_next[j][e]);
     }
-    if (c + 1 < nchunks) issue(c + 1);               // in flight under this chunk's MFMAs
+    if (c + 1 < c_hi) issue(c + 1);                  // in flight under this chunk's MFMAs
+    // the chunk's 32 products in a chain of their own, then ONE addition into the running sum: a float32 chain's rounding
+    // grows like the root of its length -- sqrt(16 + K / 32) instead of sqrt(K / 2) steps (3 x less at K = 1024)
+    f32x16 part;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[i] = 0.f;
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(T[r * 36 + 2 * s2 + h], b_cur[s2], acc, 0, 0, 0);
+      part = __builtin_amdgcn_mfma_f32_32x32x2f32(T[r * 36 + 2 * s2 + h], b_cur[s2], part, 0, 0, 0);
+    acc += part;
   }
   f32x4* out = reinterpret_cast<f32x4*>(slab);
 #pragma unroll
@@ -1204,13 +1232,13 @@ __global__ void __launch_bounds__(256) exact_product_kernel(const void* __restri
 }
 
 static hipError_t launch_exact_product(int x_dtype, const GemmPlan& p, const void* A, int64_t lda, const float* B, int64_t k_valid,
-                                       int k, int NT, float* slabs, hipStream_t s) {
+                                       int k, int NT, float* slabs, int64_t slab_stride, hipStream_t s, const SweepPrologue& pro) {
   if (!B || k_valid < 1 || k < 1) return hipErrorInvalidValue;
   const int64_t tiles = (int64_t)p.panels * p.panel_rows / 32, npairs = tiles * NT;
   const int nchunks = p.nchunks;                    // 32 reduction elements each (both storages)
-  const unsigned grid = (unsigned)((npairs + 3) / 4);
-  if (x_dtype == 1) exact_product_kernel<true><<<grid, 256, 0, s>>>(A, lda, nchunks, B, k_valid, k, NT, npairs, slabs);
-  else exact_product_kernel<false><<<grid, 256, 0, s>>>(A, lda, nchunks, B, k_valid, k, NT, npairs, slabs);
+  const unsigned grid = (unsigned)((npairs * p.max_seg + 3) / 4);
+  if (x_dtype == 1) exact_product_kernel<true><<<grid, 256, 0, s>>>(A, lda, nchunks, B, k_valid, k, NT, p.max_seg, npairs, slabs, slab_stride, pro);
+  else exact_product_kernel<false><<<grid, 256, 0, s>>>(A, lda, nchunks, B, k_valid, k, NT, p.max_seg, npairs, slabs, slab_stride, pro);
   return hipGetLastError();
 }
 
@@ -1224,10 +1252,14 @@ hipError_t launch_gemm(int x_dtype, const GemmPlan& p, const void* A, int64_t ld
     if (attr_only) return hipSuccess;
     if (pro.kind != PROLOGUE_NONE) {
       if (pro.ncols != 0) return hipErrorInvalidValue;
-      const hipError_t e = launch_prologue_alone(pro, s);
-      if (e != hipSuccess) return e;
+      const int jobs = gram_reduce_jobs(pro.k) + (pro.kind == PROLOGUE_POST ? pro.k + 1 : 0);
+      if (jobs > 4 * p.grid) {                      // too few workgroups to share the jobs: a launch of their own (as for the sweep)
+        const hipError_t e = launch_prologue_alone(pro, s);
+        if (e != hipSuccess) return e;
+        pro = SweepPrologue{};
+      }
     }
-    return launch_exact_product(x_dtype, p, A, lda, factor, k_valid, k, NT, slabs, s);
+    return launch_exact_product(x_dtype, p, A, lda, factor, k_valid, k, NT, slabs, slab_stride, s, pro);
   }
   if (pro.kind != PROLOGUE_NONE && !attr_only) {
     // The prologue's jobs (k^2 / 8 Gram entries + k + 1 column sums) are dealt over the sweep's workgroups.  A small

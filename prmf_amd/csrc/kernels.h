@@ -124,7 +124,7 @@ struct GemmPlan {
   int pmax = 1;             // most workgroups that touch one (panel, slice)
   int max_seg = 1;          // slabs allocated: nx * pmax
   bool slab_nt = true;      // partial slabs leave as non-temporal stores (false: plain stores, small slab volumes)
-  bool exact = false;       // a reduction of <= 1024 elements: exact float32 products against the unpacked factor (gemm.hip,
+  bool exact = false;       // a short reduction (padded depth x column tiles <= 512): exact float32 products against the unpacked factor (gemm.hip,
                             //   exact_product_kernel), one slab per panel; the fields above then describe that launch
   std::vector<segmask_t> segmask;  // [panels] bit s set <=> slab s holds a segment of this panel
 };
