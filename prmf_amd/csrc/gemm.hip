@@ -881,7 +881,7 @@ sweep_kernel(const uint4* __restrict__ A, int64_t lda16 /* row stride in 16-B un
 //   Cache by every segment) 2.62 -> 2.21 ms; with a 12.8 MB factor -2% at 25000 rows and +7% at 200000 rows -- hence the
 //   threshold.
 constexpr int SWEEP_NW = 4, SWEEP_MT = 2, SWEEP_WGS_PER_CU = 2, SWEEP_NW_WIDE = 8;
-constexpr int EXACT_MAX_K = 512, EXACT_PANEL_ROWS = 256;      // the exact short-reduction product (exact_product_kernel below): padded depth x column tiles <= 512
+constexpr int EXACT_MAX_K = 512, EXACT_PANEL_ROWS = 256, EXACT_WIDE_ROWS = 4096;      // the exact short-reduction product (exact_product_kernel below): padded depth x column tiles <= 512; depth <= 1024 at one column tile
 #ifndef PRMF_WIDE_MB
 #define PRMF_WIDE_MB 32.0
 #endif
@@ -899,7 +899,7 @@ static int f32_wave_tiles(int x_dtype, int NT) { return (x_dtype == 0 && NT != 2
 
 GemmPlan plan_gemm(int x_dtype, int64_t M, int64_t Kpad, int NT, int n_cus, const SweepTuning& tune) {
   GemmPlan p;
-  if (Kpad * NT <= EXACT_MAX_K && !tune.no_exact) {
+  if ((Kpad * NT <= EXACT_MAX_K || (NT == 1 && Kpad <= 2 * EXACT_MAX_K && M <= EXACT_WIDE_ROWS)) && !tune.no_exact) {
     // a short reduction: the exact float32 product, one slab per panel (exact_product_kernel)
     p.exact = true;
     p.nw = 4;
@@ -1123,7 +1123,9 @@ static hipError_t launch_sweep_nt(const GemmPlan& p, const void* A, int64_t lda1
 // multiply-add chain bit for bit (the guide) -- against the float32 factor itself, unpacked.  1/16 of the bf16 rate on a
 // product that is microseconds long (tools/ab_exact_product.py).  Longer reductions gain less (the shift falls like
 // 1 / sqrt(K)) and pay more (the float32 pipe, in proportion to depth x column tiles): the limit is
-// (padded depth) x (32-column tiles) <= 512 -- 512 samples at k <= 32, 256 at k <= 64, 128 at k <= 128.  Measured against the
+// (padded depth) x (32-column tiles) <= 512 -- 512 samples at k <= 32, 256 at k <= 64, 128 at k <= 128 -- and a depth of up
+// to 1024 at k <= 32 when the product has at most 4096 rows (X V of the reference's 100-sample, 1000-gene test problems: few
+// tiles, so the float32 pipe costs nothing there; with 20000 rows the same depth measured +13 % on the iteration).  Measured against the
 // streaming form in one session: 500 x 20000, k = 6 (the reference's typical use) 57.8 -> 60.2 us per iteration, 100 x 1000
 // 34.4 -> 35.2 us; at k = 64 / 128 with 500 samples it would have been +12 % (hence the product rule).
 //

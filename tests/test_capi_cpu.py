@@ -145,13 +145,16 @@ def test_sweep_plans_of_the_benchmark_shapes():
     xtu = plan(F32, 20000, 500, 6)
     assert (xtu["double_buffered"] & 4, xtu["panel_rows"], xtu["max_slabs"], xtu["slices"], xtu["panels"]) == (4, 256, 4, 1, 79)
     assert xtu["grid"] == (79 * 8 * 1 * 4 + 3) // 4            # 632 (tile, column tile) pairs x 4 reduction slices, 4 waves per workgroup
-    # the limit is (padded depth) x (32-column tiles) <= 512: the float32 pipe's cost grows with both
+    # the limit is (padded depth) x (32-column tiles) <= 512 (the float32 pipe's cost grows with both)
     assert plan(F32, 20000, 512, 32)["double_buffered"] & 4 and not plan(F32, 20000, 513, 32)["double_buffered"] & 4
+    # one column tile and at most 4096 rows (X V of a few hundred samples over <= 1024 genes): depth up to 1024
+    assert plan(F32, 4096, 1024, 32)["double_buffered"] & 4 and not plan(F32, 4097, 1024, 32)["double_buffered"] & 4
+    assert not plan(F32, 4096, 1025, 32)["double_buffered"] & 4 and not plan(F32, 100, 1024, 64)["double_buffered"] & 4
     assert plan(BF16, 20000, 256, 64)["double_buffered"] & 4 and not plan(BF16, 20000, 257, 64)["double_buffered"] & 4
     assert plan(BF16, 20000, 128, 128)["double_buffered"] & 4 and not plan(BF16, 20000, 129, 128)["double_buffered"] & 4
-    # the reference's test problems (100 samples): X^T U exact -- few rows, so 2 slices of its 4 chunks --, X V (1000 genes) streams
+    # the reference's test problems (100 samples x 1000 genes, k = 6): X^T U exact -- few rows, so 2 slices of its 4 chunks --, X V (1000 genes) too
     small = plan(F32, 1000, 100, 6)
-    assert small["double_buffered"] & 4 and small["max_slabs"] == 2 and not plan(F32, 100, 1000, 6)["double_buffered"] & 4
+    assert small["double_buffered"] & 4 and small["max_slabs"] == 2 and plan(F32, 100, 1000, 6)["double_buffered"] & 4
     for xd, rows, depth, k in ((BF16, 50000, 20000, 64), (BF16, 20000, 50000, 64), (F32, 10000, 5000, 16), (BF16, 20000, 6250, 64)):
         assert not plan(xd, rows, depth, k)["double_buffered"] & 4                                  # no benchmark shape is touched
     # bad arguments

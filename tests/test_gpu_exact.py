@@ -74,7 +74,8 @@ def test_short_reductions_are_exact_and_unbiased(m, n, k, x_dtype):
                              U=U, V=V, obj=od)
     nt = (k + 31) // 32
     pad = lambda d: (d + 127) // 128 * 128
-    want = (1 if pad(n) * nt <= 512 else 0) | (2 if pad(m) * nt <= 512 else 0)
+    short = lambda d, rows: pad(d) * nt <= 512 or (nt == 1 and pad(d) <= 1024 and rows <= 4096)
+    want = (1 if short(n, m) else 0) | (2 if short(m, n) else 0)
     assert want & 2
     assert got[False]["flags"] == want and got[True]["flags"] == 0
     e, s = got[False], got[True]

@@ -13,7 +13,8 @@ from prmf_amd import PathwayLibrary, synthetic as syn  # noqa: E402
 from prmf_amd.solver import PrmfEngine  # noqa: E402
 
 SHAPES = [(500, 20000, 6, "f32"), (100, 1000, 6, "f32"), (500, 20000, 64, "bf16"), (512, 20000, 128, "bf16"), (300, 9000, 20, "bf16"),
-          (500, 500, 16, "f32"), (20000, 400, 64, "bf16"), (13, 1000, 6, "f32"), (1000, 20000, 64, "bf16")]
+          (500, 500, 16, "f32"), (20000, 400, 64, "bf16"), (13, 1000, 6, "f32"), (1000, 20000, 64, "bf16"), (1000, 20000, 6, "f32"),
+          (1000, 20000, 32, "bf16"), (250, 20000, 64, "bf16")]
 for m, n, k, xd in SHAPES:
     row = []
     for no_exact in (True, False, True, False):
