@@ -225,12 +225,12 @@ def test_tradeoff_feedback_on_eight_ranks(mock, world, k, mode, m, steps):
 
     What the 1e-4 on the final gamma means here (round 6, profiles/r06_tradeoff_digits.txt, r06_first_step_errors.txt): in the
     301-sample case gamma runs from 12 to 2e33 in six steps and the recursion multiplies an error of the state by ~3 per step
-    (the float64 oracle itself turns a 1e-7 relative perturbation of U0, V0 into up to 7e-6 on the final gamma); the single-rank
-    step shows the same 9.2e-5 as the eight ranks, so nothing is lost in the exchanges.  The digits go where the manifold term
-    is normalised: the sweeps multiply with factors packed to 16-17 mantissa bits, and over 301 samples that rounding does not
-    average out -- every gene of a latent column gets the same relative shift (~1.5e-7), the column norm moves with it, and
-    v^T L v / ||v||^2 with it (3.2e-7 after ONE step, where an all-float32 NumPy iteration shows 2e-8).  At 50000 samples the
-    same shift is 5e-9.  The bar holds; what would widen it is a third bf16 piece of the factor for short reductions."""
+    (the float64 oracle itself turns a 1e-7 relative perturbation of U0, V0 into up to 7e-6 on the final gamma).  Through round
+    5 the library landed at 9.3e-5 -- one rank and eight alike, so nothing was lost in the exchanges: the digits went where the
+    manifold term is normalised, because the sweeps multiply with factors packed to 16-17 mantissa bits and over 301 samples
+    that rounding does not average out (every gene of a latent column gets the same relative shift, the column norm moves with
+    it).  Since round 6 a reduction this short is multiplied exactly (csrc/gemm.hip: exact_product_kernel): 3.0e-5 on eight
+    ranks, 1.6e-5 on one."""
     from oracle import prmf_oracle as orc
     runs = _in_worker(_small_tradeoff_worker, (world, k, mode, m, steps), {"PRMF_RCCL_LIB": mock, "MOCK_RCCL_TIMEOUT_S": "60"}, deadline_s=600)
     for a, b in zip(runs[0], runs[1]):

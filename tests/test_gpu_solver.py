@@ -21,6 +21,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # both sides were rounded).  U.csv / V.csv hold full-precision reprs and get the plain 1e-4 bar.
 TOL_FACTOR = 1e-4
 TOL_OBJ = 1e-4
+# Round 6: on the reference's own problems (100 samples) both big products are exact float32 (csrc/gemm.hip: exact_product_kernel)
+# and whole solves of 70-1000 iterations follow the reference to 1-2e-6 (3-4e-5 before: profiles/r06_parity_measured.jsonl against
+# r05_).  PIN is a regression pin a decade above that; the bar north_star states stays the TOL_* above.
+PIN = 1e-5
 OBJ_TXT_QUANTUM = 1.0e-5
 
 
@@ -168,6 +172,7 @@ def test_outer_solver_vs_reference_trace(golden_dir, tmp_path, name, tradeoff):
     # with the tradeoff feedback on every record's recon comes from the direct residual (it feeds gamma = recon / manifold
     # back every step); the trace then stays at the float32-state bar for all 1000 iterations, as without the feedback
     assert e_tr < TOL_OBJ and eu < TOL_FACTOR and ev < TOL_FACTOR
+    assert e_tr < PIN and eu < PIN and ev < PIN, (e_tr, eu, ev)
     with pytest.raises(ValueError):
         nmf_pathway(c["X"], _graphs(c), nodelist=c["nodelist_ids"], k_latent=6, U_init=np.ones((3, 6)))
 
@@ -224,6 +229,7 @@ def test_cli_outputs_vs_reference(golden_dir, tmp_path, variant, tag, norm):
     assert list(U.columns) == ["LV%d" % i for i in range(6)] and list(V.index) == c["nodelist_ids"]
     assert max(eo.values()) < TOL_OBJ, eo
     assert et < TOL_OBJ and eu < TOL_FACTOR and ev < TOL_FACTOR
+    assert et < PIN and eu < PIN and ev < PIN, (et, eu, ev)
     head = open(os.path.join(out, "V.csv")).readline().strip()
     assert head == '"","LV0","LV1","LV2","LV3","LV4","LV5"'       # QUOTE_NONNUMERIC contract
     if variant == 2 and norm == "nonorm":
@@ -278,6 +284,7 @@ def test_cli_more_variants_vs_reference(golden_dir, tmp_path, tag):
     assert mapping == json.loads(str(g["mapping"]))
     assert max(eo.values()) < TOL_OBJ, eo
     assert et < TOL_OBJ and eu < TOL_FACTOR and ev < TOL_FACTOR
+    assert et < PIN and eu < PIN and ev < PIN, (et, eu, ev)
     if tag == "g10_init":
         got = [os.path.basename(x) for x in open(os.path.join(out, "init_pathways.txt")).read().split("\n")]
         assert got == json.loads(str(g["init_pathways"]))
