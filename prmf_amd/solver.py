@@ -747,8 +747,6 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
     if ranks.multi:
         from .synthetic import shard_rows
         lo, hi = shard_rows(m, ranks.world, ranks.rank)
-    engine = PrmfEngine(hi - lo, n, k_latent, x_dtype=x_dtype, nranks=ranks.world, rank=ranks.rank,
-                        dist_mode=dist_mode if ranks.multi else None, device=ranks.device_index)
     # The cyclic collector is held off for the duration of the solve and put back as it was: a full collection walks every
     # container of the caller's process (the pathway library alone is thousands of arrays) and lands wherever an allocation
     # happens to trigger it -- 10-25 ms of a 150 ms solve at 50000 x 20000 (profiles/r06_outer_loop_host_time.txt).  Nothing
@@ -756,7 +754,10 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
     import gc
     gc_was_on = gc.isenabled()
     gc.disable()
+    engine = None
     try:
+        engine = PrmfEngine(hi - lo, n, k_latent, x_dtype=x_dtype, nranks=ranks.world, rank=ranks.rank,
+                            dist_mode=dist_mode if ranks.multi else None, device=ranks.device_index)
         torch = engine.torch
         dev = "cuda:%d" % engine.device
         # X goes up on a helper thread (one pass in the library: narrowing, padded copy, padded transpose, ||X||^2 -- a host
@@ -877,7 +878,8 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
         obj_data["latent_to_pathway_data"] = cands.as_dict()
         return U_out, V_out, obj_data
     finally:
-        engine.close()
+        if engine is not None:
+            engine.close()
         if gc_was_on:
             gc.enable()
 
