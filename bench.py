@@ -74,6 +74,8 @@ def sweep_roofline(workload, x_dtype, ml, n, k, ms_xv, ms_xtu, step_s, nnz_activ
     tflops_issued = issued / (avg_ms * 1e-3) / 1e12
     sc = stored_counters(workload)
     clock = sc["clock_ghz"]
+    if clock and clock > NOMINAL_CLOCK_GHZ:        # short dispatches read high (GRBM_GUI_ACTIVE over a 40 us launch): never above the spec
+        clock = NOMINAL_CLOCK_GHZ
     peak_at_clock = MFMA_BF16_PEAK_TFLOPS * (clock / NOMINAL_CLOCK_GHZ) if clock else None
     t_hbm = bytes_launch / (HBM_PEAK_GBS * 1e9)
     t_mfma = issued / ((peak_at_clock or MFMA_BF16_PEAK_TFLOPS) * 1e12)
