@@ -92,7 +92,10 @@ def _share_worker(workload, variants, steps, q):
         world, rank = (view.world, view.rank) if view is not None else (1, 0)
         lo, hi = syn.shard_rows(m, world, rank)
         Xd = syn.x_rows_torch(torch, "cuda:0", 41, n, k, lo, hi, tdt)
-        eng = PrmfEngine(hi - lo, n, k, x_dtype=x_dtype, device=0, nranks=world, rank=rank, dist_mode=view.mode if view is not None else None)
+        # the one-rank reference at k > 64 takes EVERY record's recon from the direct residual (prmf_runner.py:337 itself): what
+        # the comparison then shows is the multi-rank run's own identity error, not two identity errors of different chains
+        eng = PrmfEngine(hi - lo, n, k, x_dtype=x_dtype, device=0, nranks=world, rank=rank, dist_mode=view.mode if view is not None else None,
+                         direct_residual=(view is None and k > 64))
         local = eng.local_norm_sq(Xd)
         nsq = view.sum_float(local) if view is not None else local
         eng.set_x(Xd, norm_x_sq=nsq)
@@ -153,9 +156,9 @@ def test_step_dist_four_and_eight_ranks_at_real_share_shapes(workload, variants,
         assert r["rows"] == [syn.shard_rows(m, world, q)[1] - syn.shard_rows(m, world, q)[0] for q in range(world)]
         assert r["replicated_state_identical"]
         assert r["rel_U"] < 1e-5 and r["rel_V"] < 1e-5 and r["v_min"] >= np.finfo(np.float32).eps
-        # k > 64: the identity-based recon of both runs carries ~1e-7 ||X||^2 of float32 accumulation error (4.5e-5 on
-        # recon against float64 at this shape), independent between the decompositions: the 1e-4 bar
-        tol = 1e-5 if syn.CONFIGS[workload][2] <= 64 else 1e-4
+        # k > 64: the identity-based recon of the sharded run carries ~1e-7 ||X||^2 of float32 accumulation error over its
+        # 25000- / 50000-sample chains (1e-5 / 2e-5 on recon at this fit); the reference's records are exact
+        tol = 1e-5 if syn.CONFIGS[workload][2] <= 64 else 4e-5
         for key, v in r["rel_obj"].items():
             assert v < (tol if key in ("recon", "obj") else 1e-5), (world, mode, key, v)
 
