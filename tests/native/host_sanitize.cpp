@@ -47,11 +47,25 @@ int main(int argc, char** argv) {
     if (rc != PRMF_OK) continue;
     const int waves = out[0], tiles = out[1], panel_rows = out[2], grid = out[3], slices = out[4], slabs = out[5], panels = out[7];
     CHECK((waves == 4 || waves == 8) && (tiles == 1 || tiles == 2), "waves %d tiles %d", waves, tiles);
-    CHECK(panel_rows == waves * tiles * 32, "panel rows %d", panel_rows);
     CHECK(panels == (int)((rows + panel_rows - 1) / panel_rows), "panels %d for %lld rows of %d", panels, rows, panel_rows);
+    CHECK(slabs >= 1 && slabs <= 64, "slabs per panel %d (64-bit panel mask)", slabs);
+    const int NT = (k + 31) / 32;
+    const long long kpad = (depth + 127) / 128 * 128;
+    const bool short_reduction = kpad * NT <= 512 || (NT == 1 && kpad <= 1024 && rows <= 4096);
+    CHECK(((out[6] & 4) != 0) == short_reduction, "exact-product flag %d for depth %lld (padded %lld) x %d column tiles, %lld rows", out[6] & 4, depth, kpad, NT, rows);
+    if (out[6] & 4) {
+      // the exact short-reduction product (round 6): one wave per (32-row tile, 32-column tile, reduction slice), 256-row panels,
+      // at most 8 slices of at least two 32-element chunks, one slab per slice
+      const long long pairs = (long long)panels * 8 * NT, chunks = kpad / 32;
+      CHECK(panel_rows == 256 && waves == 4 && tiles == 1 && slices == 1, "exact plan shape %d %d %d %d", panel_rows, waves, tiles, slices);
+      CHECK(slabs <= 8 && (slabs == 1 || 2LL * slabs <= chunks), "exact plan: %d slices of %lld chunks", slabs, chunks);
+      CHECK(grid == (int)((pairs * slabs + 3) / 4), "exact plan: grid %d for %lld pairs x %d slices", grid, pairs, slabs);
+      ++checked;
+      continue;
+    }
+    CHECK(panel_rows == waves * tiles * 32, "panel rows %d", panel_rows);
     CHECK(grid >= 1 && grid <= 2 * n_cus + 8, "grid %d for %d CUs", grid, n_cus);
     CHECK(slices == 1 || slices == 2 || slices == 4 || slices == 8, "slices %d", slices);
-    CHECK(slabs >= 1 && slabs <= 64, "slabs per panel %d (64-bit panel mask)", slabs);
     ++checked;
   }
   // argument and error paths that end before any device work (or at the first HIP call when there is no GPU)
