@@ -123,7 +123,9 @@ int prmf_set_x(prmf_ctx* ctx, const void* dX, int64_t ld, double norm_x_sq, void
  *       (n_threads < 0: as many as the host has, at most 16) and a source wider than the storage type, worker threads
  *       narrow chunk i + 1 into pinned memory while chunk i crosses PCIe and the layout kernels take chunk i - 1 -- half
  *       (f32 -> bf16, f64 -> f32) or a quarter (f64 -> bf16) of the bytes on the wire; n_threads = 0: every chunk travels as
- *       it is and is narrowed on the device.  The stored bits are the same either way.  `stream` is synchronised on entry
+ *       it is and is narrowed on the device.  With workers that cannot keep the link busy (a busy host) the calling thread
+ *       sends every other chunk as it is while they narrow its neighbour (decided per chunk from the measured narrowing time;
+ *       PRMF_SETX_HYBRID=0/1 in the environment pins it -- a test hook).  The stored bits are the same either way.  `stream` is synchronised on entry
  *       (nothing of the caller's may still read the old X); the work runs on streams of the library's own.  The staging
  *       buffers (2 x 32 MB pinned, 2 x 32 MB on the device) are kept by the process for the next call;
  *       prmf_release_staging() frees them.

@@ -720,8 +720,10 @@ struct XStage {
   void* hb[2] = {nullptr, nullptr};
   void* ds[2] = {nullptr, nullptr};
   size_t hcap = 0, dcap = 0;
+  void* dd[2] = {nullptr, nullptr};   // device buffers of the DIRECT lane (chunks that travel in their source type next to the narrowed ones)
+  size_t ddcap = 0;
   hipStream_t sc = nullptr, sk = nullptr;
-  hipEvent_t evc[2] = {nullptr, nullptr}, evk[2] = {nullptr, nullptr};
+  hipEvent_t evc[2] = {nullptr, nullptr}, evk[2] = {nullptr, nullptr}, evd[2] = {nullptr, nullptr};
 };
 std::mutex g_stage_mu;
 std::vector<XStage*> g_stage_idle;
@@ -732,15 +734,17 @@ void stage_free(XStage* st) {
   for (int b = 0; b < 2; ++b) {
     if (st->hb[b]) (void)hipHostFree(st->hb[b]);
     if (st->ds[b]) (void)hipFree(st->ds[b]);
+    if (st->dd[b]) (void)hipFree(st->dd[b]);
     if (st->evc[b]) (void)hipEventDestroy(st->evc[b]);
     if (st->evk[b]) (void)hipEventDestroy(st->evk[b]);
+    if (st->evd[b]) (void)hipEventDestroy(st->evd[b]);
   }
   if (st->sc) (void)hipStreamDestroy(st->sc);
   if (st->sk) (void)hipStreamDestroy(st->sk);
   delete st;
 }
 
-XStage* stage_acquire(prmf_ctx* c, size_t hbytes, size_t dbytes) {
+XStage* stage_acquire(prmf_ctx* c, size_t hbytes, size_t dbytes, size_t ddbytes = 0) {
   XStage* st = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_stage_mu);
@@ -759,7 +763,8 @@ XStage* stage_acquire(prmf_ctx* c, size_t hbytes, size_t dbytes) {
               hipStreamCreateWithFlags(&st->sk, hipStreamNonBlocking) == hipSuccess;
     for (int b = 0; b < 2 && ok; ++b)
       ok = hipEventCreateWithFlags(&st->evc[b], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&st->evk[b], hipEventDisableTiming) == hipSuccess;
+           hipEventCreateWithFlags(&st->evk[b], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&st->evd[b], hipEventDisableTiming) == hipSuccess;
     if (!ok) { fail(c, PRMF_ERR_HIP, "staging streams / events could not be created"); stage_free(st); return nullptr; }
   }
   for (int b = 0; b < 2; ++b) {
@@ -784,8 +789,20 @@ XStage* stage_acquire(prmf_ctx* c, size_t hbytes, size_t dbytes) {
       }
     }
   }
+  for (int b = 0; b < 2; ++b)
+    if (ddbytes > st->ddcap) {
+      if (st->dd[b]) (void)hipFree(st->dd[b]);
+      st->dd[b] = nullptr;
+      if (hipMalloc(&st->dd[b], ddbytes) != hipSuccess) {
+        fail(c, PRMF_ERR_HIP, "hipMalloc(%zu bytes of staging) failed", ddbytes);
+        st->ddcap = 0;
+        stage_free(st);
+        return nullptr;
+      }
+    }
   if (hbytes > st->hcap) st->hcap = hbytes;
   if (dbytes > st->dcap) st->dcap = dbytes;
+  if (ddbytes > st->ddcap) st->ddcap = ddbytes;
   return st;
 }
 
@@ -817,12 +834,22 @@ class RowWorkers {
     for (auto& t : th_) t.join();
   }
   void run(const std::function<void(int, int)>& job) {
-    std::unique_lock<std::mutex> lock(mu_);
+    start(job);
+    wait();
+  }
+  // start: the job must stay alive until wait() has returned; wait() returns when every worker has finished it and gives the
+  // time the LAST one finished (what the narrowing of a chunk took, whatever the caller did meanwhile)
+  void start(const std::function<void(int, int)>& job) {
+    std::lock_guard<std::mutex> lock(mu_);
     job_ = &job;
     pending_ = n_;
     ++gen_;
     go_.notify_all();
+  }
+  std::chrono::steady_clock::time_point wait() {
+    std::unique_lock<std::mutex> lock(mu_);
     done_.wait(lock, [this] { return pending_ == 0; });
+    return finished_;
   }
 
  private:
@@ -840,7 +867,10 @@ class RowWorkers {
       (*job)(i, n_);
       {
         std::lock_guard<std::mutex> lock(mu_);
-        if (--pending_ == 0) done_.notify_all();
+        if (--pending_ == 0) {
+          finished_ = std::chrono::steady_clock::now();
+          done_.notify_all();
+        }
       }
     }
   }
@@ -852,6 +882,7 @@ class RowWorkers {
   unsigned gen_ = 0;
   int pending_ = 0;
   bool stop_ = false;
+  std::chrono::steady_clock::time_point finished_;
 };
 
 int setx_finish(prmf_ctx* c, double* local_out, hipStream_t s) {
@@ -929,7 +960,16 @@ int prmf_set_x_host(prmf_ctx* c, const void* hX, int src_dtype, int64_t ld, int 
   const int trav_dtype = narrow ? (c->x_dtype == PRMF_X_BF16 ? PRMF_SRC_BF16 : PRMF_SRC_F32) : src_dtype;   // type on the wire
   const int teb = src_elem_bytes(trav_dtype);
   const size_t chunk_bytes = (size_t)(rows_chunk * c->n * teb);
-  XStage* st = stage_acquire(c, narrow ? chunk_bytes : 0, chunk_bytes);
+  // The DIRECT lane of the narrowing path.  The worker threads share the host with whatever else runs there; when they cannot
+  // keep the link busy (measured per chunk: narrowing takes more than 1.25 x the chunk's own time on the wire) the calling
+  // thread, which would only wait for them, sends the NEXT chunk as it is -- a pageable copy in the source type, narrowed by the
+  // layout kernel -- while they work: a starved host then loses 10-25 % against a quiet one instead of 50-100 %
+  // (profiles/r06_outer_loop_host_time.txt).  Which lane a chunk took changes no stored bit and no bit of ||X||^2 (the tile
+  // tree is per 64 rows).  PRMF_SETX_HYBRID = 0 / 1 pins the decision (a test hook, like PRMF_SWEEP_XCD).
+  int hybrid = -1;
+  if (const char* e = getenv("PRMF_SETX_HYBRID")) hybrid = atoi(e) != 0 ? 1 : 0;
+  const size_t direct_bytes = narrow && hybrid != 0 ? (size_t)(rows_chunk * c->n * seb) : 0;
+  XStage* st = stage_acquire(c, narrow ? chunk_bytes : 0, chunk_bytes, direct_bytes);
   if (!st) return PRMF_ERR_HIP;
   auto bail = [&](int code) {
     (void)hipStreamSynchronize(st->sc);
@@ -946,30 +986,68 @@ int prmf_set_x_host(prmf_ctx* c, const void* hX, int src_dtype, int64_t ld, int 
   if (c->m > 0) {
     std::unique_ptr<RowWorkers> pool;
     if (narrow) pool.reset(new RowWorkers(workers));
-    int64_t i = 0;
-    for (int64_t r0 = 0; r0 < c->m; r0 += rows_chunk, ++i) {
+    auto copy_rows = [&](void* dst, int64_t r0, int64_t nr) -> hipError_t {          // pageable rows [r0, r0 + nr) in the source type
+      const char* srow = (const char*)hX + r0 * ld * seb;
+      if (ld == c->n) return hipMemcpy(dst, srow, (size_t)(nr * c->n * seb), hipMemcpyHostToDevice);
+      return hipMemcpy2D(dst, (size_t)(c->n * seb), srow, (size_t)(ld * seb), (size_t)(c->n * seb), (size_t)nr, hipMemcpyHostToDevice);
+    };
+    int64_t i = 0, j = 0;                      // chunks sent through the narrowing lane / the direct lane
+    bool direct_on = hybrid == 1;
+    double ema = 0.0;                          // narrowing time per byte on the wire, relative to 50 GB/s
+    for (int64_t r0 = 0; r0 < c->m; ++i) {
       const int b = (int)(i & 1);
       const int64_t nr = c->m - r0 < rows_chunk ? c->m - r0 : rows_chunk;
       if (narrow) {
         if (i >= 2) SX_TRY(hipEventSynchronize(st->evc[b]));            // the DMA of chunk i - 2 has left this pinned buffer
         void* dst = st->hb[b];
+        const int64_t ra = r0;
         const std::function<void(int, int)> job = [&](int w, int nw) {
-          const int64_t lo = r0 + nr * w / nw, hi = r0 + nr * (w + 1) / nw;
-          host_narrow_rows(src_dtype, c->x_dtype, hX, ld, lo, hi, c->n, (char*)dst + (lo - r0) * c->n * teb);
+          const int64_t lo = ra + nr * w / nw, hi = ra + nr * (w + 1) / nw;
+          host_narrow_rows(src_dtype, c->x_dtype, hX, ld, lo, hi, c->n, (char*)dst + (lo - ra) * c->n * teb);
         };
-        pool->run(job);
+        const auto t0 = std::chrono::steady_clock::now();
+        pool->start(job);
+        r0 += nr;
+        if (direct_on && r0 < c->m) {          // the direct lane: the next chunk as it is, while the workers narrow this one
+          const int bd = (int)(j & 1);
+          const int64_t nrd = c->m - r0 < rows_chunk ? c->m - r0 : rows_chunk;
+          hipError_t e = j >= 2 ? hipEventSynchronize(st->evd[bd]) : hipSuccess;
+          if (e == hipSuccess) e = copy_rows(st->dd[bd], r0, nrd);
+          if (e != hipSuccess) {
+            (void)pool->wait();
+            return bail(fail(c, PRMF_ERR_HIP, "direct lane: %s", hipGetErrorString(e)));
+          }
+          if ((rc = setx_rows(c, src_dtype, st->dd[bd], c->n, r0, nrd, st->sk))) {
+            (void)pool->wait();
+            return bail(rc);
+          }
+          e = hipEventRecord(st->evd[bd], st->sk);
+          if (e != hipSuccess) {
+            (void)pool->wait();
+            return bail(fail(c, PRMF_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(e)));
+          }
+          r0 += nrd;
+          ++j;
+        }
+        const double t_narrow = std::chrono::duration<double>(pool->wait() - t0).count();
+        if (hybrid < 0) {
+          const double rel = t_narrow / ((double)nr * (double)c->n * (double)teb / 50e9);
+          ema = i == 0 ? rel : 0.5 * ema + 0.5 * rel;
+          direct_on = ema > 1.25;
+        }
         if (i >= 2) SX_TRY(hipStreamWaitEvent(st->sc, st->evk[b], 0));  // the kernels of chunk i - 2 have read this device buffer
         SX_TRY(hipMemcpyAsync(st->ds[b], dst, (size_t)(nr * c->n * teb), hipMemcpyHostToDevice, st->sc));
         SX_TRY(hipEventRecord(st->evc[b], st->sc));
         SX_TRY(hipStreamWaitEvent(st->sk, st->evc[b], 0));
+        if ((rc = setx_rows(c, trav_dtype, st->ds[b], c->n, ra, nr, st->sk))) return bail(rc);
+        SX_TRY(hipEventRecord(st->evk[b], st->sk));
       } else {
         if (i >= 2) SX_TRY(hipEventSynchronize(st->evk[b]));
-        const char* srow = (const char*)hX + r0 * ld * seb;
-        if (ld == c->n) SX_TRY(hipMemcpy(st->ds[b], srow, (size_t)(nr * c->n * seb), hipMemcpyHostToDevice));
-        else SX_TRY(hipMemcpy2D(st->ds[b], (size_t)(c->n * seb), srow, (size_t)(ld * seb), (size_t)(c->n * seb), (size_t)nr, hipMemcpyHostToDevice));
+        SX_TRY(copy_rows(st->ds[b], r0, nr));
+        if ((rc = setx_rows(c, trav_dtype, st->ds[b], c->n, r0, nr, st->sk))) return bail(rc);
+        SX_TRY(hipEventRecord(st->evk[b], st->sk));
+        r0 += nr;
       }
-      if ((rc = setx_rows(c, trav_dtype, st->ds[b], c->n, r0, nr, st->sk))) return bail(rc);
-      SX_TRY(hipEventRecord(st->evk[b], st->sk));
     }
   }
 #undef SX_TRY

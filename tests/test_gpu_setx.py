@@ -58,8 +58,19 @@ def test_every_upload_path_stores_the_same_bits(x_dtype, src):
     want_bits = want_np.view(np.uint16 if x_dtype == "bf16" else np.uint32)
     stored = {}
     norms = {}
+    def hybrid(e):
+        # PRMF_SETX_HYBRID=1: every other chunk takes the direct lane (source type over the wire, narrowed by the layout kernel)
+        # while the workers narrow its neighbour -- what the library does by itself when the host threads are starved
+        import os
+        os.environ["PRMF_SETX_HYBRID"] = "1"
+        try:
+            e.set_x(X, host_threads=3)
+        finally:
+            del os.environ["PRMF_SETX_HYBRID"]
+
     paths = {
         "legacy prmf_set_x (device, storage type)": lambda e: e._legacy_set_x(want),
+        "host, both lanes (narrowed chunks next to direct ones)": hybrid,
         "device, source type": lambda e: e.set_x(torch.from_numpy(X).cuda()),
         "host, narrowed by 5 threads": lambda e: e.set_x(X, host_threads=5),
         "host, narrowed on the device": lambda e: e.set_x(X, host_threads=0),
@@ -95,8 +106,16 @@ def test_norm_is_chunking_invariant_and_exact(x_dtype, m, n):
     Xd = torch.from_numpy(X).cuda().to(tdt)
     ref = float((Xd.double() ** 2).sum().item())
     got = []
+    def both_lanes(e):
+        import os
+        os.environ["PRMF_SETX_HYBRID"] = "1"
+        try:
+            e.set_x(X, host_threads=4)
+        finally:
+            del os.environ["PRMF_SETX_HYBRID"]
+
     for feed in (lambda e: e.set_x(X, host_threads=4), lambda e: e.set_x(X, host_threads=0), lambda e: e.set_x(Xd),
-                 lambda e: e.set_x(torch.from_numpy(X).cuda())):
+                 lambda e: e.set_x(torch.from_numpy(X).cuda()), both_lanes):
         eng = PrmfEngine(m, n, 4, x_dtype=x_dtype)
         try:
             feed(eng)

@@ -95,12 +95,16 @@ for nm, o in origs.items():
     setattr(solver.PrmfEngine, nm, o)
 # the upload alone: host threads narrowing vs the chunk narrowed on the device
 eng = solver.PrmfEngine(m, n, k, x_dtype=xd)
-for label, th in (("narrowed by 16 host threads", -1), ("8 threads", 8), ("4 threads", 4), ("narrowed on the device (pageable copies)", 0)):
+for label, th, hy in (("narrowed by 16 host threads, direct lane as needed", -1, None), ("the same, direct lane off", -1, "0"), ("the same, direct lane always", -1, "1"),
+                      ("8 threads", 8, None), ("4 threads", 4, None), ("4 threads, direct lane off", 4, "0"), ("narrowed on the device (pageable copies)", 0, None)):
     ts = []
     for _ in range(3):
+        if hy is not None:
+            os.environ["PRMF_SETX_HYBRID"] = hy
         t0 = time.perf_counter()
         eng.set_x(X, host_threads=th)
         ts.append(time.perf_counter() - t0)
+        os.environ.pop("PRMF_SETX_HYBRID", None)
     print("set_x(host float32 %d x %d -> %s), %s: %s ms  (%.1f GB/s of source)" % (
         m, n, xd, label, " ".join("%.1f" % (1e3 * t) for t in ts), X.nbytes / min(ts) / 1e9), flush=True)
 eng.close()
