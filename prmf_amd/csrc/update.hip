@@ -1149,7 +1149,7 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
 
 // Multi-rank phase_post in one pass: the gathered per-rank column blocks -> row-major V (caller's buffer),
 // packed fragments for the next sweep, V^T V partials (GRAM).  Same tile machinery as the epilogues.
-// STAGED (kc % 4 == 0): a tile's share of every rank block is one contiguous run of 32 kc floats; the wave copies the
+// STAGED (kc % 4 == 0 and the rank blocks together no wider than the tile): a tile's share of every rank block is one contiguous run of 32 kc floats; the wave copies the
 // runs with 16-B loads into a private LDS tile and reads its C/D-layout values from there.  Read straight from the
 // blocks in the C/D layout, one load instruction touched 2 rows x 32 / kc blocks with kc * 4 bytes each (32 B at eight
 // ranks of k = 64): 25.5 us per iteration at 20000 genes against 18 us for the whole fused V epilogue.
@@ -1182,7 +1182,7 @@ v_post_kernel(float* __restrict__ V, int64_t n, int k, const float* __restrict__
       float* T = stage[wave];
       const int rows_here = row0 < n ? (int)(n - row0 < 32 ? n - row0 : 32) : 0;
       const int run4 = rows_here * kc / 4;                  // float4 per rank block
-      const int total4 = nblocks_src * run4;                // <= 8 KP = 64 lanes x 4 NT
+      const int total4 = nblocks_src * run4;                // <= 8 KP = 64 lanes x 4 NT (launch_v_post: nblocks_src kc <= KP)
       float4 x[4 * NT];
       int dst[4 * NT];
 #pragma unroll
@@ -1255,7 +1255,11 @@ hipError_t launch_v_post(float* V, int64_t n, int k, const float* v_recv, int64_
   const int64_t ntiles = Kpad / 32;
   const int grid = epilogue_blocks(Kpad);
   *gram_done = NT <= 2;
-  const bool staged = (kc & 3) == 0 && (blk_stride & 3) == 0;
+  // the staged copy places rank block b at columns [b kc, (b + 1) kc) of a KP-wide tile: when the blocks together are wider
+  // than the tile (k = 96 on five ranks: 5 x 20 = 100 > 96) the copy neither fits the tile nor its 4 NT load slots per lane
+  // -- those shapes read the blocks directly
+  const int nblocks_src = kc > 0 ? (k + kc - 1) / kc : 0;
+  const bool staged = (kc & 3) == 0 && (blk_stride & 3) == 0 && nblocks_src * kc <= KP;
 #define PRMF_VPOST(NTV, GR)                                                                                      \
   do {                                                                                                           \
     if (staged) v_post_kernel<NTV, GR, true, false><<<grid, 256, 0, s>>>(V, n, k, v_recv, blk_stride, kc, packed, ntiles, gram_partial, pos_all, vsup, max_support); \

@@ -190,11 +190,14 @@ def _small_worker(world, k, x_dtype, mode, m, q, tradeoff=None, steps=6):
 
 
 @pytest.mark.parametrize("world,k,x_dtype,mode,m", [(8, 13, "bf16", "colshard", 700), (8, 13, "bf16", "replicated", 700), (8, 100, "f32", "colshard", 700),
-                                                    (8, 6, "f32", "colshard", 5), (6, 64, "bf16", "colshard", 333), (8, 128, "bf16", "replicated", 700)])
+                                                    (8, 6, "f32", "colshard", 5), (6, 64, "bf16", "colshard", 333), (8, 128, "bf16", "replicated", 700),
+                                                    (5, 96, "f32", "colshard", 333), (5, 96, "bf16", "colshard", 4)])
 def test_step_dist_eight_ranks_small_shapes_vs_oracle(mock, world, k, x_dtype, mode, m):
     """Ragged everything on 8 (and 6) ranks through the in-library step: k = 13 (kc = 2: one rank with one column, one with
     none), k = 100 and 128 (the column-split epilogues, kc = 13 / 16), 5 samples on 8 ranks (three ranks without rows),
-    87- and 88-row shards -- against the oracle, and run twice: bit-identical."""
+    87- and 88-row shards; k = 96 on FIVE ranks (kc = 20: the five blocks together are 100 columns, wider than the 96-column
+    tile -- the assembling kernel's staged copy did not fit and the ranks disagreed until round 6's fuzzer found it; once with a
+    rank that holds no sample) -- against the oracle, and run twice: bit-identical."""
     from oracle import prmf_oracle as orc
     runs = _in_worker(_small_worker, (world, k, x_dtype, mode, m), {"PRMF_RCCL_LIB": mock, "MOCK_RCCL_TIMEOUT_S": "60"}, deadline_s=600)
     for a, b in zip(runs[0], runs[1]):

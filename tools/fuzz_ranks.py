@@ -3,7 +3,7 @@
 collectives through the RCCL test double tests/native/mock_rccl.cpp), both V-update modes, with and without the tradeoff
 feedback -- sample counts below the rank count (ranks without rows), k below it (ranks without a latent column), ragged
 everything -- against the single-rank prmf_step on the whole matrix: U, V, every objective component within 1e-5 (the same
-arithmetic, another summation order), V / records / flags bit-identical across the ranks, a second run bit-identical.
+arithmetic, another summation order; recon at k > 64: 4e-5), V / records / flags bit-identical across the ranks, a second run bit-identical.
 Not part of the test suite; a failure prints the case and exits non-zero.
     SEED=1 CASES=40 python tools/fuzz_ranks.py"""
 import math
@@ -112,7 +112,10 @@ for ci in range(ncases):
     for key in KEYS:
         errs[key] = max([abs(a[key] - b[key]) / max(abs(b[key]), 1e-12) for a, b, f in zip(res[0][0][2], objs1, flags1)
                          if not ((f & 2) and key in ("recon", "obj"))] or [0.0])
-    bad += [key for key, e in errs.items() if not (e < 1e-5)]
+    # k > 64: the Gram-identity recon carries ~1e-7 ||X||^2 of float32 accumulation error that depends on how the product was
+    # summed (a rank's short shard takes the exact product where the whole matrix streams): the bar tests/test_gpu_eightway.py holds
+    tol = {key: (4e-5 if k > 64 and key in ("recon", "obj") else 1e-5) for key in errs}
+    bad += [key for key, e in errs.items() if not (e < tol[key])]
     if not all(np.array_equal(r[0][1], res[0][0][1]) and r[0][2] == res[0][0][2] and r[0][3] == res[0][0][3] for r in res[1:]):
         bad.append("replicated state differs between ranks")
     if not all(np.array_equal(r[0][0], r[1][0]) and np.array_equal(r[0][1], r[1][1]) and r[0][2] == r[1][2] for r in res):
