@@ -54,6 +54,8 @@ def draw():
     else:
         m, n = rs.randint(20, 2500), rs.randint(20, 3000)
     k = int(rs.choice([1, 2, 3, 5, 6, 7, 8, 13, 16, 31, 32, 33, 48, 64, 65, 96, 100, 128]))
+    if os.environ.get("ANY_K", "0") == "1" and rs.rand() < 0.6:      # every k x rank-count combination, not the usual suspects only
+        k = int(rs.randint(1, 129))
     return dict(m=int(m), n=int(n), k=k, P=int(rs.randint(1, 7)), order=int(min(max(2, n // 2), rs.randint(2, 150))),
                 x_dtype=str(rs.choice(["f32", "bf16"])), steps=int(rs.randint(2, 5)), seed=int(rs.randint(1 << 30)),
                 world=int(rs.randint(2, 9)), mode=str(rs.choice(["colshard", "replicated"])),
