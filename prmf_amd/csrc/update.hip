@@ -281,10 +281,10 @@ __device__ __forceinline__ void tile_times_gram(const float (&ua)[16 * NT], int 
 // per thread BEFORE the LDS stores of the batch: written as `Gs[i] = (float)G[...]` in one loop the compiler kept every
 // load behind the previous store, and the staging was a chain of KP*KP/256 dependent L2 round trips -- 24 us of a
 // 53 us epilogue workgroup at k = 128 (tools/epi_phases.py), ~5 us at k = 64.
-template <int NT>
+template <int NT, int BMAX = 16>
 __device__ __forceinline__ void stage_gram(const double* __restrict__ G, int k, int col0, int ncols, float* Gs) {
   constexpr int KP = 32 * NT, PER = KP * KP / 256;           // 4, 16, 36, 64 values per thread
-  constexpr int B = PER % 16 == 0 ? 16 : (PER % 12 == 0 ? 12 : PER);
+  constexpr int B = BMAX < 16 ? (PER < BMAX ? PER : BMAX) : (PER % 16 == 0 ? 16 : (PER % 12 == 0 ? 12 : PER));
   static_assert(PER % B == 0 && B <= 16, "whole batches");
 #pragma unroll 1
   for (int b0 = 0; b0 < PER; b0 += B) {
@@ -345,6 +345,50 @@ __device__ __forceinline__ void load_slab_tile(const float* __restrict__ slabs, 
           p[t][4 * q4 + 3] += on[j] * v[j][t][q4].w;
         }
   }
+}
+
+// The same sum in two halves, for callers that put other work between the issue of a batch's loads and their use (the fused
+// epilogues: the MFMA chain of the tile runs under the first batch's memory round trip).  issue: the loads of the next NB
+// segments of `mask` (which it consumes); add: their sum into p, in the order load_slab_tile adds them -- bit-identical.
+template <int NT, int NB>
+struct SlabBatch {
+  float4 v[NB][NT][4];
+  float on[NB];
+};
+template <int NT, int NB>
+__device__ __forceinline__ void slab_batch_issue(const float* __restrict__ slabs, int64_t slab_stride, segmask_t& mask, int64_t tile, int lane,
+                                                 SlabBatch<NT, NB>& b) {
+  const int64_t base = tile * NT * 256 + lane;
+  int sg[NB];
+  const int first = __ffsll((long long)mask) - 1;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    sg[j] = mask ? __ffsll((long long)mask) - 1 : first;
+    b.on[j] = mask ? 1.f : 0.f;
+    mask &= mask - 1;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const float4* sl = reinterpret_cast<const float4*>(slabs + (int64_t)sg[j] * slab_stride) + base;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) b.v[j][t][q4] = sl[(t * 4 + q4) * 64];
+  }
+}
+template <int NT, int NB>
+__device__ __forceinline__ void slab_batch_add(const SlabBatch<NT, NB>& b, float (&p)[NT][16]) {
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        p[t][4 * q4] += b.on[j] * b.v[j][t][q4].x;
+        p[t][4 * q4 + 1] += b.on[j] * b.v[j][t][q4].y;
+        p[t][4 * q4 + 2] += b.on[j] * b.v[j][t][q4].z;
+        p[t][4 * q4 + 3] += b.on[j] * b.v[j][t][q4].w;
+      }
 }
 
 // Cooperative slab sum.  With few tiles and many segments per tile (small matrices: a 5000-row X V has 157 tiles of
@@ -491,56 +535,87 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
     return;
   }
   EPI_STAMP(0);
-  stage_gram<NT>(Gv, k, 0, k, Gs);
-  __syncthreads();
-  EPI_STAMP(1);
   // the wave index is made provably uniform: tile bases then live in scalar registers
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int c = lane & 31, h = lane >> 5;
   const int tpw = 4 / wpt, sub = wave % wpt, tslot = wave / wpt;
+  constexpr int NB = NT == 1 ? 4 : PRMF_EPI_NB2;
   float gtot[GRAM ? NP : 1][4];
 #pragma unroll
   for (int p = 0; p < (GRAM ? NP : 1); ++p)
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) gtot[p][ii] = 0.f;
+  // A round is ONE memory round trip deep where it was four (G staged | the panel's segment mask | the slab batches | the tile
+  // of U: 8 of the 15 us of a workgroup at 6250 x 20000, 5.5 of 9 at 5000 x 10000, tools/epi_phases.py): everything that
+  // depends on nothing -- the mask, the tile of U in both layouts -- is requested first (in the first round: before G is
+  // staged), the slab loads follow as soon as the mask is there, and the MFMA chain U G runs under their round trip.
   // uniform trip count over the workgroup (the cooperative sum and the Gram round have barriers)
-  for (int64_t base = (int64_t)blockIdx.x * tpw; base < ntiles_pack; base += (int64_t)nblocks_main * tpw) {
+  const int64_t base0 = (int64_t)blockIdx.x * tpw;
+  for (int64_t base = base0; base < ntiles_pack; base += (int64_t)nblocks_main * tpw) {
     const int64_t tile = base + tslot;
     const int64_t row0 = tile * 32;
     const bool live = tile < ntiles_pack && row0 < m;
     const bool lead = tile < ntiles_pack && sub == 0;            // this wave finishes the tile
-    float p[NT][16];
-    if constexpr (NT <= 2) {
-      if (wpt > 1) {
-        if (live) load_slab_tile<NT, NT == 1 ? 4 : PRMF_EPI_NB2>(slabs, slab_stride, my_segments(segmask[row0 / panel_rows], wpt, sub), tile, lane, p);
-        else load_slab_tile<NT>(slabs, slab_stride, segmask_t(0), tile, lane, p);
-        combine_tile_sums<NT>(p, wpt, sub, wave, lane, red_store);
+    const bool mine = lead && live;
+    segmask_t mask = 0;
+    if (live && (wpt > 1 || lead)) mask = segmask[row0 / panel_rows];
+    float ua[16 * NT], uu[NT][16];
+    float* const Ut = U + row0 * k;
+    const int last = (int)((m - row0 < 32 ? m - row0 : 32) - 1);
+    auto cd_off = [&](int t, int i) -> unsigned {
+      const int rr = (i & 3) + 8 * (i >> 2) + 4 * h, col = 32 * t + c;
+      return (unsigned)((rr < last ? rr : last) * k + (col < k ? col : k - 1));
+    };
+    if (mine) {
+      load_tile_a_layout<NT, VEC4>(U, m, k, row0, lane, ua);
+      if constexpr (NT == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) uu[0][i] = Ut[cd_off(0, i)];
       }
     }
+    if (base == base0) {
+      stage_gram<NT, 8>(Gv, k, 0, k, Gs);        // (two batches at k > 32: with 16 doubles next to the tile of U the kernel spills)
+      __syncthreads();
+      EPI_STAMP(1);
+    }
+    float p[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) p[t][i] = 0.f;
+    mask = my_segments(mask, wpt, sub);
+    SlabBatch<NT, NB> sb;
+    const bool any = mask != 0;
+    f32x16 den[NT];
+    // (k > 32: the chain first -- with the batch's 64 registers live under it the kernel spills)
+    if constexpr (NT > 1) {
+      if (mine) {
+        tile_times_gram<NT>(ua, lane, Gs, den);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) uu[t][i] = Ut[cd_off(t, i)];      // C/D layout: travels with the slab batch
+      }
+    }
+    if (any) slab_batch_issue<NT, NB>(slabs, slab_stride, mask, tile, lane, sb);
+    if constexpr (NT == 1) {
+      if (mine) tile_times_gram<NT>(ua, lane, Gs, den);
+    }
+    if (any) slab_batch_add<NT, NB>(sb, p);
+    while (mask) {
+      slab_batch_issue<NT, NB>(slabs, slab_stride, mask, tile, lane, sb);
+      slab_batch_add<NT, NB>(sb, p);
+    }
+    if constexpr (NT <= 2) combine_tile_sums<NT>(p, wpt, sub, wave, lane, red_store);
     float un[NT][16];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) un[t][i] = 0.f;
-    if (lead && live) {
-      // issue every load of the tile first (slabs, A layout, C/D layout), then the MFMA chain
-      float ua[16 * NT], uu[NT][16];
-      if (wpt == 1) load_slab_tile<NT, NT == 1 ? 4 : PRMF_EPI_NB2>(slabs, slab_stride, segmask[row0 / panel_rows], tile, lane, p);
-      load_tile_a_layout<NT, VEC4>(U, m, k, row0, lane, ua);
-      float* const Ut = U + row0 * k;
-      const int last = (int)((m - row0 < 32 ? m - row0 : 32) - 1);
-      auto cd_off = [&](int t, int i) -> unsigned {
-        const int rr = (i & 3) + 8 * (i >> 2) + 4 * h, col = 32 * t + c;
-        return (unsigned)((rr < last ? rr : last) * k + (col < k ? col : k - 1));
-      };
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) uu[t][i] = Ut[cd_off(t, i)];
+    if (mine) {
       EPI_DEP(p);
       EPI_STAMP(2);
-      f32x16 den[NT];
-      tile_times_gram<NT>(ua, lane, Gs, den);
       EPI_DEP(den);
       EPI_STAMP(3);
 #pragma unroll
@@ -568,7 +643,7 @@ u_epilogue_kernel(float* __restrict__ U, int64_t m, int k, const float* __restri
       for (int q = 0; q < NP; ++q)
 #pragma unroll
         for (int i = 0; i < 16; ++i) gt[q][i] = 0.f;
-      if (lead && live) gram_accumulate<NT>(un, gt);
+      if (mine) gram_accumulate<NT>(un, gt);
       gram_round<NT>(gt, gtot, red, wave, lane);
     }
     EPI_STAMP(6);
@@ -969,14 +1044,30 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
                   const float* __restrict__ gnum, const float* __restrict__ gden, int max_support,
                   void* __restrict__ packed, int64_t ntiles_pack, double* __restrict__ partial /*[waves][k+1]*/,
                   float* __restrict__ gram_partial, float* __restrict__ vsup /* null or [k][max_support]: V_new on the supports */,
-                  int wpt /* waves per tile (cooperative slab sum, see my_segments): 1, 2 or 4; 1 with DENSE */) {
+                  int wpt /* waves per tile (cooperative slab sum, see my_segments): 1, 2 or 4; 1 with DENSE */,
+                  unsigned long long* __restrict__ stamps /* debug (tools/epi_phases.py), may be null */) {
   constexpr int KP = 32 * NT, NP = NT * (NT + 1) / 2;
   constexpr int COMB = (NT <= 2 && !DENSE) ? 4 * NT * 16 * 64 : 1;
+  // phase stamps as in u_epilogue_kernel, but compiled in only with -DPRMF_EPI_V_STAMPS (a variant build for tools/epi_phases.py):
+  // the k = 33..64 forms have no register to spare for them
+#ifdef PRMF_EPI_V_STAMPS
+  bool first_round = true;
+#define EPI_STAMP(j) do { if (stamps && threadIdx.x == 0 && first_round) stamps[8 * blockIdx.x + (j)] = wall_clock64(); } while (0)
+#define EPI_DEP(arr) do { if (stamps) { float t_ = 0.f; for (int t2_ = 0; t2_ < NT; ++t2_) for (int i_ = 0; i_ < 16; ++i_) t_ += arr[t2_][i_]; if (t_ == 1.2345e-33f) vn[0][0] = t_; } } while (0)
+#define EPI_ROUND_DONE() first_round = false
+#else
+  (void)stamps;
+#define EPI_STAMP(j) do { } while (0)
+#define EPI_DEP(arr) do { } while (0)
+#define EPI_ROUND_DONE() do { } while (0)
+#endif
   __shared__ float Gs[KP * KP];
   __shared__ float red_store[(GRAM ? NP * 4 * 16 * 64 : 1) > COMB ? (GRAM ? NP * 4 * 16 * 64 : 1) : COMB];   // Gram exchange (all NP blocks of a tile at once) | slab-sum exchange
   float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(red_store);
+  EPI_STAMP(0);
   stage_gram<NT>(Gu, k, 0, k, Gs);
   __syncthreads();
+  EPI_STAMP(1);
   // the wave index is made provably uniform: tile bases then live in scalar registers and every per-lane
   // address is one 32-bit offset (the kernel is register-bound: 2 workgroups per CU need <= 256 VGPRs)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1009,6 +1100,10 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) vn[t][i] = 0.f;
+    if constexpr (NT <= 2 && !DENSE) {
+      if (wpt > 1) { EPI_DEP(q); }
+    }
+    EPI_STAMP(2);
     if (lead && live) {
       // C/D-layout accesses of this tile: uniform tile base + 32-bit element offset (rows past n re-read the last row)
       float* const Vt = V + row0 * k;
@@ -1032,6 +1127,8 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
       load_tile_a_layout<NT, VEC4>(V, n, k, row0, lane, ua);
       f32x16 den[NT];
       tile_times_gram<NT>(ua, lane, Gs, den);
+      EPI_DEP(den);
+      EPI_STAMP(3);
       // The element-wise update, one 32-column half at a time (register budget: q, den and the new tile stay live;
       // V in C/D layout, the position map and the gathered pathway terms are per half).
       // The pathway terms are gathered BRANCH-FREE: entries off the support (98% of them) read element 0 and are
@@ -1074,7 +1171,10 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
         }
       }
     }
+    EPI_DEP(vn);
+    EPI_STAMP(4);
     if (lead) pack_tile<NT, W16>(vn, row0, lane, packed);   // tiles past n are packed as zeros
+    EPI_STAMP(5);
     if constexpr (GRAM) {
       f32x16 gt[NP];
 #pragma unroll
@@ -1084,7 +1184,13 @@ v_epilogue_kernel(float* __restrict__ V, int64_t n, int k, const float* __restri
       if (lead && live) gram_accumulate<NT>(vn, gt);
       gram_round<NT>(gt, gtot, red, wave, lane);
     }
+    EPI_STAMP(6);
+    EPI_STAMP(7);
+    EPI_ROUND_DONE();
   }
+#undef EPI_STAMP
+#undef EPI_DEP
+#undef EPI_ROUND_DONE
   // per-wave partials: column sums from the two half-waves, cross over all lanes (fixed order)
   double* out = partial + ((int64_t)blockIdx.x * 4 + wave) * (k + 1);
 #pragma unroll
@@ -1126,7 +1232,7 @@ hipError_t launch_v_epilogue(float* V, int64_t n, int k, const float* slabs, con
   *gram_done = NT <= 2;
   const float* qsrc = qdense ? qdense : slabs;
 #define PRMF_VEP3(NTV, GR, V4, DN, WV)                                                                              \
-  v_epilogue_kernel<NTV, V4, GR, DN, WV><<<grid, 256, 0, s>>>(V, n, k, qsrc, segmask, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial, vsup, kwpt)
+  v_epilogue_kernel<NTV, V4, GR, DN, WV><<<grid, 256, 0, s>>>(V, n, k, qsrc, segmask, panel_rows, slab_stride, Gu, pos, gnum, gden, max_support, packed, ntiles, partial, gram_partial, vsup, kwpt, g_epi_stamps)
 #define PRMF_VEP2(NTV, GR, V4, DN)                                                                                  \
   do { if (NTV == 2 && w16) { PRMF_VEP3(2, GR, V4, DN, true); } else { PRMF_VEP3(NTV, GR, V4, DN, false); } } while (0)
 #define PRMF_VEP(NTV, GR)                                                                                           \

@@ -21,8 +21,14 @@ st = torch.zeros(8 * 2048, dtype=torch.int64, device=dev)
 cs = k > 64
 names = (["G staged", "slab sum", "MFMA chain", "barrier", "update+stores", "pack+exchange", "Gram"] if cs else
          ["G staged", "slab + U loads", "MFMA chain", "update+stores", "pack", "Gram round", "-"])
-sides = (("U", None, eng.phase_u), ("V", eng.phase_q, eng.phase_v)) if cs else (("U", None, eng.phase_u),)   # k <= 64: U kernel only
+# k <= 64: the V kernel carries stamps only in a variant build (-DPRMF_EPI_V_STAMPS: python -c "from prmf_amd import _build;
+# _build.build_variant('vstamps', ['PRMF_EPI_V_STAMPS'])", then PRMF_HIP_LIB=prmf_amd/lib/variants/libprmf_hip_vstamps.so VSTAMPS=1)
+vst = os.environ.get("VSTAMPS", "0") == "1"
+names_v = names if cs else ["G staged", "slab sum (+ exchange)", "tile load + MFMA chain", "V, positions | pathway terms | update", "pack", "Gram round", "-"]
+sides = (("U", None, eng.phase_u), ("V", eng.phase_q, eng.phase_v)) if (cs or vst) else (("U", None, eng.phase_u),)
 for side, pre, ph in sides:
+    if side == "V":
+        names = names_v
     if pre:
         pre()
     torch.cuda.synchronize()
