@@ -52,6 +52,8 @@ def test_bench_line_contract():
     assert d["update_only"]["value"] > 0 and d["outer_loop"]["iterations"] == 100
     ol = d["outer_loop"]
     assert abs(ol["it_per_s_warm"] * ol["seconds_warm_call"] - 100) < 1e-6 and abs(ol["it_per_s_device_resident"] * ol["seconds_device_resident"] - 100) < 1e-6
+    # the reported warm / device-resident call is the median of the three that ran, all of them listed
+    assert sorted(ol["seconds_warm_calls"])[1] == ol["seconds_warm_call"] and sorted(ol["seconds_device_resident_calls"])[1] == ol["seconds_device_resident"]
     # the other workloads of the same run: the same arithmetic
     sec = d["secondary"]
     assert sorted(sec) == ["c2", "c4_share_of_8"]

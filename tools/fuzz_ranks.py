@@ -5,7 +5,7 @@ feedback -- sample counts below the rank count (ranks without rows), k below it 
 everything -- against the single-rank prmf_step on the whole matrix: U, V, every objective component within 1e-5 (the same
 arithmetic, another summation order; recon at k > 64: 4e-5), V / records / flags bit-identical across the ranks, a second run bit-identical.
 Not part of the test suite; a failure prints the case and exits non-zero.
-    SEED=1 CASES=40 python tools/fuzz_ranks.py"""
+    SEED=1 CASES=40 [ANY_K=1] [NATIVE=0] python tools/fuzz_ranks.py"""
 import math
 import os
 import subprocess
@@ -38,6 +38,7 @@ from prmf_amd.synthetic import shard_rows  # noqa: E402
 rs = np.random.RandomState(int(os.environ.get("SEED", 1)))
 ncases = int(os.environ.get("CASES", 40))
 KEYS = ("recon", "manifold", "ignore", "fro", "obj")
+NATIVE = os.environ.get("NATIVE", "1") == "1"      # NATIVE=0: the four phase calls with the rank group's own exchanges in between
 
 
 def rel(a, b):
@@ -66,6 +67,8 @@ t_start = time.time()
 worst = 0.0
 for ci in range(ncases):
     c = draw()
+    if not NATIVE:
+        c["tradeoff"] = None      # (host-driven exchanges keep the Gram-identity recon under the tradeoff: another quantity)
     case = synth.small_case(seed=c["seed"], m=c["m"], n=c["n"], k=c["k"], P=c["P"], order=c["order"], zero_genes=min(3, c["n"] // 4),
                             isolated=min(2, max(0, c["order"] - 2)), bf16_x=(c["x_dtype"] == "bf16"))
     m, n, k = c["m"], c["n"], c["k"]
@@ -84,7 +87,7 @@ for ci in range(ncases):
             eng.set_library(lib)
             eng.set_active(active)
             outs = []
-            stepper = DistributedPrmf(eng, group=view, native=True).step if view is not None else eng.step
+            stepper = DistributedPrmf(eng, group=view, native=NATIVE).step if view is not None else eng.step
             for _rep in range(2):
                 U = eng.device_tensor(case["U0"][lo:hi], torch.float32)
                 V = eng.device_tensor(case["V0"], torch.float32)
