@@ -284,8 +284,8 @@ __device__ __forceinline__ void tile_times_gram(const float (&ua)[16 * NT], int 
 template <int NT, int BMAX = 16>
 __device__ __forceinline__ void stage_gram(const double* __restrict__ G, int k, int col0, int ncols, float* Gs) {
   constexpr int KP = 32 * NT, PER = KP * KP / 256;           // 4, 16, 36, 64 values per thread
-  constexpr int B = BMAX < 16 ? (PER < BMAX ? PER : BMAX) : (PER % 16 == 0 ? 16 : (PER % 12 == 0 ? 12 : PER));
-  static_assert(PER % B == 0 && B <= 16, "whole batches");
+  constexpr int B = BMAX < 16 ? (PER < BMAX ? PER : BMAX) : (BMAX >= 32 && PER % 32 == 0 ? 32 : (PER % 16 == 0 ? 16 : (PER % 12 == 0 ? 12 : PER)));
+  static_assert(PER % B == 0 && B <= 32, "whole batches");
 #pragma unroll 1
   for (int b0 = 0; b0 < PER; b0 += B) {
     double v[B];
@@ -734,7 +734,9 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
     return;
   }
   EPI_STAMP(0);
-  stage_gram<NT>(a.G, k, 0, k, Gs);
+  // (k = 128: 64 values per thread in two batches of 32 -- at the top of the kernel the registers are free; four batches of 16
+  //  were four dependent L2 round trips, 5 us of a 24 us round)
+  stage_gram<NT, 32>(a.G, k, 0, k, Gs);
   __syncthreads();
   EPI_STAMP(1);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -748,7 +750,11 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) gacc[p][i] = 0.f;
   double colsq = 0.0, cross = 0.0;
-  for (int64_t base = (int64_t)blockIdx.x * TPW; base < a.ntiles_pack; base += (int64_t)a.nblocks_main * TPW) {
+  // A round's loads in dependence order (round 6; it was: G | mask | slab batches | tile | chain | pathway gathers, six
+  // dependent round trips, tools/epi_phases.py): the panel's segment mask, the tile in both layouts and (V) the positions
+  // are requested first, the chain F G follows, the pathway gathers travel under the slab batches.
+  const int64_t base0 = (int64_t)blockIdx.x * TPW;
+  for (int64_t base = base0; base < a.ntiles_pack; base += (int64_t)a.nblocks_main * TPW) {
     const int64_t tile = base + tslot;
     const int64_t row0 = tile * 32;
     const bool in_range = wave_on && tile < a.ntiles_pack;
@@ -768,47 +774,13 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
       q[i] = 0.f;
       den[i] = 0.f;
     }
-    if (live) {
-      // (1) this wave's column tile of the slab segments, in slab-index order, 4 segments per round trip
-      if constexpr (DENSE) {
-        const float* const Qt = a.slabs + row0 * k;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) q[i] = Qt[cd_off(i)];
-      } else {
-        const int64_t fbase = (tile * NT + t) * 256 + lane;         // float4 index of (tile, t, q4 = 0, lane)
-        segmask_t mask = a.segmask[row0 / a.panel_rows];
-        while (mask) {
-          int sg[4];
-          float on[4];
-          const int first = __ffsll((long long)mask) - 1;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            sg[j] = mask ? __ffsll((long long)mask) - 1 : first;
-            on[j] = mask ? 1.f : 0.f;
-            mask &= mask - 1;
-          }
-          float4 v[4][4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float4* sl = reinterpret_cast<const float4*>(a.slabs + (int64_t)sg[j] * a.slab_stride) + fbase;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) v[j][q4] = sl[q4 * 64];
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-              q[4 * q4] += on[j] * v[j][q4].x;
-              q[4 * q4 + 1] += on[j] * v[j][q4].y;
-              q[4 * q4 + 2] += on[j] * v[j][q4].z;
-              q[4 * q4 + 3] += on[j] * v[j][q4].w;
-            }
-        }
-      }
-      if (a.stamps) { float t_ = 0.f; for (int i = 0; i < 16; ++i) t_ += q[i]; if (t_ == 1.2345e-33f) vn[0] = t_; EPI_STAMP(2); }
-      // (2) den = F_tile (all k columns, A layout) x G[:, this column tile] on the f32 MFMA; the old values of this
-      //     column tile (C/D layout) and, V side, the position map and the gathered pathway terms
-      float ua[HALF];
+    // (k % 4 != 0 -- element-wise tile loads, a kernel that spills as it is -- keeps the old order: slab sum, then the tile)
+    constexpr bool EARLY = VEC4;
+    segmask_t mask = 0;
+    float ua[HALF];
+    // den = F_tile (all k columns, A layout) x G[:, this column tile] on the f32 MFMA; the old values of this
+    // column tile (C/D layout) and, V side, the position map
+    auto load_tile = [&]() {
       load_tile_a_layout<NT, VEC4>(a.F, a.rows, k, row0, lane, ua);
 #pragma unroll
       for (int i = 0; i < 16; ++i) fv[i] = Ft[cd_off(i)];
@@ -817,6 +789,8 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) ps[i] = pt[cd_off(i)];
       }
+    };
+    auto chain = [&]() {
 #pragma unroll
       for (int s2 = 0; s2 < HALF; ++s2)
         den = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[s2], Gs[(s2 + HALF * h) * KP + 32 * t + r], den, 0, 0, 0);
@@ -827,6 +801,61 @@ epilogue_cs_kernel(const EpiArgs a, const GraphJob gj) {
           gn[i] = a.gnum[goff];
           gd[i] = a.gden[goff];
         }
+      }
+    };
+    if (live) {
+      if constexpr (!DENSE) mask = a.segmask[row0 / a.panel_rows];
+      if constexpr (EARLY) load_tile();
+      if constexpr (DENSE) {
+        const float* const Qt = a.slabs + row0 * k;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) q[i] = Qt[cd_off(i)];
+      }
+    }
+    if (live) {
+      // this wave's column tile of the slab segments, in slab-index order, 4 segments per round trip
+      const int64_t fbase = (tile * NT + t) * 256 + lane;         // float4 index of (tile, t, q4 = 0, lane)
+      float4 v[4][4];
+      float on[4];
+      auto issue = [&]() {
+        int sg[4];
+        const int first = __ffsll((long long)mask) - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sg[j] = mask ? __ffsll((long long)mask) - 1 : first;
+          on[j] = mask ? 1.f : 0.f;
+          mask &= mask - 1;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4* sl = reinterpret_cast<const float4*>(a.slabs + (int64_t)sg[j] * a.slab_stride) + fbase;
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) v[j][q4] = sl[q4 * 64];
+        }
+      };
+      auto add = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            q[4 * q4] += on[j] * v[j][q4].x;
+            q[4 * q4 + 1] += on[j] * v[j][q4].y;
+            q[4 * q4 + 2] += on[j] * v[j][q4].z;
+            q[4 * q4 + 3] += on[j] * v[j][q4].w;
+          }
+      };
+      // (the first batch requested before the chain, to travel under it, spills on both sides: measured in registers only)
+      if constexpr (EARLY) chain();
+      if constexpr (!DENSE) {
+        while (mask) {
+          issue();
+          add();
+        }
+      }
+      if (a.stamps) { float t_ = 0.f; for (int i = 0; i < 16; ++i) t_ += q[i]; if (t_ == 1.2345e-33f) vn[0] = t_; EPI_STAMP(2); }
+      if constexpr (!EARLY) {
+        load_tile();
+        chain();
       }
     }
     if (a.stamps) { float t_ = 0.f; for (int i = 0; i < 16; ++i) t_ += den[i]; if (t_ == 1.2345e-33f) vn[1] = t_; EPI_STAMP(3); }
