@@ -764,16 +764,30 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
         # matrix chunk by chunk under its own PCIe copy); what does not need X yet runs under it: the reference's random
         # draws (:651-653: the ORDER of the draws is the contract, not when they happen) and the pathway library (:670-696)
         pending = engine.set_x_async(X.rows(lo, hi) if hasattr(X, "rows") else X[lo:hi])
+        if "scipy.optimize" not in sys.modules:
+            # the matching at the end of the candidate rounds needs scipy.optimize (171 modules, 35-40 ms in a fresh process: every
+            # command-line run): imported on a thread of its own it runs while this one waits, interpreter lock released, for the
+            # upload and for the first batches of iterations
+            import threading
+            threading.Thread(target=__import__, args=("scipy.optimize",), name="prmf-import", daemon=True).start()
         early = None
         try:
             # rank 0's factors are THE factors, drawn here (:651-653) or handed in: every rank takes rank 0's (a caller's
             # per-rank initialisers need not agree, e.g. set iteration order under different hash seeds); as tensors
             given = ranks.from_rank0((U_init is not None, V_init is not None)) if ranks.multi else (U_init is not None, V_init is not None)
             if ranks.rank == 0 or not ranks.multi:
+                # 3 * (1 - rand(..))  (:651-653), written with explicit outputs: as one expression numpy asks, for each of its two
+                # temporaries, whether it may reuse it in place -- a check that walks the C stack (glibc backtrace), and the first
+                # walk of a process with torch and the ROCm libraries loaded costs 80 ms (profiles/r06_first_call.txt; every
+                # command-line run is a first call).  The same two operations per element, the same values.
                 if not given[0]:
-                    U_init = 3 * (1 - np.random.rand(m, k_latent))
+                    U_init = np.random.rand(m, k_latent)
+                    np.subtract(1, U_init, out=U_init)
+                    np.multiply(3, U_init, out=U_init)
                 if not given[1]:
-                    V_init = 3 * (1 - np.random.rand(n, k_latent))
+                    V_init = np.random.rand(n, k_latent)
+                    np.subtract(1, V_init, out=V_init)
+                    np.multiply(3, V_init, out=V_init)
             if library is None:
                 try:
                     library = PathwayLibrary.from_graphs(Gs, nodelist)    # :670-696
