@@ -769,7 +769,7 @@ def nmf_pathway(X, Gs, gamma=1.0, delta=1.0, tradeoff=None, k_latent=6, tol=1e-3
             # command-line run): imported on a thread of its own it runs while this one waits, interpreter lock released, for the
             # upload and for the first batches of iterations
             import threading
-            threading.Thread(target=__import__, args=("scipy.optimize",), name="prmf-import", daemon=True).start()
+            threading.Thread(target=__import__, args=("scipy.optimize",), name="prmf-import").start()      # (not a daemon: never cut off mid-import at exit)
         early = None
         try:
             # rank 0's factors are THE factors, drawn here (:651-653) or handed in: every rank takes rank 0's (a caller's
