@@ -65,4 +65,7 @@ def test_bench_line_contract():
     sh = sec["c4_share_of_8"]
     assert "6250 rows" in sh["workload"] and sh["speedup_bound_before_exchanges"] is None          # (no c3 headline in this run to divide by)
     assert sum(sh["sweep_ms"]) < sh["ms_per_iteration_device"] and abs(sh["other_kernels_ms"] - (sh["ms_per_iteration_device"] - sum(sh["sweep_ms"]))) < 1e-9
+    # the stand-in copies, timed alone, are not part of the kernels' figure
+    assert 0 < sh["stand_in_copies_ms"] < 0.05 and abs(sh["ms_per_iteration_kernels"] - (sh["ms_per_iteration_device"] - sh["stand_in_copies_ms"])) < 1e-12
+    assert abs(sh["iteration_frac"] - (2.0 * 6250 * 20000 * 2 + 12.0 * (6250 + 20000) * 64) / (sh["ms_per_iteration_kernels"] * 1e-3) / 1e9 / 8000.0) < 1e-9
     assert abs(sh["sweep_hbm_frac"] - (6250 * 20000 * 2 + 2.0 * (20000 + 6250) * 64) / (0.5e-3 * sum(sh["sweep_ms"])) / 1e9 / 8000.0) < 1e-9
