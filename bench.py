@@ -113,7 +113,7 @@ def parse():
                     help="skip the measurements next to the headline: pure-stream calibration, update-only rate, outer loop")
     ap.add_argument("--secondary", default="auto",
                     help="the other BASELINE workloads measured after the headline and reported under `secondary`: a comma list of "
-                         "c2, c3f32, c5, c4_share_of_8, c5_share_of_8; `auto` (default): all of them after the c3 headline, none "
+                         "c2, c3f32, c5, c4_share_of_2, c4_share_of_4, c4_share_of_8, c5_share_of_8; `auto` (default): all of them after the c3 headline, none "
                          "after another workload; `none`")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--cpu-baseline-size", default="auto", choices=["auto", "full", "sample"],
@@ -437,14 +437,22 @@ def secondary_workloads(torch, args, c3_ms, names):
         except Exception as e:        # a workload that does not fit this box must not take the headline line with it
             out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
-    for name, whole, label in (("c3", c3_ms, "c4_share_of_8"), ("c5", out.get("c5", {}).get("ms_per_step"), "c5_share_of_8")):
+    # one rank's share of the N-rank partitions of C3 (N = 2, 4, 8 = C4) and of C5 (N = 8): what a single GPU can say about the
+    # scaling curve -- the kernels of a rank at the real share shape, before any exchange
+    for name, whole, label, nr in (("c3", c3_ms, "c4_share_of_2", 2), ("c3", c3_ms, "c4_share_of_4", 4), ("c3", c3_ms, "c4_share_of_8", 8),
+                                   ("c5", out.get("c5", {}).get("ms_per_step"), "c5_share_of_8", 8)):
         if label not in names:
             continue
         try:
-            out[label] = measure_share(torch, name, 8, args.seed, 30, whole)
+            out[label] = measure_share(torch, name, nr, args.seed, 30, whole)
         except Exception as e:
             out[label] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
+    if c3_ms:
+        curve = {str(nr): out[lb]["speedup_bound_before_exchanges"] for lb, nr in (("c4_share_of_2", 2), ("c4_share_of_4", 4), ("c4_share_of_8", 8))
+                 if lb in out and "error" not in out[lb]}
+        if curve:
+            out["c3_scaling_bound_before_exchanges"] = dict({"1": 1.0}, **curve)
     return out
 
 
@@ -601,7 +609,7 @@ def run_rank(args, ranks, proc):
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, Xd, U0, V0, pathways, active, gamma, delta, m, args.cpu_seconds, args.cpu_baseline_size)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        names = {"auto": ["c2", "c3f32", "c5", "c4_share_of_8", "c5_share_of_8"] if (args.workload == "c3" and not args.no_extras) else [],
+        names = {"auto": ["c2", "c3f32", "c5", "c4_share_of_2", "c4_share_of_4", "c4_share_of_8", "c5_share_of_8"] if (args.workload == "c3" and not args.no_extras) else [],
                  "none": []}.get(args.secondary, [x for x in args.secondary.split(",") if x])
         if names:
             del Xd, U, V, U0, V0
